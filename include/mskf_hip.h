@@ -1,0 +1,147 @@
+/* mskf_hip.h — C ABI of the MI355X (gfx950) hot path: stereo KLT front-end + MSCKF measurement update.
+ *
+ * This is the drop-in boundary: the host-side C++ mirror of the reference classes
+ * (msckf_stereo_c_amd/csrc/host/: cg::ImageProcessor, cg::MsckfVio, cg::System) calls ONLY these
+ * entry points; a maintainer of the reference would bind the same symbols from
+ * msckf_core/src/image_processor.cpp and msckf_core/src/msckf_vio.cpp.
+ *
+ * Conventions: plain pointers and sizes, no C++ / torch types; every function returns MSKF_OK (0)
+ * or a negative mskf_status and never throws; the caller owns all host buffers; device buffers are
+ * owned by the handles; calls on one mskf_ctx are serialised by the caller, different contexts may be
+ * driven from different host threads.  One mskf_ctx = one HIP stream on one GPU plus the batch
+ * staging buffers; one mskf_stream = one VIO stream (one ImageProcessor + one MsckfVio state).
+ * The *_batch entry points process one frame of many VIO streams per kernel launch; the single
+ * stream entry points are batches of one.
+ *
+ * There is no CPU fallback: every compute entry point fails with MSKF_ERR_NO_DEVICE / MSKF_ERR_HIP
+ * when no gfx950 device or code object is available.
+ */
+#ifndef MSKF_HIP_H
+#define MSKF_HIP_H
+
+#include "mskf_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mskf_status {
+    MSKF_OK = 0,
+    MSKF_ERR_INVALID = -1,      /* bad argument */
+    MSKF_ERR_HIP = -2,          /* a HIP runtime call failed (mskf_last_error() has the text) */
+    MSKF_ERR_UNSUPPORTED = -3,  /* e.g. equidistant distortion model on the device path */
+    MSKF_ERR_CAPACITY = -4,     /* more points / clones / rows than the stream was created for */
+    MSKF_ERR_NO_DEVICE = -5
+} mskf_status;
+
+typedef struct mskf_ctx mskf_ctx;
+typedef struct mskf_stream mskf_stream;
+
+const char *mskf_last_error(void);
+int mskf_abi_version(void);
+
+int mskf_ctx_create(int device, mskf_ctx **out);
+void mskf_ctx_destroy(mskf_ctx *ctx);
+int mskf_ctx_sync(mskf_ctx *ctx);
+/* the HIP stream of this context as a void* (hipStream_t), for event timing by the caller */
+void *mskf_ctx_hip_stream(mskf_ctx *ctx);
+
+int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
+                       mskf_stream **out);
+void mskf_stream_destroy(mskf_stream *s);
+
+/* ------------------------------------------------------------------ front-end
+ * Replaces, inside cg::ImageProcessor::stereoCallback (image_processor.cpp:139-203):
+ *   createImagePyramids()              :213-245  -> mskf_fe_push_stereo*   (pyramids of cam0/cam1 in HBM)
+ *   detector_.detect_features()        :259,:657 -> mskf_fe_push_stereo*   (per-cell maxima) + mskf_fe_get_cell_maxima
+ *   predictFeatureTracking + optical_flow_multi_level + stereoMatch  :389-463 -> mskf_fe_track (do_temporal = 1)
+ *   stereoMatch of new candidates      :268,:688 -> mskf_fe_track (do_temporal = 0)
+ *   std::swap(prev pyramid, curr pyramid) :194   -> mskf_fe_swap
+ */
+
+/* Upload one stereo pair (host memory, row pitch in bytes), build the 4-level pyramids of both
+ * cameras and the detector's per-cell maxima of cam0 level 0.  Asynchronous on the context stream. */
+int mskf_fe_push_stereo(mskf_stream *s, const uint8_t *cam0, const uint8_t *cam1, int width, int height, int pitch,
+                        double time_stamp);
+/* Same with the images already resident in device memory (dense, pitch == width). */
+int mskf_fe_push_stereo_device(mskf_stream *s, const uint8_t *d_cam0, const uint8_t *d_cam1, int width, int height,
+                               double time_stamp);
+int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
+                              const uint8_t *const *cam1, int on_device);
+
+/* All det_rows*det_cols per-cell maxima of the last pushed cam0 image (score 0 = no corner). Synchronises. */
+int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out);
+
+typedef struct mskf_fe_track_args {
+    int32_t n;                    /* number of points */
+    int32_t do_temporal;          /* 1: prev cam0 -> curr cam0 LK, then stereo; 0: stereo only */
+    const mskf_point2f *in_pts;   /* prev cam0 points (temporal) or curr cam0 points (stereo only) */
+    double Hpred[9];              /* K R_p_c K^-1 (image_processor.cpp:335-340); identity-like under Q2 */
+    mskf_point2f *out0, *out1;    /* tracked cam0 / matched cam1 pixels */
+    mskf_point2f *und0, *und1;    /* undistorted normalised coordinates of out0 / out1 */
+    uint8_t *status;              /* bit0 temporal ok, bit1 stereo inlier */
+} mskf_fe_track_args;
+
+int mskf_fe_track(mskf_stream *s, const mskf_fe_track_args *args);
+int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args);
+
+/* curr cam0 pyramid becomes the prev pyramid (image_processor.cpp:194) */
+int mskf_fe_swap(mskf_stream *s);
+
+/* download pyramid level `level` (0..3) of image role 0: prev cam0, 1: curr cam0, 2: curr cam1 (parity tests) */
+int mskf_fe_get_level(mskf_stream *s, int role, int level, uint8_t *out, int capacity, int *w, int *h);
+
+/* ------------------------------------------------------------------ EKF (covariance resident in HBM)
+ * Replaces, inside cg::MsckfVio (msckf_vio.cpp):
+ *   state_cov part of processModel     :458-469  -> mskf_ekf_propagate
+ *   state_cov part of stateAugmentation :564-582 -> mskf_ekf_augment
+ *   Feature::initializePosition        feature.hpp:289-450 -> inside mskf_ekf_update (needs_init)
+ *   featureJacobian / measurementJacobian / gatingTest / stacking / measurementUpdate
+ *                                      :610-935, :986-1017, :1124-1159 -> mskf_ekf_update
+ *   clone row/column deletion          :1161-1181 -> mskf_ekf_remove_clone
+ *   covariance reset                   :102-112, :1222-1232 -> mskf_ekf_reset
+ */
+typedef struct mskf_clone_state {   /* CAMState, common/cam_state.h:25-55 */
+    double q[4], p[3], q_null[4], p_null[3];
+} mskf_clone_state;
+
+typedef struct mskf_ekf_feature {   /* one feature of an update */
+    int32_t obs_start, n_obs;       /* range in the observation arrays */
+    int32_t needs_init;             /* 1: triangulate from ALL its observations listed in init_* first */
+    int32_t init_start, n_init;     /* observation range used for triangulation (all of the feature's obs) */
+    int32_t _pad;
+    double position[3];             /* in: world position if !needs_init; out: triangulated position */
+} mskf_ekf_feature;
+
+typedef struct mskf_ekf_update_args {
+    int32_t n_clones;
+    int32_t n_feat;
+    int32_t n_obs;
+    int32_t dof_offset;             /* gating dof = n_obs_j + dof_offset: -1 lost features, 0 pruning (Q12) */
+    int32_t apply_row_cap;          /* 1: stop stacking once rows > max_stack_rows (removeLostFeatures only, Q13) */
+    int32_t _pad;
+    double gravity[3];
+    const mskf_clone_state *clones; /* n_clones, in state order */
+    mskf_ekf_feature *features;     /* in/out: position, and status in `feat_status` */
+    const int32_t *obs_clone;       /* n_obs: clone index of each observation */
+    const double *obs_z;            /* n_obs x 4: u0 v0 u1 v1 */
+    double *delta_x;                /* out: 21 + 6 n_clones */
+    uint8_t *feat_status;           /* out per feature: bit0 triangulation valid, bit1 gating passed (stacked) */
+    double *gamma;                  /* out per feature (may be NULL): Mahalanobis gate value */
+    int32_t *rows_out;              /* out: number of stacked rows (0 => no update applied) */
+} mskf_ekf_update_args;
+
+int mskf_ekf_reset(mskf_stream *s, const double *P0 /* 21x21 row-major */);
+int mskf_ekf_propagate(mskf_stream *s, int n_steps, const double *Phi /* n x 21x21 */, const double *Q /* n x 21x21 */);
+int mskf_ekf_augment(mskf_stream *s, const double *J /* 6x21 */);
+int mskf_ekf_update(mskf_stream *s, mskf_ekf_update_args *args);
+int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args);
+int mskf_ekf_remove_clone(mskf_stream *s, int clone_index);
+int mskf_ekf_get_dim(mskf_stream *s, int *d);
+int mskf_ekf_get_cov(mskf_stream *s, double *P, int capacity /* doubles */);
+int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSKF_HIP_H */

@@ -1,0 +1,362 @@
+// mskf_capi_ekf.cpp — C-ABI: EKF entry points (include/mskf_hip.h).  The covariance lives in HBM;
+// the host passes small per-frame descriptors (Phi/Q sequence, J, clone states, observation lists).
+#include <algorithm>
+#include <cstring>
+#include "../../../include/mskf_chi2_table.h"
+#include "mskf_internal.h"
+
+extern "C" {
+void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st);
+void ekf_launch_update(const EkfStreamDev *d, int n, int max_feat, int max_m, int max_d, hipStream_t st);
+}
+
+namespace {
+constexpr int kMaxClonesDev = 64;   // MAX_CLONES_DEV in ekf_kernels.hip
+constexpr int kMaxRows = 6000;      // LDS-resident Householder vector in k_ekf_qr
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int dev_alloc(double **p, size_t n) {
+    MSKF_HIPCHK(hipMalloc((void **)p, n * sizeof(double)));
+    MSKF_HIPCHK(hipMemset(*p, 0, n * sizeof(double)));
+    return MSKF_OK;
+}
+
+// a pinned host arena with a device twin and an event guarding reuse of the host side
+int arena_ensure(char **h, char **d, size_t *cap, size_t need) {
+    if (need <= *cap) return MSKF_OK;
+    if (*h) (void)hipHostFree(*h);
+    if (*d) (void)hipFree(*d);
+    *h = *d = nullptr; *cap = 0;
+    const size_t c = align_up(need + need / 2, 4096);
+    MSKF_HIPCHK(hipHostMalloc((void **)h, c, hipHostMallocDefault));
+    MSKF_HIPCHK(hipMalloc((void **)d, c));
+    *cap = c;
+    return MSKF_OK;
+}
+}  // namespace
+
+struct EkfExtra {  // lives behind EkfStreamState via the stream (kept out of the device header)
+    double *P_alt = nullptr;          // ping-pong target of clone removal
+    char *h_small = nullptr, *d_small = nullptr;   // Phi/Q sequence, J
+    size_t small_cap = 0;
+    hipEvent_t small_done = nullptr;
+    bool small_pending = false;
+};
+static EkfExtra *extra_of(mskf_stream *s) { return (EkfExtra *)s->ekf_extra; }
+
+int mskf_ekf_stream_init(mskf_stream *s) {
+    EkfStreamState &E = s->ekf_state;
+    E.max_clones = s->ekf.max_cam_state_size;
+    if (E.max_clones < 4 || E.max_clones > kMaxClonesDev) {
+        mskf_set_error("max_cam_state_size must be in [4, 64]");
+        return MSKF_ERR_UNSUPPORTED;
+    }
+    E.ld = (int)align_up((size_t)(EKF_IMU_DIM + 6 * E.max_clones), 8);
+    E.d = EKF_IMU_DIM;
+    E.nmax = 4 * E.max_clones;
+    int rc;
+    const size_t pl = (size_t)E.ld * E.ld;
+    if ((rc = dev_alloc(&E.P, pl)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.T, pl)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.S, pl)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.gate_T, (size_t)EKF_SLOTS * E.nmax * E.ld)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.chi2, 128)) != MSKF_OK) return rc;
+    double tab[100];
+    tab[0] = 0.0;
+    for (int i = 1; i < 100; ++i) tab[i] = s->ekf.chi2_mode == 1 ? mskf_chi2_ppf95[i - 1] : mskf_chi2_ppf05[i - 1];  // msckf_vio.cpp:181-185
+    MSKF_HIPCHK(hipMemcpy(E.chi2, tab, sizeof(tab), hipMemcpyHostToDevice));
+    EkfExtra *X = new EkfExtra();
+    s->ekf_extra = X;
+    if ((rc = dev_alloc(&X->P_alt, pl)) != MSKF_OK) return rc;
+    MSKF_HIPCHK(hipEventCreateWithFlags(&X->small_done, hipEventDisableTiming));
+    return MSKF_OK;
+}
+
+void mskf_ekf_stream_free(mskf_stream *s) {
+    EkfStreamState &E = s->ekf_state;
+    double *ptrs[] = {E.P, E.T, E.S, E.gate_T, E.gate_S, E.chi2, E.Hs, E.rs};
+    for (double *p : ptrs) if (p) (void)hipFree(p);
+    if (E.h_arena) (void)hipHostFree(E.h_arena);
+    if (E.d_arena) (void)hipFree(E.d_arena);
+    if (E.h_out) (void)hipHostFree(E.h_out);
+    if (E.d_out) (void)hipFree(E.d_out);
+    if (EkfExtra *X = extra_of(s)) {
+        if (X->P_alt) (void)hipFree(X->P_alt);
+        if (X->h_small) (void)hipHostFree(X->h_small);
+        if (X->d_small) (void)hipFree(X->d_small);
+        if (X->small_done) (void)hipEventDestroy(X->small_done);
+        delete X;
+        s->ekf_extra = nullptr;
+    }
+}
+
+static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
+    std::memset(&D, 0, sizeof(D));
+    const EkfStreamState &E = s->ekf_state;
+    D.P = E.P; D.d = E.d; D.ld = E.ld;
+    D.sigma2 = s->ekf.noise_feature * s->ekf.noise_feature;   // msckf_vio.cpp:74,81
+    D.max_stack_rows = s->ekf.max_stack_rows;
+    D.chi2 = E.chi2;
+    D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.gate_T = E.gate_T; D.gate_S = E.gate_S; D.nmax = E.nmax;
+    hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
+    std::memcpy(D.R_c0_c1, T01.R.m, sizeof(D.R_c0_c1));
+    for (int i = 0; i < 3; ++i) D.t_c0_c1[i] = T01.t[i];
+}
+
+static int small_begin(mskf_stream *s, EkfExtra *X, size_t bytes) {
+    if (X->small_pending) { MSKF_HIPCHK(hipEventSynchronize(X->small_done)); X->small_pending = false; }
+    if (bytes > X->small_cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+        int rc = arena_ensure(&X->h_small, &X->d_small, &X->small_cap, bytes);
+        if (rc != MSKF_OK) return rc;
+    }
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_reset(mskf_stream *s, const double *P0) {
+    if (!s || !P0) return MSKF_ERR_INVALID;
+    EkfStreamState &E = s->ekf_state;
+    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipMemset(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld));
+    MSKF_HIPCHK(hipMemcpy2D(E.P, sizeof(double) * E.ld, P0, sizeof(double) * EKF_IMU_DIM, sizeof(double) * EKF_IMU_DIM, EKF_IMU_DIM,
+                            hipMemcpyHostToDevice));
+    E.d = EKF_IMU_DIM;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d) {
+    if (!s || !P) return MSKF_ERR_INVALID;
+    EkfStreamState &E = s->ekf_state;
+    if (d < EKF_IMU_DIM || (d - EKF_IMU_DIM) % 6 || d > EKF_IMU_DIM + 6 * E.max_clones) return MSKF_ERR_CAPACITY;
+    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipMemset(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld));
+    MSKF_HIPCHK(hipMemcpy2D(E.P, sizeof(double) * E.ld, P, sizeof(double) * d, sizeof(double) * d, d, hipMemcpyHostToDevice));
+    E.d = d;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_get_dim(mskf_stream *s, int *d) {
+    if (!s || !d) return MSKF_ERR_INVALID;
+    *d = s->ekf_state.d;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_get_cov(mskf_stream *s, double *P, int capacity) {
+    if (!s || !P) return MSKF_ERR_INVALID;
+    EkfStreamState &E = s->ekf_state;
+    if (capacity < E.d * E.d) return MSKF_ERR_CAPACITY;
+    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipMemcpy2D(P, sizeof(double) * E.d, E.P, sizeof(double) * E.ld, sizeof(double) * E.d, E.d, hipMemcpyDeviceToHost));
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_propagate(mskf_stream *s, int n_steps, const double *Phi, const double *Q) {
+    if (!s || n_steps < 0 || (n_steps && (!Phi || !Q))) return MSKF_ERR_INVALID;
+    if (n_steps == 0) return MSKF_OK;
+    EkfExtra *X = extra_of(s);
+    mskf_ctx *ctx = s->ctx;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    const size_t nn = EKF_IMU_DIM * EKF_IMU_DIM;
+    const size_t bytes = sizeof(double) * 2 * nn * (size_t)n_steps + sizeof(EkfStreamDev);
+    int rc = small_begin(s, X, bytes);
+    if (rc != MSKF_OK) return rc;
+    EkfStreamDev *D = (EkfStreamDev *)X->h_small;
+    double *pq = (double *)(X->h_small + sizeof(EkfStreamDev));
+    for (int k = 0; k < n_steps; ++k) {
+        std::memcpy(pq + (size_t)k * 2 * nn, Phi + (size_t)k * nn, sizeof(double) * nn);
+        std::memcpy(pq + (size_t)k * 2 * nn + nn, Q + (size_t)k * nn, sizeof(double) * nn);
+    }
+    base_desc(s, *D);
+    D->PhiQ = (const double *)(X->d_small + sizeof(EkfStreamDev));
+    D->n_steps = n_steps;
+    MSKF_HIPCHK(hipMemcpyAsync(X->d_small, X->h_small, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
+    X->small_pending = true;
+    ekf_launch_propagate((const EkfStreamDev *)X->d_small, 1, ctx->stream);
+    MSKF_HIPCHK(hipGetLastError());
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {
+    if (!s || !J) return MSKF_ERR_INVALID;
+    EkfStreamState &E = s->ekf_state;
+    if (E.d + 6 > EKF_IMU_DIM + 6 * E.max_clones) { mskf_set_error("clone capacity exceeded"); return MSKF_ERR_CAPACITY; }
+    EkfExtra *X = extra_of(s);
+    mskf_ctx *ctx = s->ctx;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    // the augment descriptor lives after a possible propagate descriptor: use a second region of the small arena
+    const size_t off = 0;
+    const size_t bytes = sizeof(EkfStreamDev) + sizeof(double) * 6 * EKF_IMU_DIM;
+    int rc = small_begin(s, X, bytes);
+    if (rc != MSKF_OK) return rc;
+    EkfStreamDev *D = (EkfStreamDev *)(X->h_small + off);
+    base_desc(s, *D);
+    std::memcpy(X->h_small + off + sizeof(EkfStreamDev), J, sizeof(double) * 6 * EKF_IMU_DIM);
+    D->J = (const double *)(X->d_small + off + sizeof(EkfStreamDev));
+    MSKF_HIPCHK(hipMemcpyAsync(X->d_small + off, X->h_small + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
+    X->small_pending = true;
+    ekf_launch_augment((const EkfStreamDev *)(X->d_small + off), 1, ctx->stream);
+    MSKF_HIPCHK(hipGetLastError());
+    E.d += 6;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
+    if (!s) return MSKF_ERR_INVALID;
+    EkfStreamState &E = s->ekf_state;
+    const int n_clones = (E.d - EKF_IMU_DIM) / 6;
+    if (clone_index < 0 || clone_index >= n_clones) return MSKF_ERR_INVALID;
+    EkfExtra *X = extra_of(s);
+    mskf_ctx *ctx = s->ctx;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(EkfStreamDev) + sizeof(double *);
+    int rc = small_begin(s, X, bytes);
+    if (rc != MSKF_OK) return rc;
+    EkfStreamDev *D = (EkfStreamDev *)X->h_small;
+    base_desc(s, *D);
+    D->remove_index = clone_index;
+    *(double **)(X->h_small + sizeof(EkfStreamDev)) = X->P_alt;
+    MSKF_HIPCHK(hipMemcpyAsync(X->d_small, X->h_small, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
+    X->small_pending = true;
+    ekf_launch_remove_clone((const EkfStreamDev *)X->d_small, (double *const *)(X->d_small + sizeof(EkfStreamDev)), 1, ctx->stream);
+    MSKF_HIPCHK(hipGetLastError());
+    std::swap(E.P, X->P_alt);
+    E.d -= 6;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args) {
+    if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ctx->ekf_desc.ensure(n);
+    if (rc != MSKF_OK) return rc;
+    int max_feat = 0, max_m = 0, max_d = 0;
+    struct Lay { size_t clones, feats, obs_clone, obs_z, total; size_t o_dx, o_gamma, o_rows, o_status, o_total; int m_total; };
+    std::vector<Lay> lay(n);
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        mskf_ekf_update_args &a = args[i];
+        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
+        EkfStreamState &E = s->ekf_state;
+        if (a.n_clones * 6 + EKF_IMU_DIM != E.d) { mskf_set_error("n_clones does not match the covariance dimension"); return MSKF_ERR_INVALID; }
+        if (a.n_feat < 0 || a.n_obs < 0) return MSKF_ERR_INVALID;
+        if (a.n_feat && (!a.clones || !a.features || !a.obs_clone || !a.obs_z || !a.delta_x || !a.feat_status || !a.rows_out)) return MSKF_ERR_INVALID;
+        Lay &L = lay[i];
+        int m_total = 0;
+        for (int j = 0; j < a.n_feat; ++j) {
+            const mskf_ekf_feature &f = a.features[j];
+            if (f.n_obs < 2 || f.n_obs > E.max_clones || f.obs_start < 0 || f.obs_start + f.n_obs > a.n_obs) return MSKF_ERR_INVALID;
+            if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
+            m_total += 4 * f.n_obs - 3;
+        }
+        if (m_total > kMaxRows) { mskf_set_error("stacked Jacobian exceeds the row capacity"); return MSKF_ERR_CAPACITY; }
+        L.m_total = m_total;
+        L.clones = 0;
+        L.feats = align_up(L.clones + sizeof(mskf_clone_state) * (size_t)a.n_clones, 16);
+        L.obs_clone = align_up(L.feats + sizeof(EkfFeatDev) * (size_t)a.n_feat, 16);
+        L.obs_z = align_up(L.obs_clone + sizeof(int) * (size_t)a.n_obs, 16);
+        L.total = align_up(L.obs_z + sizeof(double) * 4 * (size_t)a.n_obs, 16);
+        L.o_dx = 0;
+        L.o_gamma = align_up(sizeof(double) * (size_t)E.ld, 16);
+        L.o_rows = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
+        L.o_status = L.o_rows + 16;
+        L.o_total = align_up(L.o_status + (size_t)a.n_feat, 16);
+        if (L.total > E.arena_bytes || L.o_total > E.out_bytes || m_total > E.max_rows) {
+            MSKF_HIPCHK(hipStreamSynchronize(st));
+            if ((rc = arena_ensure(&E.h_arena, &E.d_arena, &E.arena_bytes, L.total)) != MSKF_OK) return rc;
+            if ((rc = arena_ensure(&E.h_out, &E.d_out, &E.out_bytes, L.o_total)) != MSKF_OK) return rc;
+            if (m_total > E.max_rows) {
+                if (E.Hs) (void)hipFree(E.Hs);
+                if (E.rs) (void)hipFree(E.rs);
+                E.Hs = E.rs = nullptr;
+                const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
+                if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld)) != MSKF_OK) return rc;
+                if ((rc = dev_alloc(&E.rs, (size_t)cap)) != MSKF_OK) return rc;
+                E.max_rows = cap;
+            }
+        }
+        // pack
+        if (a.n_clones) std::memcpy(E.h_arena + L.clones, a.clones, sizeof(mskf_clone_state) * (size_t)a.n_clones);
+        EkfFeatDev *fd = (EkfFeatDev *)(E.h_arena + L.feats);
+        int row = 0;
+        for (int j = 0; j < a.n_feat; ++j) {
+            const mskf_ekf_feature &f = a.features[j];
+            fd[j].obs_start = f.obs_start; fd[j].n_obs = f.n_obs;
+            fd[j].needs_init = f.needs_init; fd[j].init_start = f.init_start; fd[j].n_init = f.n_init;
+            fd[j].row_off = row;
+            fd[j].position[0] = f.position[0]; fd[j].position[1] = f.position[1]; fd[j].position[2] = f.position[2];
+            row += 4 * f.n_obs - 3;
+        }
+        if (a.n_obs) {
+            std::memcpy(E.h_arena + L.obs_clone, a.obs_clone, sizeof(int) * (size_t)a.n_obs);
+            std::memcpy(E.h_arena + L.obs_z, a.obs_z, sizeof(double) * 4 * (size_t)a.n_obs);
+        }
+        EkfStreamDev &D = ctx->ekf_desc.h[i];
+        base_desc(s, D);
+        D.n_clones = a.n_clones; D.n_feat = a.n_feat; D.n_obs = a.n_obs;
+        D.dof_offset = a.dof_offset; D.apply_row_cap = a.apply_row_cap;
+        D.m_total = m_total;
+        for (int k = 0; k < 3; ++k) D.gravity[k] = a.gravity[k];
+        D.clones = (const mskf_clone_state *)(E.d_arena + L.clones);
+        D.feats = (EkfFeatDev *)(E.d_arena + L.feats);
+        D.obs_clone = (const int *)(E.d_arena + L.obs_clone);
+        D.obs_z = (const double *)(E.d_arena + L.obs_z);
+        D.delta_x = (double *)(E.d_out + L.o_dx);
+        D.gamma = (double *)(E.d_out + L.o_gamma);
+        D.rows_out = (int *)(E.d_out + L.o_rows);
+        D.feat_status = (uint8_t *)(E.d_out + L.o_status);
+        if (L.total) MSKF_HIPCHK(hipMemcpyAsync(E.d_arena, E.h_arena, L.total, hipMemcpyHostToDevice, st));
+        MSKF_HIPCHK(hipMemsetAsync(E.d_out, 0, L.o_total, st));
+        max_feat = std::max(max_feat, a.n_feat);
+        max_m = std::max(max_m, m_total);
+        max_d = std::max(max_d, E.d);
+    }
+    if (max_feat > 0) {
+        MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+        ekf_launch_update(ctx->ekf_desc.d, n, max_feat, max_m, max_d, st);
+        MSKF_HIPCHK(hipGetLastError());
+    }
+    for (int i = 0; i < n; ++i) {
+        EkfStreamState &E = streams[i]->ekf_state;
+        const Lay &L = lay[i];
+        if (!args[i].n_feat) continue;
+        MSKF_HIPCHK(hipMemcpyAsync(E.h_out, E.d_out, L.o_total, hipMemcpyDeviceToHost, st));
+        MSKF_HIPCHK(hipMemcpyAsync(E.h_arena + L.feats, E.d_arena + L.feats, sizeof(EkfFeatDev) * (size_t)args[i].n_feat, hipMemcpyDeviceToHost, st));
+    }
+    MSKF_HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        mskf_ekf_update_args &a = args[i];
+        EkfStreamState &E = streams[i]->ekf_state;
+        const Lay &L = lay[i];
+        const int d = E.d;
+        if (!a.n_feat) {
+            if (a.delta_x) std::memset(a.delta_x, 0, sizeof(double) * (size_t)d);
+            if (a.rows_out) *a.rows_out = 0;
+            continue;
+        }
+        std::memcpy(a.delta_x, E.h_out + L.o_dx, sizeof(double) * (size_t)d);
+        if (a.gamma) std::memcpy(a.gamma, E.h_out + L.o_gamma, sizeof(double) * (size_t)a.n_feat);
+        *a.rows_out = ((const int *)(E.h_out + L.o_rows))[0];
+        std::memcpy(a.feat_status, E.h_out + L.o_status, (size_t)a.n_feat);
+        const EkfFeatDev *fd = (const EkfFeatDev *)(E.h_arena + L.feats);
+        for (int j = 0; j < a.n_feat; ++j)
+            for (int k = 0; k < 3; ++k) a.features[j].position[k] = fd[j].position[k];
+    }
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_update(mskf_stream *s, mskf_ekf_update_args *args) {
+    if (!s || !args) return MSKF_ERR_INVALID;
+    mskf_stream *ss[1] = {s};
+    return mskf_ekf_update_batch(s->ctx, 1, ss, args);
+}

@@ -1,0 +1,326 @@
+// mskf_capi_fe.cpp — C-ABI: contexts, streams and the front-end entry points (include/mskf_hip.h).
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include "mskf_internal.h"
+
+static thread_local std::string g_last_error;
+void mskf_set_error(const std::string &s) { g_last_error = s; }
+
+extern "C" const char *mskf_last_error(void) { return g_last_error.c_str(); }
+extern "C" int mskf_abi_version(void) { return 1; }
+
+extern "C" int mskf_ctx_create(int device, mskf_ctx **out) {
+    if (!out) return MSKF_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        mskf_set_error("no HIP device visible (this library has no CPU fallback)");
+        return MSKF_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { mskf_set_error("device index out of range"); return MSKF_ERR_INVALID; }
+    MSKF_HIPCHK(hipSetDevice(device));
+    mskf_ctx *c = new mskf_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; mskf_set_error(hipGetErrorString(e)); return MSKF_ERR_HIP; }
+    *out = c;
+    return MSKF_OK;
+}
+
+extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 3; ++i) c->desc[i].release();
+    c->jobs.release();
+    c->ekf_desc.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mskf_ctx_sync(mskf_ctx *c) {
+    if (!c) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    return MSKF_OK;
+}
+
+extern "C" void *mskf_ctx_hip_stream(mskf_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+void fill_pyr(const mskf_stream *s, int idx, PyrDev &p) {
+    for (int l = 0; l < MSKF_LEVELS; ++l) {
+        p.lvl[l] = s->pyr[idx] + s->lvl_off[l];
+        p.w[l] = s->lw[l];
+        p.h[l] = s->lh[l];
+    }
+}
+
+extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
+                                  mskf_stream **out) {
+    if (!ctx || !calib || !fe || !ekf || !out) return MSKF_ERR_INVALID;
+    if (calib->cam0_model != MSKF_MODEL_RADTAN || calib->cam1_model != MSKF_MODEL_RADTAN) {
+        mskf_set_error("only the radtan distortion model is implemented on the device path");
+        return MSKF_ERR_UNSUPPORTED;
+    }
+    if (calib->width < 64 || calib->height < 64 || fe->det_rows <= 0 || fe->det_cols <= 0 || fe->grid_row <= 0 || fe->grid_col <= 0)
+        return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    mskf_stream *s = new mskf_stream();
+    s->ctx = ctx;
+    s->calib = *calib; s->fe = *fe; s->ekf = *ekf;
+    s->w = calib->width; s->h = calib->height;
+    size_t off = 0;
+    int w = s->w, h = s->h;
+    for (int l = 0; l < MSKF_LEVELS; ++l) {
+        s->lw[l] = w; s->lh[l] = h; s->lvl_off[l] = off;
+        off += ((size_t)w * h + 255) & ~(size_t)255;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    s->pyr_bytes = off;
+    int rc = MSKF_OK;
+    for (int i = 0; i < 3 && rc == MSKF_OK; ++i) {
+        hipError_t e = hipMalloc((void **)&s->pyr[i], s->pyr_bytes);
+        if (e != hipSuccess) { mskf_set_error(hipGetErrorString(e)); rc = MSKF_ERR_HIP; }
+    }
+    // point capacity: every live grid slot plus every detector cell
+    const int det_cells = fe->det_rows * fe->det_cols;
+    s->pt_cap = (fe->grid_row + 1) * (fe->grid_col + 1) * (fe->grid_max_feature_num + 1) + det_cells + 64;
+    if (rc == MSKF_OK) rc = s->in_pts.ensure(s->pt_cap);
+    if (rc == MSKF_OK) rc = s->out0.ensure(s->pt_cap);
+    if (rc == MSKF_OK) rc = s->out1.ensure(s->pt_cap);
+    if (rc == MSKF_OK) rc = s->und0.ensure(s->pt_cap);
+    if (rc == MSKF_OK) rc = s->und1.ensure(s->pt_cap);
+    if (rc == MSKF_OK) rc = s->status.ensure(s->pt_cap);
+    if (rc == MSKF_OK) rc = s->cell_max.ensure(det_cells);
+    if (rc == MSKF_OK) rc = mskf_ekf_stream_init(s);
+    if (rc != MSKF_OK) { mskf_stream_destroy(s); return rc; }
+
+    for (int i = 0; i < 4; ++i) {
+        s->cam0.K[i] = calib->cam0_intrinsics[i]; s->cam0.D[i] = calib->cam0_distortion[i];
+        s->cam1.K[i] = calib->cam1_intrinsics[i]; s->cam1.D[i] = calib->cam1_distortion[i];
+    }
+    // image_processor.cpp:63-72 (loadParameters) and :544,:587-591 (stereoMatch)
+    using namespace hm;
+    Rigid m4_cam0_imu = Rigid::from_rowmajor16(calib->T_cam0_imu);
+    Mat3 R_cam0_imu = m4_cam0_imu.R.transpose();
+    Vec3 t_cam0_imu = -(R_cam0_imu * m4_cam0_imu.t);
+    Rigid m4_cam1_cam0 = Rigid::from_rowmajor16(calib->T_cam1_cam0);
+    Rigid T_cam1_imu = m4_cam1_cam0 * m4_cam0_imu;
+    Mat3 R_cam1_imu = T_cam1_imu.R.transpose();
+    Vec3 t_cam1_imu = -(R_cam1_imu * T_cam1_imu.t);
+    Mat3 R_cam0_cam1 = R_cam1_imu.transpose() * R_cam0_imu;
+    Vec3 t_cam0_cam1 = R_cam1_imu.transpose() * (t_cam0_imu - t_cam1_imu);
+    Mat3 E = skew(t_cam0_cam1) * R_cam0_cam1;
+    std::memcpy(s->R01, R_cam0_cam1.m, sizeof(s->R01));
+    std::memcpy(s->E, E.m, sizeof(s->E));
+    const double norm_pixel_unit = 4.0 / (s->cam0.K[0] + s->cam0.K[1] + s->cam1.K[0] + s->cam1.K[1]);
+    s->epi_thresh = fe->stereo_threshold * norm_pixel_unit;
+    s->det_ch = (s->h + fe->det_rows - 1) / fe->det_rows;
+    s->det_cw = (s->w + fe->det_cols - 1) / fe->det_cols;
+    ctx->streams.push_back(s);
+    *out = s;
+    return MSKF_OK;
+}
+
+extern "C" void mskf_stream_destroy(mskf_stream *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (int i = 0; i < 3; ++i) if (s->pyr[i]) (void)hipFree(s->pyr[i]);
+    s->in_pts.release(); s->out0.release(); s->out1.release(); s->und0.release(); s->und1.release();
+    s->status.release(); s->cell_max.release();
+    mskf_ekf_stream_free(s);
+    auto &v = s->ctx->streams;
+    for (size_t i = 0; i < v.size(); ++i) if (v[i] == s) { v.erase(v.begin() + i); break; }
+    delete s;
+}
+
+static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
+    std::memset(&d, 0, sizeof(d));
+    fill_pyr(s, s->i_prev0, d.prev0);
+    fill_pyr(s, s->i_curr0, d.curr0);
+    fill_pyr(s, s->i_curr1, d.curr1);
+    d.cam0 = s->cam0; d.cam1 = s->cam1;
+    std::memcpy(d.R01, s->R01, sizeof(d.R01));
+    std::memcpy(d.E, s->E, sizeof(d.E));
+    d.epi_thresh = s->epi_thresh;
+    d.in_pts = s->in_pts.d; d.out0 = s->out0.d; d.out1 = s->out1.d; d.und0 = s->und0.d; d.und1 = s->und1.d;
+    d.status = s->status.d;
+    d.det_rows = s->fe.det_rows; d.det_cols = s->fe.det_cols; d.cell_w = s->det_cw; d.cell_h = s->det_ch;
+    d.cell_max = s->cell_max.d;
+}
+
+extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
+                                         const uint8_t *const *cam1, int on_device) {
+    if (!ctx || n <= 0 || !streams || !cam0 || !cam1) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ctx->jobs.ensure((size_t)n * 2 * (MSKF_LEVELS - 1));
+    if (rc != MSKF_OK) return rc;
+    rc = ctx->desc[0].ensure(n);
+    if (rc != MSKF_OK) return rc;
+    int max_cells = 0;
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        if (!s || s->ctx != ctx || !cam0[i] || !cam1[i]) return MSKF_ERR_INVALID;
+        const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr0], cam0[i], (size_t)s->w * s->h, kind, st));
+        MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr1], cam1[i], (size_t)s->w * s->h, kind, st));
+        s->has_curr = true;
+        max_cells = std::max(max_cells, s->fe.det_rows * s->fe.det_cols);
+    }
+    // pyramid levels 1..3 of both cameras, one launch per level over all streams
+    int max_dw[MSKF_LEVELS] = {0}, max_dh[MSKF_LEVELS] = {0};
+    for (int l = 1; l < MSKF_LEVELS; ++l)
+        for (int i = 0; i < n; ++i) {
+            mskf_stream *s = streams[i];
+            for (int c = 0; c < 2; ++c) {
+                PyrJob &j = ctx->jobs.h[(size_t)(l - 1) * 2 * n + 2 * i + c];
+                uint8_t *base = s->pyr[c == 0 ? s->i_curr0 : s->i_curr1];
+                j.src = base + s->lvl_off[l - 1]; j.dst = base + s->lvl_off[l];
+                j.sw = s->lw[l - 1]; j.sh = s->lh[l - 1]; j.dw = s->lw[l]; j.dh = s->lh[l];
+            }
+            max_dw[l] = std::max(max_dw[l], s->lw[l]); max_dh[l] = std::max(max_dh[l], s->lh[l]);
+        }
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(PyrJob) * (size_t)n * 2 * (MSKF_LEVELS - 1), hipMemcpyHostToDevice, st));
+    for (int l = 1; l < MSKF_LEVELS; ++l)
+        fe_launch_pyr_down(ctx->jobs.d + (size_t)(l - 1) * 2 * n, 2 * n, max_dw[l], max_dh[l], st);
+    // detector per-cell maxima on cam0 level 0
+    for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    fe_launch_detect(ctx->desc[0].d, n, max_cells, st);
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        MSKF_HIPCHK(hipMemcpyAsync(s->cell_max.h, s->cell_max.d, sizeof(mskf_corner) * (size_t)s->fe.det_rows * s->fe.det_cols,
+                                   hipMemcpyDeviceToHost, st));
+    }
+    MSKF_HIPCHK(hipGetLastError());
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_push_stereo(mskf_stream *s, const uint8_t *cam0, const uint8_t *cam1, int width, int height, int pitch,
+                                   double time_stamp) {
+    if (!s || !cam0 || !cam1) return MSKF_ERR_INVALID;
+    if (width != s->w || height != s->h || pitch < width) { mskf_set_error("image size differs from the calibration"); return MSKF_ERR_INVALID; }
+    s->time_stamp = time_stamp;
+    if (pitch != width) {
+        // repack rows on the way in (2D copy), then run the batch path on the device-resident planes
+        MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+        uint8_t *tmp0 = nullptr, *tmp1 = nullptr;
+        MSKF_HIPCHK(hipMalloc((void **)&tmp0, (size_t)width * height));
+        MSKF_HIPCHK(hipMalloc((void **)&tmp1, (size_t)width * height));
+        MSKF_HIPCHK(hipMemcpy2D(tmp0, width, cam0, pitch, width, height, hipMemcpyHostToDevice));
+        MSKF_HIPCHK(hipMemcpy2D(tmp1, width, cam1, pitch, width, height, hipMemcpyHostToDevice));
+        const uint8_t *a[1] = {tmp0}, *b[1] = {tmp1};
+        mskf_stream *ss[1] = {s};
+        int rc = mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 1);
+        (void)hipStreamSynchronize(s->ctx->stream);
+        (void)hipFree(tmp0); (void)hipFree(tmp1);
+        return rc;
+    }
+    const uint8_t *a[1] = {cam0}, *b[1] = {cam1};
+    mskf_stream *ss[1] = {s};
+    return mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 0);
+}
+
+extern "C" int mskf_fe_push_stereo_device(mskf_stream *s, const uint8_t *d_cam0, const uint8_t *d_cam1, int width, int height,
+                                          double time_stamp) {
+    if (!s || !d_cam0 || !d_cam1) return MSKF_ERR_INVALID;
+    if (width != s->w || height != s->h) return MSKF_ERR_INVALID;
+    s->time_stamp = time_stamp;
+    const uint8_t *a[1] = {d_cam0}, *b[1] = {d_cam1};
+    mskf_stream *ss[1] = {s};
+    return mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 1);
+}
+
+extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out) {
+    if (!s || !out || !n_out) return MSKF_ERR_INVALID;
+    const int n = s->fe.det_rows * s->fe.det_cols;
+    if (capacity < n) return MSKF_ERR_CAPACITY;
+    if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
+    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    std::memcpy(out, s->cell_max.h, sizeof(mskf_corner) * (size_t)n);
+    *n_out = n;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args) {
+    if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = ctx->desc[1].ensure(n);
+    if (rc != MSKF_OK) return rc;
+    int max_pts = 0;
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        const mskf_fe_track_args &a = args[i];
+        if (!s || s->ctx != ctx || a.n < 0) return MSKF_ERR_INVALID;
+        if (a.n > s->pt_cap) { mskf_set_error("too many points for this stream"); return MSKF_ERR_CAPACITY; }
+        if (a.n > 0 && (!a.in_pts || !a.out0 || !a.out1 || !a.und0 || !a.und1 || !a.status)) return MSKF_ERR_INVALID;
+        if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
+        FeStreamDev &d = ctx->desc[1].h[i];
+        fill_fe_desc(s, d);
+        d.n_pts = a.n;
+        d.do_temporal = a.do_temporal;
+        std::memcpy(d.Hpred, a.Hpred, sizeof(d.Hpred));
+        if (a.n > 0) {
+            std::memcpy(s->in_pts.h, a.in_pts, sizeof(mskf_point2f) * (size_t)a.n);
+            MSKF_HIPCHK(hipMemcpyAsync(s->in_pts.d, s->in_pts.h, sizeof(mskf_point2f) * (size_t)a.n, hipMemcpyHostToDevice, st));
+        }
+        max_pts = std::max(max_pts, a.n);
+    }
+    if (max_pts > 0) {
+        MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+        fe_launch_lk(ctx->desc[1].d, n, max_pts, st);
+        for (int i = 0; i < n; ++i) {
+            mskf_stream *s = streams[i];
+            const size_t np = (size_t)args[i].n;
+            if (!np) continue;
+            MSKF_HIPCHK(hipMemcpyAsync(s->out0.h, s->out0.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
+            MSKF_HIPCHK(hipMemcpyAsync(s->out1.h, s->out1.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
+            MSKF_HIPCHK(hipMemcpyAsync(s->und0.h, s->und0.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
+            MSKF_HIPCHK(hipMemcpyAsync(s->und1.h, s->und1.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
+            MSKF_HIPCHK(hipMemcpyAsync(s->status.h, s->status.d, np, hipMemcpyDeviceToHost, st));
+        }
+        MSKF_HIPCHK(hipGetLastError());
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < n; ++i) {
+            mskf_stream *s = streams[i];
+            const mskf_fe_track_args &a = args[i];
+            const size_t np = (size_t)a.n;
+            if (!np) continue;
+            std::memcpy(a.out0, s->out0.h, sizeof(mskf_point2f) * np);
+            std::memcpy(a.out1, s->out1.h, sizeof(mskf_point2f) * np);
+            std::memcpy(a.und0, s->und0.h, sizeof(mskf_point2f) * np);
+            std::memcpy(a.und1, s->und1.h, sizeof(mskf_point2f) * np);
+            std::memcpy(a.status, s->status.h, np);
+        }
+    }
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_track(mskf_stream *s, const mskf_fe_track_args *args) {
+    if (!s || !args) return MSKF_ERR_INVALID;
+    mskf_stream *ss[1] = {s};
+    return mskf_fe_track_batch(s->ctx, 1, ss, args);
+}
+
+extern "C" int mskf_fe_swap(mskf_stream *s) {
+    if (!s) return MSKF_ERR_INVALID;
+    std::swap(s->i_prev0, s->i_curr0);
+    s->has_curr = false;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_get_level(mskf_stream *s, int role, int level, uint8_t *out, int capacity, int *w, int *h) {
+    if (!s || !out || role < 0 || role > 2 || level < 0 || level >= MSKF_LEVELS) return MSKF_ERR_INVALID;
+    const int idx = role == 0 ? s->i_prev0 : (role == 1 ? s->i_curr0 : s->i_curr1);
+    const size_t bytes = (size_t)s->lw[level] * s->lh[level];
+    if ((size_t)capacity < bytes) return MSKF_ERR_CAPACITY;
+    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipMemcpy(out, s->pyr[idx] + s->lvl_off[level], bytes, hipMemcpyDeviceToHost));
+    if (w) *w = s->lw[level];
+    if (h) *h = s->lh[level];
+    return MSKF_OK;
+}

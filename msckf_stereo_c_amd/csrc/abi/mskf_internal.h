@@ -1,0 +1,87 @@
+// mskf_internal.h — private definitions of the C-ABI handles (mskf_ctx / mskf_stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../../include/mskf_hip.h"
+#include "../hip/fe_device.h"
+#include "../hip/ekf_device.h"
+#include "host_math.h"
+
+struct PyrJob { const uint8_t *src; uint8_t *dst; int sw, sh, dw, dh; };
+
+extern "C" {
+void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t st);
+void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_cells, hipStream_t st);
+void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st);
+}
+
+void mskf_set_error(const std::string &s);
+
+#define MSKF_HIPCHK(expr)                                                                            \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            mskf_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+            return MSKF_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+template <typename T>
+struct PinnedDev {  // a pinned host array with a device twin
+    T *h = nullptr, *d = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return MSKF_OK;
+        release();
+        size_t c = n < 16 ? 16 : n + n / 2;
+        MSKF_HIPCHK(hipHostMalloc((void **)&h, c * sizeof(T), hipHostMallocDefault));
+        MSKF_HIPCHK(hipMalloc((void **)&d, c * sizeof(T)));
+        cap = c;
+        return MSKF_OK;
+    }
+    void release() {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr; cap = 0;
+    }
+};
+
+struct mskf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
+    PinnedDev<PyrJob> jobs;
+    PinnedDev<EkfStreamDev> ekf_desc;
+    std::vector<mskf_stream *> streams;
+};
+
+struct mskf_stream {
+    mskf_ctx *ctx = nullptr;
+    mskf_calib calib;
+    mskf_fe_cfg fe;
+    mskf_ekf_cfg ekf;
+    // ---- front-end
+    int w = 0, h = 0;
+    int lw[MSKF_LEVELS], lh[MSKF_LEVELS];
+    size_t lvl_off[MSKF_LEVELS];
+    size_t pyr_bytes = 0;
+    uint8_t *pyr[3] = {nullptr, nullptr, nullptr};
+    int i_prev0 = 0, i_curr0 = 1, i_curr1 = 2;
+    bool has_curr = false;
+    int pt_cap = 0;
+    PinnedDev<mskf_point2f> in_pts, out0, out1, und0, und1;
+    PinnedDev<uint8_t> status;
+    PinnedDev<mskf_corner> cell_max;
+    CamDev cam0, cam1;
+    double R01[9], E[9], epi_thresh = 0;
+    int det_cw = 0, det_ch = 0;
+    double time_stamp = 0;
+    // ---- EKF
+    EkfStreamState ekf_state;
+    void *ekf_extra = nullptr;
+};
+
+void fill_pyr(const mskf_stream *s, int idx, PyrDev &p);
+int mskf_ekf_stream_init(mskf_stream *s);
+void mskf_ekf_stream_free(mskf_stream *s);

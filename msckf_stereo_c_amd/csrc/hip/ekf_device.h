@@ -1,0 +1,61 @@
+// ekf_device.h — device-side descriptors of the MSCKF measurement-update kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/mskf_hip.h"
+
+#define EKF_IMU_DIM 21
+#define EKF_SLOTS 32          // feature workgroups per stream and launch (each loops over its features)
+
+// Per feature of one update (device copy of mskf_ekf_feature + row offset of its block)
+struct EkfFeatDev {
+    int obs_start, n_obs;
+    int needs_init, init_start, n_init;
+    int row_off;              // first row of this feature's (4 n_obs - 3)-row block in Hs / rs
+    double position[3];
+};
+
+// Everything the update kernels need for one VIO stream.
+struct EkfStreamDev {
+    double *P;                // ld x ld, row-major, only [0,d) x [0,d) is live
+    int d, ld;
+    int n_clones, n_feat, n_obs;
+    int dof_offset, apply_row_cap, max_stack_rows;
+    int m_total;              // sum of block rows of all features
+    double sigma2;            // Feature::observation_noise (variance)
+    double gravity[3];
+    double R_c0_c1[9], t_c0_c1[3];       // CAMState::T_cam0_cam1
+    const double *chi2;                  // table[100], index = dof
+    const mskf_clone_state *clones;      // n_clones
+    EkfFeatDev *feats;                   // n_feat
+    const int *obs_clone;                // n_obs
+    const double *obs_z;                 // n_obs x 4
+    double *Hs;               // m_total x ld stacked (null-space projected) Jacobian, failed blocks zeroed
+    double *rs;               // m_total
+    double *T;                // ld x ld work (H P, then Y = L^-1 H P)
+    double *S;                // ld x ld work
+    double *gate_T;           // EKF_SLOTS x (nmax x ld)
+    double *gate_S;           // EKF_SLOTS x (nmax x nmax)
+    int nmax;                 // 4 * max_clones
+    double *delta_x;          // d
+    uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
+    double *gamma;            // n_feat
+    int *rows_out;            // [0] stacked rows, [1] rows used by the update (after QR: min(m, d))
+    // propagation / augmentation
+    const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q
+    int n_steps;
+    const double *J;          // 6 x 21
+    int remove_index;         // clone to delete
+};
+
+struct EkfStreamState {       // host-side bookkeeping of the device buffers of one stream
+    int max_clones = 0, ld = 0, d = EKF_IMU_DIM;
+    int max_rows = 0, max_feat = 0, max_obs = 0, nmax = 0;
+    double *P = nullptr, *Hs = nullptr, *rs = nullptr, *T = nullptr, *S = nullptr, *gate_T = nullptr, *gate_S = nullptr;
+    double *chi2 = nullptr;
+    // per-update staging: one pinned+device arena, laid out by the host
+    char *h_arena = nullptr, *d_arena = nullptr;
+    size_t arena_bytes = 0;
+    char *h_out = nullptr, *d_out = nullptr;   // results: delta_x, status, gamma, rows, positions
+    size_t out_bytes = 0;
+};

@@ -1,0 +1,727 @@
+// ekf_kernels.hip — hand-written gfx950 kernels of the MSCKF measurement update.
+//
+//  k_ekf_propagate      : covariance part of processModel        (msckf_vio.cpp:458-469)
+//  k_ekf_augment        : covariance part of stateAugmentation   (:564-582)
+//  k_ekf_remove_clone   : clone row/column deletion              (:1161-1181)
+//  k_ekf_feature_blocks : Feature::initializePosition (feature.hpp:289-450), measurementJacobian
+//                         (:610-677), featureJacobian null-space projection (:679-775), gatingTest (:909-935)
+//  k_ekf_cap            : stacking order + 1500-row cap          (:1003-1010)
+//  k_ekf_qr             : QR compression of the stacked Jacobian (:795-811)
+//  k_ekf_update         : gain, state correction vector, covariance update (:831-904)
+//
+// All arithmetic is FP64.  The covariance P stays resident in HBM (ld x ld, row-major, exactly
+// symmetric by construction); one workgroup handles one VIO stream (or one feature of one
+// stream), blockIdx.y is the stream of the batch.
+#include "ekf_device.h"
+
+#define WG 256
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide sum, result broadcast to all threads (s_red: >= blockDim/64 doubles + 1)
+__device__ __forceinline__ double block_sum(double v, double *s_red) {
+    v = wave_sum(v);
+    const int nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < nw; ++i) t += s_red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------ small math
+__device__ __forceinline__ void quat_to_rot(const double *q, double *R) {
+    // JPL: R = (2w^2-1) I - 2w [qv]x + 2 qv qv^T   
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double a = 2 * w * w - 1, tw = 2 * w;
+    R[0] = a + 2 * x * x;        R[1] = tw * z + 2 * x * y;   R[2] = -tw * y + 2 * x * z;
+    R[3] = -tw * z + 2 * y * x;  R[4] = a + 2 * y * y;        R[5] = tw * x + 2 * y * z;
+    R[6] = tw * y + 2 * z * x;   R[7] = -tw * x + 2 * z * y;  R[8] = a + 2 * z * z;
+}
+__device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_vec(const double *A, const double *v, double *o) {
+    for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+__device__ __forceinline__ void mat3t_vec(const double *A, const double *v, double *o) {
+    for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+}
+
+// ------------------------------------------------------------------------------------ propagate
+// P_II <- sym(Phi P_II Phi^T + Q);  P_IC <- Phi P_IC;  P_CI <- P_IC^T     (per IMU step)
+__global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    if (S.n_steps <= 0) return;
+    double *P = S.P;
+    const int d = S.d, ld = S.ld, N = EKF_IMU_DIM;
+    __shared__ double sPhi[N * N], sQ[N * N], sP[N * N], sT[N * N];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N * N; i += WG) sP[i] = P[(size_t)(i / N) * ld + (i % N)];
+    for (int step = 0; step < S.n_steps; ++step) {
+        const double *PhiQ = S.PhiQ + (size_t)step * 2 * N * N;
+        __syncthreads();
+        for (int i = tid; i < N * N; i += WG) { sPhi[i] = PhiQ[i]; sQ[i] = PhiQ[N * N + i]; }
+        __syncthreads();
+        for (int i = tid; i < N * N; i += WG) {
+            const int r = i / N, c = i % N;
+            double s = 0;
+            for (int k = 0; k < N; ++k) s += sPhi[r * N + k] * sP[k * N + c];
+            sT[i] = s;
+        }
+        __syncthreads();
+        double x0 = 0, x1 = 0;  // each thread owns elements tid and tid+WG (N*N = 441 <= 512)
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + e * WG;
+            if (i < N * N) {
+                const int r = i / N, c = i % N;
+                double s = 0, st = 0;
+                for (int k = 0; k < N; ++k) { s += sT[r * N + k] * sPhi[c * N + k]; st += sT[c * N + k] * sPhi[r * N + k]; }
+                const double v = ((s + sQ[r * N + c]) + (st + sQ[c * N + r])) * 0.5;
+                if (e == 0) x0 = v; else x1 = v;
+            }
+        }
+        // P_IC columns
+        for (int c = N + tid; c < d; c += WG) {
+            double col[N];
+            for (int k = 0; k < N; ++k) col[k] = P[(size_t)k * ld + c];
+            for (int r = 0; r < N; ++r) {
+                double s = 0;
+                for (int k = 0; k < N; ++k) s += sPhi[r * N + k] * col[k];
+                P[(size_t)r * ld + c] = s;
+                P[(size_t)c * ld + r] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < N * N) sP[tid] = x0;
+        if (tid + WG < N * N) sP[tid + WG] = x1;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += WG) P[(size_t)(i / N) * ld + (i % N)] = sP[i];
+}
+
+// ------------------------------------------------------------------------------------ augment
+// rows/cols [d, d+6): [J P11, J P12], corner sym(J P11 J^T)
+__global__ __launch_bounds__(WG) void k_ekf_augment(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    if (!S.J) return;
+    double *P = S.P;
+    const int d = S.d, ld = S.ld, N = EKF_IMU_DIM;  // d = dimension BEFORE augmentation
+    __shared__ double sJ[6 * N], sC[6 * N];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 6 * N; i += WG) sJ[i] = S.J[i];
+    __syncthreads();
+    for (int c = tid; c < d; c += WG) {
+        double col[N];
+        for (int k = 0; k < N; ++k) col[k] = P[(size_t)k * ld + c];
+        for (int r = 0; r < 6; ++r) {
+            double s = 0;
+            for (int k = 0; k < N; ++k) s += sJ[r * N + k] * col[k];
+            P[(size_t)(d + r) * ld + c] = s;
+            P[(size_t)c * ld + (d + r)] = s;
+            if (c < N) sC[r * N + c] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int r = tid / 6, c = tid % 6;
+        double s = 0, st = 0;
+        for (int k = 0; k < N; ++k) { s += sC[r * N + k] * sJ[c * N + k]; st += sC[c * N + k] * sJ[r * N + k]; }
+        P[(size_t)(d + r) * ld + (d + c)] = (s + st) / 2.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------ remove clone
+// out-of-place: Pdst <- P with rows/cols [s0, s0+6) removed
+__global__ __launch_bounds__(WG) void k_ekf_remove_clone(const EkfStreamDev *streams, double *const *dst) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    const int d = S.d, ld = S.ld;
+    const int s0 = EKF_IMU_DIM + 6 * S.remove_index;
+    double *Pd = dst[blockIdx.y];
+    const int dn = d - 6;
+    for (int idx = blockIdx.x * WG + threadIdx.x; idx < dn * dn; idx += gridDim.x * WG) {
+        const int i = idx / dn, j = idx - i * dn;
+        const int si = i < s0 ? i : i + 6, sj = j < s0 ? j : j + 6;
+        Pd[(size_t)i * ld + j] = S.P[(size_t)si * ld + sj];
+    }
+}
+
+// ------------------------------------------------------------------------------------ feature blocks
+#define MAX_CLONES_DEV 64          // 4*64 = 256 block rows max per feature
+
+struct TriScratch {
+    double R[2 * MAX_CLONES_DEV][9];
+    double t[2 * MAX_CLONES_DEV][3];
+    double z[2 * MAX_CLONES_DEV][2];
+};
+
+// Levenberg-Marquardt inverse-depth triangulation, executed by wave 0 of the workgroup.
+// feature.hpp:289-450; parameters feature.hpp:46-52.
+__device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, TriScratch &ts, double *pos_out) {
+    const int lane = threadIdx.x & 63;
+    const int n_meas = 2 * F.n_init;
+    // first camera pose (camera -> world): R0 = R(q)^T, t0 = p
+    double R0[9], t0[3];
+    {
+        const mskf_clone_state &c = S.clones[S.obs_clone[F.init_start]];
+        double Rw[9];
+        quat_to_rot(c.q, Rw);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R0[3 * i + j] = Rw[3 * j + i];
+        t0[0] = c.p[0]; t0[1] = c.p[1]; t0[2] = c.p[2];
+    }
+    // T_cam0_cam1^-1 = (R^T, -R^T t)
+    double Rinv[9], tinv[3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rinv[3 * i + j] = S.R_c0_c1[3 * j + i];
+    { double tmp[3]; mat3_vec(Rinv, S.t_c0_c1, tmp); tinv[0] = -tmp[0]; tinv[1] = -tmp[1]; tinv[2] = -tmp[2]; }
+    for (int m = lane; m < n_meas; m += 64) {
+        const int o = F.init_start + (m >> 1);
+        const mskf_clone_state &c = S.clones[S.obs_clone[o]];
+        double Rw[9], Rc[9], tc[3];
+        quat_to_rot(c.q, Rw);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rc[3 * i + j] = Rw[3 * j + i];  // cam0 -> world
+        tc[0] = c.p[0]; tc[1] = c.p[1]; tc[2] = c.p[2];
+        if (m & 1) {  // cam1_pose = cam0_pose * T_cam0_cam1^-1
+            double R2[9], t2[3];
+            mat3_mul(Rc, Rinv, R2);
+            mat3_vec(Rc, tinv, t2);
+            for (int i = 0; i < 9; ++i) Rc[i] = R2[i];
+            for (int i = 0; i < 3; ++i) tc[i] = t2[i] + tc[i];
+        }
+        // pose <- pose^-1 * T_c0_w : R = Rc^T R0, t = Rc^T (t0 - tc)
+        double Rt[9], dt[3] = {t0[0] - tc[0], t0[1] - tc[1], t0[2] - tc[2]};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[3 * i + j] = Rc[3 * j + i];
+        mat3_mul(Rt, R0, ts.R[m]);
+        mat3_vec(Rt, dt, ts.t[m]);
+        ts.z[m][0] = S.obs_z[4 * o + ((m & 1) ? 2 : 0)];
+        ts.z[m][1] = S.obs_z[4 * o + ((m & 1) ? 3 : 1)];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // initial guess (feature.hpp:231-255) from the last pose, first and last measurement
+    double sol[3];
+    {
+        const double *Rl = ts.R[n_meas - 1], *tl = ts.t[n_meas - 1];
+        const double z1[2] = {ts.z[0][0], ts.z[0][1]}, z2[2] = {ts.z[n_meas - 1][0], ts.z[n_meas - 1][1]};
+        double v[3] = {z1[0], z1[1], 1.0}, m[3];
+        mat3_vec(Rl, v, m);
+        const double A0 = m[0] - z2[0] * m[2], A1 = m[1] - z2[1] * m[2];
+        const double b0 = z2[0] * tl[2] - tl[0], b1 = z2[1] * tl[2] - tl[1];
+        const double depth = (A0 * b0 + A1 * b1) / (A0 * A0 + A1 * A1);
+        const double p0 = z1[0] * depth, p1 = z1[1] * depth, p2 = depth;
+        sol[0] = p0 / p2; sol[1] = p1 / p2; sol[2] = 1.0 / p2;
+    }
+    auto cost_of = [&](const double *x) {
+        double e = 0;
+        for (int m = lane; m < n_meas; m += 64) {
+            const double *R = ts.R[m], *t = ts.t[m];
+            const double h0 = R[0] * x[0] + R[1] * x[1] + R[2] + x[2] * t[0];
+            const double h1 = R[3] * x[0] + R[4] * x[1] + R[5] + x[2] * t[1];
+            const double h2 = R[6] * x[0] + R[7] * x[1] + R[8] + x[2] * t[2];
+            const double d0 = h0 / h2 - ts.z[m][0], d1 = h1 / h2 - ts.z[m][1];
+            e += d0 * d0 + d1 * d1;
+        }
+        return wave_sum(e);
+    };
+    double lambda = 1e-3;
+    int inner = 0, outer = 0;
+    bool reduced = false;
+    double delta_norm = 0;
+    double total_cost = cost_of(sol);
+    do {
+        double A[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};  // A: 00 01 02 11 12 22
+        for (int m = lane; m < n_meas; m += 64) {
+            const double *R = ts.R[m], *t = ts.t[m];
+            const double h1 = R[0] * sol[0] + R[1] * sol[1] + R[2] + sol[2] * t[0];
+            const double h2 = R[3] * sol[0] + R[4] * sol[1] + R[5] + sol[2] * t[1];
+            const double h3 = R[6] * sol[0] + R[7] * sol[1] + R[8] + sol[2] * t[2];
+            double W[3][3];
+            for (int i = 0; i < 3; ++i) { W[i][0] = R[3 * i]; W[i][1] = R[3 * i + 1]; W[i][2] = t[i]; }
+            double J0[3], J1[3];
+            for (int j = 0; j < 3; ++j) {
+                J0[j] = 1 / h3 * W[0][j] - h1 / (h3 * h3) * W[2][j];
+                J1[j] = 1 / h3 * W[1][j] - h2 / (h3 * h3) * W[2][j];
+            }
+            const double r0 = h1 / h3 - ts.z[m][0], r1 = h2 / h3 - ts.z[m][1];
+            const double e = sqrt(r0 * r0 + r1 * r1);
+            const double w = (e <= 0.01) ? 1.0 : sqrt(2.0 * 0.01 / e);
+            const double ws = (w == 1) ? 1.0 : w * w;
+            A[0] += ws * (J0[0] * J0[0] + J1[0] * J1[0]); A[1] += ws * (J0[0] * J0[1] + J1[0] * J1[1]);
+            A[2] += ws * (J0[0] * J0[2] + J1[0] * J1[2]); A[3] += ws * (J0[1] * J0[1] + J1[1] * J1[1]);
+            A[4] += ws * (J0[1] * J0[2] + J1[1] * J1[2]); A[5] += ws * (J0[2] * J0[2] + J1[2] * J1[2]);
+            b[0] += ws * (J0[0] * r0 + J1[0] * r1); b[1] += ws * (J0[1] * r0 + J1[1] * r1); b[2] += ws * (J0[2] * r0 + J1[2] * r1);
+        }
+        for (int i = 0; i < 6; ++i) A[i] = wave_sum(A[i]);
+        for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
+        do {
+            // Cholesky solve of (A + lambda I) delta = b
+            const double a00 = A[0] + lambda, a01 = A[1], a02 = A[2], a11 = A[3] + lambda, a12 = A[4], a22 = A[5] + lambda;
+            double delta[3] = {0, 0, 0};
+            const double l00 = sqrt(a00);
+            const double l10 = a01 / l00, l20 = a02 / l00;
+            const double s11 = a11 - l10 * l10;
+            const double l11 = sqrt(s11);
+            const double l21 = (a12 - l20 * l10) / l11;
+            const double s22 = a22 - l20 * l20 - l21 * l21;
+            if (a00 > 0 && s11 > 0 && s22 > 0) {
+                const double l22 = sqrt(s22);
+                const double y0 = b[0] / l00, y1 = (b[1] - l10 * y0) / l11, y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
+                delta[2] = y2 / l22;
+                delta[1] = (y1 - l21 * delta[2]) / l11;
+                delta[0] = (y0 - l10 * delta[1] - l20 * delta[2]) / l00;
+            }
+            const double ns[3] = {sol[0] - delta[0], sol[1] - delta[1], sol[2] - delta[2]};
+            delta_norm = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+            const double new_cost = cost_of(ns);
+            if (new_cost < total_cost) {
+                reduced = true;
+                sol[0] = ns[0]; sol[1] = ns[1]; sol[2] = ns[2];
+                total_cost = new_cost;
+                lambda = lambda / 10 > 1e-10 ? lambda / 10 : 1e-10;
+            } else {
+                reduced = false;
+                lambda = lambda * 10 < 1e12 ? lambda * 10 : 1e12;
+            }
+        } while (inner++ < 10 && !reduced);
+        inner = 0;
+    } while (outer++ < 10 && delta_norm > 5e-7);
+
+    const double fp[3] = {sol[0] / sol[2], sol[1] / sol[2], 1.0 / sol[2]};
+    int bad = 0;
+    for (int m = lane; m < n_meas; m += 64) {
+        const double *R = ts.R[m], *t = ts.t[m];
+        const double pz = R[6] * fp[0] + R[7] * fp[1] + R[8] * fp[2] + t[2];
+        if (pz <= 0) bad = 1;
+    }
+    bad = __any(bad);
+    double pw[3];
+    mat3_vec(R0, fp, pw);
+    pos_out[0] = pw[0] + t0[0]; pos_out[1] = pw[1] + t0[1]; pos_out[2] = pw[2] + t0[2];
+    return !bad;
+}
+
+// LDS budget of k_ekf_feature_blocks (bytes): Hf 6K + Hx 12K + r 2K + V 6K + coef 9K + tri 17K ~ 52K
+__global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    const int tid = threadIdx.x;
+    const int d = S.d, ld = S.ld;
+    __shared__ double sHf[4 * MAX_CLONES_DEV][3];
+    __shared__ double sHx[4 * MAX_CLONES_DEV][6];
+    __shared__ double sr[4 * MAX_CLONES_DEV];
+    __shared__ double sV[3][4 * MAX_CLONES_DEV];
+    __shared__ double sCoef[6 * MAX_CLONES_DEV + 1][3];
+    __shared__ double sBeta[3], sVV[3];  // beta_k ; v2.v1, v3.v1, v3.v2
+    __shared__ int sObsOfClone[MAX_CLONES_DEV];
+    __shared__ int sCloneOfObs[MAX_CLONES_DEV];
+    __shared__ TriScratch sTri;
+    __shared__ double sPos[3];
+    __shared__ int sValid;
+    __shared__ double sRed[8];
+
+    for (int j = blockIdx.x; j < S.n_feat; j += gridDim.x) {
+        __syncthreads();
+        EkfFeatDev &F = S.feats[j];
+        const int M = F.n_obs, rows = 4 * M, n = rows - 3;
+        double *Hrow0 = S.Hs + (size_t)F.row_off * ld;
+        double *r0 = S.rs + F.row_off;
+        // ---- 1. position
+        if (tid < 64) {
+            bool valid = true;
+            double pos[3] = {F.position[0], F.position[1], F.position[2]};
+            if (F.needs_init) valid = triangulate_wave(S, F, sTri, pos);
+            if (tid == 0) {
+                sPos[0] = pos[0]; sPos[1] = pos[1]; sPos[2] = pos[2];
+                sValid = valid ? 1 : 0;
+                F.position[0] = pos[0]; F.position[1] = pos[1]; F.position[2] = pos[2];
+            }
+        }
+        for (int c = tid; c < MAX_CLONES_DEV; c += WG) sObsOfClone[c] = -1;
+        __syncthreads();
+        if (!sValid || M < 2) {
+            if (tid == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; }
+            for (int i = tid; i < n * ld; i += WG) Hrow0[i] = 0.0;
+            for (int i = tid; i < n; i += WG) r0[i] = 0.0;
+            continue;
+        }
+        // ---- 2. per-observation Jacobians (msckf_vio.cpp:610-677)
+        if (tid < M) {
+            const int o = F.obs_start + tid;
+            const int ci = S.obs_clone[o];
+            sObsOfClone[ci] = tid;
+            sCloneOfObs[tid] = ci;
+            const mskf_clone_state &cam = S.clones[ci];
+            double R_w_c0[9], R_w_c1[9], tmp[3];
+            quat_to_rot(cam.q, R_w_c0);
+            mat3_mul(S.R_c0_c1, R_w_c0, R_w_c1);
+            mat3t_vec(R_w_c1, S.t_c0_c1, tmp);
+            const double t_c1_w[3] = {cam.p[0] - tmp[0], cam.p[1] - tmp[1], cam.p[2] - tmp[2]};
+            const double dp0[3] = {sPos[0] - cam.p[0], sPos[1] - cam.p[1], sPos[2] - cam.p[2]};
+            const double dp1[3] = {sPos[0] - t_c1_w[0], sPos[1] - t_c1_w[1], sPos[2] - t_c1_w[2]};
+            double p_c0[3], p_c1[3];
+            mat3_vec(R_w_c0, dp0, p_c0);
+            mat3_vec(R_w_c1, dp1, p_c1);
+            // dz_dpc0 (rows 0,1), dz_dpc1 (rows 2,3)
+            double dz[4][3] = {{1 / p_c0[2], 0, -p_c0[0] / (p_c0[2] * p_c0[2])},
+                               {0, 1 / p_c0[2], -p_c0[1] / (p_c0[2] * p_c0[2])},
+                               {1 / p_c1[2], 0, -p_c1[0] / (p_c1[2] * p_c1[2])},
+                               {0, 1 / p_c1[2], -p_c1[1] / (p_c1[2] * p_c1[2])}};
+            // dpc0_dxc = [skew(p_c0), -R_w_c0], dpc1_dxc = [R_c0_c1 skew(p_c0), -R_w_c1]
+            const double sk[9] = {0, -p_c0[2], p_c0[1], p_c0[2], 0, -p_c0[0], -p_c0[1], p_c0[0], 0};
+            double Rsk[9];
+            mat3_mul(S.R_c0_c1, sk, Rsk);
+            double Hx[4][6];
+            for (int rr = 0; rr < 4; ++rr) {
+                const double *L = rr < 2 ? sk : Rsk;
+                const double *Rm = rr < 2 ? R_w_c0 : R_w_c1;
+                for (int c = 0; c < 3; ++c) {
+                    Hx[rr][c] = dz[rr][0] * L[c] + dz[rr][1] * L[3 + c] + dz[rr][2] * L[6 + c];
+                    Hx[rr][3 + c] = -(dz[rr][0] * Rm[c] + dz[rr][1] * Rm[3 + c] + dz[rr][2] * Rm[6 + c]);
+                }
+            }
+            // observability constraint: H_x <- A - A u (u^T u)^-1 u^T ; H_f <- -H_x[:, 3:6]
+            double Rn[9], u[6], g[3] = {S.gravity[0], S.gravity[1], S.gravity[2]};
+            quat_to_rot(cam.q_null, Rn);
+            mat3_vec(Rn, g, u);
+            const double dn[3] = {sPos[0] - cam.p_null[0], sPos[1] - cam.p_null[1], sPos[2] - cam.p_null[2]};
+            u[3] = dn[1] * g[2] - dn[2] * g[1]; u[4] = dn[2] * g[0] - dn[0] * g[2]; u[5] = dn[0] * g[1] - dn[1] * g[0];
+            double uu = 0;
+            for (int k = 0; k < 6; ++k) uu += u[k] * u[k];
+            for (int rr = 0; rr < 4; ++rr) {
+                double Au = 0;
+                for (int k = 0; k < 6; ++k) Au += Hx[rr][k] * u[k];
+                for (int c = 0; c < 6; ++c) sHx[4 * tid + rr][c] = Hx[rr][c] - Au * (1.0 / uu) * u[c];
+            }
+            for (int rr = 0; rr < 4; ++rr) for (int c = 0; c < 3; ++c) sHf[4 * tid + rr][c] = -sHx[4 * tid + rr][3 + c];
+            const double *z = S.obs_z + 4 * o;
+            sr[4 * tid + 0] = z[0] - p_c0[0] / p_c0[2];
+            sr[4 * tid + 1] = z[1] - p_c0[1] / p_c0[2];
+            sr[4 * tid + 2] = z[2] - p_c1[0] / p_c1[2];
+            sr[4 * tid + 3] = z[3] - p_c1[1] / p_c1[2];
+        }
+        __syncthreads();
+        // ---- 3. three Householder reflectors of H_f (left null space, msckf_vio.cpp:757-766)
+        for (int k = 0; k < 3; ++k) {
+            double part = 0;
+            for (int i = k + tid; i < rows; i += WG) part += sHf[i][k] * sHf[i][k];
+            const double nrm2 = block_sum(part, sRed);
+            const double nrm = sqrt(nrm2);
+            const double x0 = sHf[k][k];
+            const double alpha = x0 > 0 ? -nrm : nrm;
+            __syncthreads();
+            for (int i = tid; i < rows; i += WG) sV[k][i] = (i < k) ? 0.0 : (i == k ? x0 - alpha : sHf[i][k]);
+            __syncthreads();
+            double pv = 0;
+            for (int i = k + tid; i < rows; i += WG) pv += sV[k][i] * sV[k][i];
+            const double vn = block_sum(pv, sRed);
+            const double beta = (nrm == 0.0 || vn == 0.0) ? 0.0 : 2.0 / vn;
+            if (tid == 0) sBeta[k] = beta;
+            // apply to the remaining columns of H_f
+            for (int c = k + 1; c < 3; ++c) {
+                double pd = 0;
+                for (int i = k + tid; i < rows; i += WG) pd += sV[k][i] * sHf[i][c];
+                const double sdot = block_sum(pd, sRed) * beta;
+                for (int i = k + tid; i < rows; i += WG) sHf[i][c] -= sdot * sV[k][i];
+                __syncthreads();
+            }
+        }
+        {
+            double p21 = 0, p31 = 0, p32 = 0;
+            for (int i = tid; i < rows; i += WG) { p21 += sV[1][i] * sV[0][i]; p31 += sV[2][i] * sV[0][i]; p32 += sV[2][i] * sV[1][i]; }
+            const double a = block_sum(p21, sRed), b = block_sum(p31, sRed), c = block_sum(p32, sRed);
+            if (tid == 0) { sVV[0] = a; sVV[1] = b; sVV[2] = c; }
+        }
+        __syncthreads();
+        // ---- 4. coefficients c_k of every compact column (6M Jacobian columns + the residual)
+        for (int cc = tid; cc <= 6 * M; cc += WG) {
+            double s1 = 0, s2 = 0, s3 = 0;
+            if (cc < 6 * M) {
+                const int blk = cc / 6, c6 = cc - 6 * blk;
+                for (int rr = 0; rr < 4; ++rr) {
+                    const double v = sHx[4 * blk + rr][c6];
+                    s1 += sV[0][4 * blk + rr] * v; s2 += sV[1][4 * blk + rr] * v; s3 += sV[2][4 * blk + rr] * v;
+                }
+            } else {
+                for (int i = 0; i < rows; ++i) { s1 += sV[0][i] * sr[i]; s2 += sV[1][i] * sr[i]; s3 += sV[2][i] * sr[i]; }
+            }
+            const double c1 = sBeta[0] * s1;
+            const double c2 = sBeta[1] * (s2 - c1 * sVV[0]);
+            const double c3 = sBeta[2] * (s3 - c1 * sVV[1] - c2 * sVV[2]);
+            sCoef[cc][0] = c1; sCoef[cc][1] = c2; sCoef[cc][2] = c3;
+        }
+        __syncthreads();
+        // ---- 5. write the projected block: rows 3..4M-1 of Q^T [H_xj | r_j]
+        for (int idx = tid; idx < n * d; idx += WG) {
+            const int i = idx / d + 3, c = idx - (i - 3) * d;
+            double v = 0.0;
+            if (c >= EKF_IMU_DIM) {
+                const int cl = (c - EKF_IMU_DIM) / 6, c6 = (c - EKF_IMU_DIM) - 6 * cl;
+                const int ob = sObsOfClone[cl];
+                if (ob >= 0) {
+                    const int cc = 6 * ob + c6;
+                    const double base = ((i >> 2) == ob) ? sHx[i][c6] : 0.0;
+                    v = base - sCoef[cc][0] * sV[0][i] - sCoef[cc][1] * sV[1][i] - sCoef[cc][2] * sV[2][i];
+                }
+            }
+            Hrow0[(size_t)(i - 3) * ld + c] = v;
+        }
+        for (int i = 3 + tid; i < rows; i += WG)
+            r0[i - 3] = sr[i] - sCoef[6 * M][0] * sV[0][i] - sCoef[6 * M][1] * sV[1][i] - sCoef[6 * M][2] * sV[2][i];
+        __syncthreads();
+        // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
+        const int kc = 6 * M;                     // compact columns
+        double *Tc = S.gate_T + (size_t)blockIdx.x * S.nmax * ld;      // n x kc (row stride kc)
+        double *Sg = S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax;  // n x n
+        const double *P = S.P;
+        for (int idx = tid; idx < n * kc; idx += WG) {
+            const int i = idx / kc, b = idx - i * kc;
+            const int colb = EKF_IMU_DIM + 6 * sCloneOfObs[b / 6] + (b % 6);
+            const double *hrow = Hrow0 + (size_t)i * ld;
+            double s = 0;
+            for (int a = 0; a < kc; ++a) {
+                const int cola = EKF_IMU_DIM + 6 * sCloneOfObs[a / 6] + (a % 6);
+                s += hrow[cola] * P[(size_t)cola * ld + colb];
+            }
+            Tc[idx] = s;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n * n; idx += WG) {
+            const int i = idx / n, i2 = idx - i * n;
+            if (i2 > i) continue;
+            const double *h2 = Hrow0 + (size_t)i2 * ld;
+            double s = 0;
+            for (int b = 0; b < kc; ++b) {
+                const int colb = EKF_IMU_DIM + 6 * sCloneOfObs[b / 6] + (b % 6);
+                s += Tc[(size_t)i * kc + b] * h2[colb];
+            }
+            if (i == i2) s += S.sigma2;
+            Sg[(size_t)i * n + i2] = s;
+        }
+        __syncthreads();
+        // in-place Cholesky (lower) of Sg, right-looking, then forward solve L y = r, gamma = y.y
+        bool pd_ok = true;
+        for (int k = 0; k < n; ++k) {
+            const double dk = Sg[(size_t)k * n + k];
+            if (!(dk > 0)) { pd_ok = false; break; }
+            const double lkk = sqrt(dk);
+            __syncthreads();
+            for (int i = k + tid; i < n; i += WG) Sg[(size_t)i * n + k] = (i == k) ? lkk : Sg[(size_t)i * n + k] / lkk;
+            __syncthreads();
+            const int rem = n - k - 1;
+            for (int idx = tid; idx < rem * rem; idx += WG) {
+                const int a = idx / rem + k + 1, b = idx % rem + k + 1;
+                if (b <= a) Sg[(size_t)a * n + b] -= Sg[(size_t)a * n + k] * Sg[(size_t)b * n + k];
+            }
+            __syncthreads();
+        }
+        double gamma = 1e300;
+        if (pd_ok) {
+            // y in Tc[0..n)
+            __syncthreads();
+            for (int i = tid; i < n; i += WG) Tc[i] = r0[i];
+            __syncthreads();
+            if (tid < 64) {
+                for (int i = 0; i < n; ++i) {
+                    double part = 0;
+                    for (int p = tid; p < i; p += 64) part += Sg[(size_t)i * n + p] * Tc[p];
+                    part = wave_sum(part);
+                    if (tid == 0) Tc[i] = (Tc[i] - part) / Sg[(size_t)i * n + i];
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                }
+            }
+            __syncthreads();
+            double pg = 0;
+            for (int i = tid; i < n; i += WG) pg += Tc[i] * Tc[i];
+            gamma = block_sum(pg, sRed);
+        }
+        const int dof = M + S.dof_offset;
+        const bool pass = pd_ok && dof >= 1 && dof < 100 && gamma < S.chi2[dof];
+        if (tid == 0) { S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma; }
+        if (!pass) {
+            __syncthreads();
+            for (int i = tid; i < n * ld; i += WG) Hrow0[i] = 0.0;
+            for (int i = tid; i < n; i += WG) r0[i] = 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ cap
+// msckf_vio.cpp:1002-1010: stack passing blocks in feature order, stop once rows > cap
+__global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    __shared__ int s_cap_from, s_stack;
+    if (threadIdx.x == 0) {
+        int stack = 0, cap_from = S.n_feat;
+        for (int j = 0; j < S.n_feat; ++j) {
+            if (S.feat_status[j] & 2) stack += 4 * S.feats[j].n_obs - 3;
+            if (S.apply_row_cap && stack > S.max_stack_rows) { cap_from = j + 1; break; }
+        }
+        s_cap_from = cap_from; s_stack = stack;
+        S.rows_out[0] = stack;
+    }
+    __syncthreads();
+    for (int j = s_cap_from; j < S.n_feat; ++j) {
+        if (!(S.feat_status[j] & 2)) continue;
+        __syncthreads();
+        const EkfFeatDev &F = S.feats[j];
+        const int n = 4 * F.n_obs - 3;
+        double *Hrow0 = S.Hs + (size_t)F.row_off * S.ld;
+        for (int i = threadIdx.x; i < n * S.ld; i += WG) Hrow0[i] = 0.0;
+        for (int i = threadIdx.x; i < n; i += WG) S.rs[F.row_off + i] = 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) S.feat_status[j] &= (uint8_t)~2;
+    }
+}
+
+// ------------------------------------------------------------------------------------ QR
+// Unblocked Householder QR of [Hs | rs] (m x d | m), in place, one workgroup per stream.
+#define QR_WG 1024
+__global__ __launch_bounds__(QR_WG) void k_ekf_qr(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    const int m = S.m_total, d = S.d, ld = S.ld;
+    if (S.rows_out[0] <= 0) return;       // nothing stacked
+    if (m <= d) { if (threadIdx.x == 0) S.rows_out[1] = m; return; }
+    double *H = S.Hs, *r = S.rs;
+    extern __shared__ double s_dyn[];     // v[m], then red[16 + d + 1]
+    double *sv = s_dyn;
+    double *sRed = s_dyn + m;
+    double *sDot = sRed + 32;
+    const int tid = threadIdx.x;
+    const int ncols_t = 256;              // threads along columns
+    const int tx = tid % ncols_t, ty = tid / ncols_t;   // 4 row groups
+    for (int k = 0; k < d && k < m - 1; ++k) {
+        double part = 0;
+        for (int i = k + tid; i < m; i += QR_WG) { const double x = H[(size_t)i * ld + k]; part += x * x; }
+        const double nrm = sqrt(block_sum(part, sRed));
+        if (nrm == 0.0) continue;         // uniform
+        const double x0 = H[(size_t)k * ld + k];
+        const double alpha = x0 > 0 ? -nrm : nrm;
+        __syncthreads();
+        for (int i = k + tid; i < m; i += QR_WG) sv[i] = (i == k) ? x0 - alpha : H[(size_t)i * ld + k];
+        __syncthreads();
+        double pv = 0;
+        for (int i = k + tid; i < m; i += QR_WG) pv += sv[i] * sv[i];
+        const double vn = block_sum(pv, sRed);
+        if (vn == 0.0) continue;
+        const double beta = 2.0 / vn;
+        // trailing columns k..d-1 and the residual (column index d)
+        for (int c0 = k; c0 <= d; c0 += ncols_t) {
+            const int c = c0 + tx;
+            double pd = 0;
+            if (c <= d) {
+                if (c < d) { for (int i = k + ty; i < m; i += 4) pd += sv[i] * H[(size_t)i * ld + c]; }
+                else { for (int i = k + ty; i < m; i += 4) pd += sv[i] * r[i]; }
+            }
+            __syncthreads();
+            sDot[ty * ncols_t + tx] = pd;
+            __syncthreads();
+            if (c <= d) {
+                const double sdot = (sDot[tx] + sDot[ncols_t + tx] + sDot[2 * ncols_t + tx] + sDot[3 * ncols_t + tx]) * beta;
+                if (c < d) { for (int i = k + ty; i < m; i += 4) H[(size_t)i * ld + c] -= sdot * sv[i]; }
+                else { for (int i = k + ty; i < m; i += 4) r[i] -= sdot * sv[i]; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) S.rows_out[1] = d;
+}
+
+// ------------------------------------------------------------------------------------ update
+// With H = first nr rows of Hs (upper-trapezoidal after QR):  T = H P, S = T H^T + s2 I = L L^T,
+// Y = L^-1 T, delta_x = Y^T L^-1 r, P <- P - Y^T Y  (== (I - K H) P, symmetric by construction).
+#define UP_WG 1024
+__global__ __launch_bounds__(UP_WG) void k_ekf_update(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    const int d = S.d, ld = S.ld;
+    const int tid = threadIdx.x;
+    if (S.rows_out[0] <= 0) { for (int i = tid; i < d; i += UP_WG) S.delta_x[i] = 0.0; return; }
+    const int nr = S.rows_out[1];
+    const bool tri = S.m_total > d;       // H upper triangular
+    double *P = S.P, *T = S.T, *Sm = S.S;
+    const double *H = S.Hs;
+    __shared__ double sRed[32];
+    // T = H P
+    for (int idx = tid; idx < nr * d; idx += UP_WG) {
+        const int i = idx / d, c = idx - i * d;
+        const double *h = H + (size_t)i * ld;
+        double s = 0;
+        for (int k = tri ? i : 0; k < d; ++k) s += h[k] * P[(size_t)k * ld + c];
+        T[(size_t)i * ld + c] = s;
+    }
+    __syncthreads();
+    // S = T H^T + sigma2 I (lower)
+    for (int idx = tid; idx < nr * nr; idx += UP_WG) {
+        const int i = idx / nr, j = idx - i * nr;
+        if (j > i) continue;
+        const double *h = H + (size_t)j * ld;
+        const double *t = T + (size_t)i * ld;
+        double s = 0;
+        for (int k = tri ? j : 0; k < d; ++k) s += t[k] * h[k];
+        if (i == j) s += S.sigma2;
+        Sm[(size_t)i * ld + j] = s;
+    }
+    __syncthreads();
+    // Cholesky, right-looking
+    for (int k = 0; k < nr; ++k) {
+        const double lkk = sqrt(Sm[(size_t)k * ld + k]);
+        __syncthreads();
+        for (int i = k + tid; i < nr; i += UP_WG) Sm[(size_t)i * ld + k] = (i == k) ? lkk : Sm[(size_t)i * ld + k] / lkk;
+        __syncthreads();
+        const int rem = nr - k - 1;
+        for (int idx = tid; idx < rem * rem; idx += UP_WG) {
+            const int a = idx / rem + k + 1, b = idx % rem + k + 1;
+            if (b <= a) Sm[(size_t)a * ld + b] -= Sm[(size_t)a * ld + k] * Sm[(size_t)b * ld + k];
+        }
+        __syncthreads();
+    }
+    // Y = L^-1 T (one thread per column, in place in T); column d holds w = L^-1 r
+    for (int c = tid; c <= d; c += UP_WG) {
+        for (int i = 0; i < nr; ++i) {
+            double s = (c < d) ? T[(size_t)i * ld + c] : S.rs[i];
+            const double *L = Sm + (size_t)i * ld;
+            if (c < d) { for (int p = 0; p < i; ++p) s -= L[p] * T[(size_t)p * ld + c]; }
+            else { for (int p = 0; p < i; ++p) s -= L[p] * S.rs[p]; }
+            s /= L[i];
+            if (c < d) T[(size_t)i * ld + c] = s; else S.rs[i] = s;
+        }
+    }
+    __syncthreads();
+    // delta_x = Y^T w
+    for (int c = tid; c < d; c += UP_WG) {
+        double s = 0;
+        for (int i = 0; i < nr; ++i) s += T[(size_t)i * ld + c] * S.rs[i];
+        S.delta_x[c] = s;
+    }
+    // P <- P - Y^T Y (lower triangle computed, mirrored)
+    for (int idx = tid; idx < d * d; idx += UP_WG) {
+        const int a = idx / d, b = idx - a * d;
+        if (b > a) continue;
+        double s = 0;
+        for (int i = 0; i < nr; ++i) s += T[(size_t)i * ld + a] * T[(size_t)i * ld + b];
+        const double v = P[(size_t)a * ld + b] - s;
+        P[(size_t)a * ld + b] = v;
+        P[(size_t)b * ld + a] = v;
+    }
+    (void)sRed;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+extern "C" {
+void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_propagate, dim3(1, n), dim3(WG), 0, st, d); }
+void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_augment, dim3(1, n), dim3(WG), 0, st, d); }
+void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d, dst);
+}
+void ekf_launch_update(const EkfStreamDev *d, int n, int max_feat, int max_m, int max_d, hipStream_t st) {
+    const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
+    hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), 0, st, d);
+    hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d);
+    const size_t lds = (size_t)(max_m + 32 + 4 * 256 + 8) * sizeof(double);
+    hipLaunchKernelGGL(k_ekf_qr, dim3(1, n), dim3(QR_WG), lds, st, d);
+    hipLaunchKernelGGL(k_ekf_update, dim3(1, n), dim3(UP_WG), 0, st, d);
+    (void)max_d;
+}
+}
