@@ -131,7 +131,23 @@ typedef struct mskf_ekf_update_args {
     int32_t *rows_out;              /* out: number of stacked rows (0 => no update applied) */
 } mskf_ekf_update_args;
 
+/* What processModel (msckf_vio.cpp:409-469) needs to propagate the covariance over one IMU sample.
+ * The host integrates the 16-dim nominal state (predictNewState, :482-531) and hands over these
+ * quantities; F, Phi (3rd-order expm + observability fix-up) and Q are formed on the device. */
+typedef struct mskf_imu_step {
+    double dt;
+    double gyro[3], acc[3];   /* bias-corrected measurements (:412-413) */
+    double R_t[9];            /* R(q)^T before the step (:422-423) */
+    double Phi00[9];          /* R(q_new) R(q_null)^T (:443) */
+    double u[3], s[3];        /* u = R(q_null) g, s = u / (u.u) (:445-446) */
+    double w1[3], w2[3];      /* [v_null - v_new]x g (:450), [dt v_null + p_null - p_new]x g (:454) */
+} mskf_imu_step;
+
 int mskf_ekf_reset(mskf_stream *s, const double *P0 /* 21x21 row-major */);
+int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_imu_step *steps);
+/* position variances P(12,12), P(13,13), P(14,14) for onlineReset (msckf_vio.cpp:1194-1196). Synchronises. */
+int mskf_ekf_get_pos_var(mskf_stream *s, double out[3]);
+int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out /* 3n */);
 int mskf_ekf_propagate(mskf_stream *s, int n_steps, const double *Phi /* n x 21x21 */, const double *Q /* n x 21x21 */);
 int mskf_ekf_augment(mskf_stream *s, const double *J /* 6x21 */);
 int mskf_ekf_update(mskf_stream *s, mskf_ekf_update_args *args);

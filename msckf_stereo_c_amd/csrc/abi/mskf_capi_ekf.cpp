@@ -101,6 +101,11 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
     D.sigma2 = s->ekf.noise_feature * s->ekf.noise_feature;   // msckf_vio.cpp:74,81
     D.max_stack_rows = s->ekf.max_stack_rows;
     D.chi2 = E.chi2;
+    // continuous_noise_cov diagonal blocks: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:70-80, 174-178)
+    D.qc[0] = s->ekf.noise_gyro * s->ekf.noise_gyro;
+    D.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
+    D.qc[2] = s->ekf.noise_acc * s->ekf.noise_acc;
+    D.qc[3] = s->ekf.noise_acc_bias * s->ekf.noise_acc_bias;
     D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.gate_T = E.gate_T; D.gate_S = E.gate_S; D.nmax = E.nmax;
     hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
     std::memcpy(D.R_c0_c1, T01.R.m, sizeof(D.R_c0_c1));
@@ -182,6 +187,49 @@ extern "C" int mskf_ekf_propagate(mskf_stream *s, int n_steps, const double *Phi
     ekf_launch_propagate((const EkfStreamDev *)X->d_small, 1, ctx->stream);
     MSKF_HIPCHK(hipGetLastError());
     return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_imu_step *steps) {
+    if (!s || n_steps < 0 || (n_steps && !steps)) return MSKF_ERR_INVALID;
+    if (n_steps == 0) return MSKF_OK;
+    EkfExtra *X = extra_of(s);
+    mskf_ctx *ctx = s->ctx;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(EkfStreamDev) + sizeof(mskf_imu_step) * (size_t)n_steps;
+    int rc = small_begin(s, X, bytes);
+    if (rc != MSKF_OK) return rc;
+    EkfStreamDev *D = (EkfStreamDev *)X->h_small;
+    std::memcpy(X->h_small + sizeof(EkfStreamDev), steps, sizeof(mskf_imu_step) * (size_t)n_steps);
+    base_desc(s, *D);
+    D->imu_steps = (const mskf_imu_step *)(X->d_small + sizeof(EkfStreamDev));
+    D->n_steps = n_steps;
+    MSKF_HIPCHK(hipMemcpyAsync(X->d_small, X->h_small, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
+    X->small_pending = true;
+    ekf_launch_propagate((const EkfStreamDev *)X->d_small, 1, ctx->stream);
+    MSKF_HIPCHK(hipGetLastError());
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out) {
+    if (!ctx || n <= 0 || !streams || !out) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
+        const EkfStreamState &E = s->ekf_state;
+        // 3 diagonal entries: a strided 2D copy (pitch ld+1 doubles)
+        MSKF_HIPCHK(hipMemcpy2DAsync(out + 3 * i, sizeof(double), E.P + (size_t)12 * E.ld + 12, sizeof(double) * (E.ld + 1),
+                                     sizeof(double), 3, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MSKF_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_get_pos_var(mskf_stream *s, double out[3]) {
+    if (!s || !out) return MSKF_ERR_INVALID;
+    mskf_stream *ss[1] = {s};
+    return mskf_ekf_get_pos_var_batch(s->ctx, 1, ss, out);
 }
 
 extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {

@@ -42,7 +42,9 @@ struct EkfStreamDev {
     double *gamma;            // n_feat
     int *rows_out;            // [0] stacked rows, [1] rows used by the update (after QR: min(m, d))
     // propagation / augmentation
-    const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q
+    const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)
+    const mskf_imu_step *imu_steps;   // or: n_steps compact IMU records, Phi/Q formed on the device
+    double qc[4];             // continuous noise variances: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:174-178)
     int n_steps;
     const double *J;          // 6 x 21
     int remove_index;         // clone to delete

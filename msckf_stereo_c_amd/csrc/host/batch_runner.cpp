@@ -1,0 +1,147 @@
+// batch_runner.cpp — see batch_runner.h.
+#include "batch_runner.h"
+#include <cstring>
+
+namespace cg {
+
+BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf) {
+    int rc = mskf_ctx_create(device, &ctx_);
+    if (rc != MSKF_OK) { error_ = mskf_last_error(); return; }
+    for (int i = 0; i < n; ++i) {
+        systems_.emplace_back(new System(calib, fe, ekf, ctx_, device));
+        if (!systems_.back()->ok()) { error_ = std::string("stream setup failed: ") + mskf_last_error(); return; }
+        systems_.back()->copy_draw_buffers = false;
+        streams_.push_back(systems_.back()->stream());
+    }
+    a1_.resize(n); a2_.resize(n); u_.resize(n); p0_.resize(n); p1_.resize(n); t_.resize(n);
+    seq.resize(n);
+    ok_ = true;
+}
+
+BatchGroup::~BatchGroup() {
+    systems_.clear();
+    if (ctx_) mskf_ctx_destroy(ctx_);
+}
+
+void BatchGroup::imu(int i, const mskf_imu_sample &s) {
+    std::shared_ptr<Imu> m(new Imu);
+    m->time_stamp = s.time_stamp;
+    m->angular_velocity = Vector3(s.angular_velocity[0], s.angular_velocity[1], s.angular_velocity[2]);
+    m->linear_acceleration = Vector3(s.linear_acceleration[0], s.linear_acceleration[1], s.linear_acceleration[2]);
+    systems_[i]->imu_callback(m);
+}
+
+#define BR_CHK(expr) do { int _rc = (expr); if (_rc != MSKF_OK) { error_ = std::string(#expr) + ": " + mskf_last_error(); return _rc; } } while (0)
+
+int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw) {
+    const int n = size();
+    if (!ok_ || n == 0) return MSKF_ERR_INVALID;
+    // ---- front-end (System::stereo_callback for every stream)
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams_[i];
+        (void)s;
+        ImageProcessor &ip = *systems_[i]->imgproc_ptr_;
+        // image size comes from the calibration the stream was created with
+        ip.phaseBegin(t[i], 0, 0);
+    }
+    BR_CHK(mskf_fe_push_stereo_batch(ctx_, n, streams_.data(), cam0, cam1, on_device));
+    for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phasePrepare1(a1_[i]);
+    BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a1_.data()));
+    for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phaseAfter1(a2_[i]);
+    BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a2_.data()));
+    for (int i = 0; i < n; ++i) {
+        systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
+        systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
+    }
+    // ---- back-end (System::backend_callback for every stream)
+    std::vector<mskf_stream *> sub_s;
+    std::vector<mskf_ekf_update_args> sub_a;
+    std::vector<int> sub_i;
+    auto run_updates = [&]() -> int {
+        sub_s.clear(); sub_a.clear(); sub_i.clear();
+        for (int i = 0; i < n; ++i) if (u_[i].n_feat > 0) { sub_s.push_back(streams_[i]); sub_a.push_back(u_[i]); sub_i.push_back(i); }
+        if (sub_s.empty()) return MSKF_OK;
+        return mskf_ekf_update_batch(ctx_, (int)sub_s.size(), sub_s.data(), sub_a.data());
+    };
+    bool any = false;
+    for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->phaseA(systems_[i]->feature_msg(), u_[i]);
+    if (!any) return MSKF_OK;
+    BR_CHK(run_updates());
+    for (int i = 0; i < n; ++i) if (systems_[i]->msckfvio_ptr()->frameActive()) systems_[i]->msckfvio_ptr()->phaseB(u_[i]); else std::memset(&u_[i], 0, sizeof(u_[i]));
+    BR_CHK(run_updates());
+    for (int i = 0; i < n; ++i) systems_[i]->msckfvio_ptr()->phaseC();
+    std::vector<double> pv(3 * (size_t)n);
+    BR_CHK(mskf_ekf_get_pos_var_batch(ctx_, n, streams_.data(), pv.data()));
+    for (int i = 0; i < n; ++i) systems_[i]->msckfvio_ptr()->phaseD(&pv[3 * i]);
+    return MSKF_OK;
+}
+
+static double ns_to_sec(long long ns) {   // apps/run_euroc_single_thread.cpp:164-166,192 (Q9)
+    const long long sec = ns / 1000000000LL, nsec = ns % 1000000000LL;
+    const double stamp_ns = (double)(int)sec * 1e9 + (double)(int)nsec;
+    return stamp_ns * 1e-9;
+}
+
+int BatchGroup::run(int first, int n_frames) {
+    const int n = size();
+    for (int k = first; k < first + n_frames; ++k) {
+        for (int i = 0; i < n; ++i) {
+            StreamSequence &q = seq[i];
+            if (!q.cam0_base || !q.imu) { error_ = "no sequence attached"; return MSKF_ERR_INVALID; }
+            const double t_img = ns_to_sec(q.t0_ns + (long long)k * q.frame_dt_ns);
+            // do { feed IMU } while (t_imu <= t_img)  (apps/run_euroc_single_thread.cpp:209-238, Q10)
+            double t_imu = 0.0;
+            do {
+                if (q.imu_cursor >= q.n_imu) { error_ = "IMU sequence exhausted"; return MSKF_ERR_CAPACITY; }
+                const mskf_imu_sample &s = q.imu[q.imu_cursor++];
+                imu(i, s);
+                t_imu = s.time_stamp;
+            } while (t_imu <= t_img);
+            const int key = k < q.n_static ? k : q.n_static + (k - q.n_static) % q.n_loop;
+            p0_[i] = q.cam0_base + (size_t)key * q.frame_bytes;
+            p1_[i] = q.cam1_base + (size_t)key * q.frame_bytes;
+            t_[i] = t_img;
+        }
+        int rc = step(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
+        if (rc != MSKF_OK) return rc;
+    }
+    return MSKF_OK;
+}
+
+MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf)
+    : n_groups_(n_groups), per_group_(per_group) {
+    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf));
+}
+
+bool MultiRunner::ok() const {
+    for (const auto &g : groups_) if (!g->ok()) return false;
+    return !groups_.empty();
+}
+
+std::string MultiRunner::error() const {
+    for (const auto &g : groups_) if (!g->error().empty()) return g->error();
+    return std::string();
+}
+
+int MultiRunner::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t) {
+    for (int g = 0; g < n_groups_; ++g) {
+        int rc = groups_[g]->step(cam0 + (size_t)g * per_group_, cam1 + (size_t)g * per_group_, on_device, t + (size_t)g * per_group_, false);
+        if (rc != MSKF_OK) return rc;
+    }
+    return MSKF_OK;
+}
+
+int MultiRunner::run(int first, int n, bool threaded) {
+    std::vector<int> rcs(n_groups_, MSKF_OK);
+    if (!threaded || n_groups_ == 1) {
+        for (int g = 0; g < n_groups_; ++g) { rcs[g] = groups_[g]->run(first, n); if (rcs[g] != MSKF_OK) return rcs[g]; }
+        return MSKF_OK;
+    }
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = groups_[g]->run(first, n); });
+    for (auto &t : th) t.join();
+    for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
+    return MSKF_OK;
+}
+
+}  // namespace cg

@@ -1,0 +1,71 @@
+// batch_runner.h — steps many independent VIO streams (cg::System objects) in lockstep so that every
+// device phase of a frame is ONE batched C-ABI call (mskf_fe_push_stereo_batch, mskf_fe_track_batch,
+// mskf_ekf_update_batch, ...).  Streams are independent units: no data crosses streams.
+// A BatchGroup owns one mskf_ctx (one HIP stream); a MultiRunner runs several groups on their own host
+// threads so the host bookkeeping of one group overlaps the kernels of another.
+#pragma once
+#include <memory>
+#include <thread>
+#include <vector>
+#include "system.h"
+
+namespace cg {
+
+struct StreamSequence {   // a looping pre-rendered stereo sequence + IMU samples for one stream
+    const uint8_t *cam0_base = nullptr, *cam1_base = nullptr;   // frame key k at base + k * frame_bytes
+    int on_device = 1;
+    size_t frame_bytes = 0;
+    int n_static = 0, n_loop = 1;
+    long long t0_ns = 0, frame_dt_ns = 50000000LL;
+    const mskf_imu_sample *imu = nullptr;   // sample j, j in [0, n_imu)
+    int n_imu = 0;
+    int imu_cursor = 0;
+};
+
+class BatchGroup {
+  public:
+    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf);
+    ~BatchGroup();
+    bool ok() const { return ok_; }
+    int size() const { return (int)systems_.size(); }
+    System &system(int i) { return *systems_[i]; }
+    void imu(int i, const mskf_imu_sample &s);
+    // one frame of every stream: front-end + back-end
+    int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw);
+    // frames [first, first+n) of the attached sequences, IMU fed in the reference harness order (Q10)
+    int run(int first, int n);
+    std::vector<StreamSequence> seq;
+    mskf_ctx *ctx() const { return ctx_; }
+    const std::string &error() const { return error_; }
+
+  private:
+    mskf_ctx *ctx_ = nullptr;
+    bool ok_ = false;
+    std::string error_;
+    std::vector<std::unique_ptr<System>> systems_;
+    std::vector<mskf_stream *> streams_;
+    std::vector<mskf_fe_track_args> a1_, a2_;
+    std::vector<mskf_ekf_update_args> u_;
+    std::vector<const uint8_t *> p0_, p1_;
+    std::vector<double> t_;
+};
+
+class MultiRunner {
+  public:
+    MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf);
+    bool ok() const;
+    int n_streams() const { return n_groups_ * per_group_; }
+    BatchGroup &group_of(int stream, int &local) { local = stream % per_group_; return *groups_[stream / per_group_]; }
+    System &system(int stream) { int l; BatchGroup &g = group_of(stream, l); return g.system(l); }
+    StreamSequence &sequence(int stream) { int l; BatchGroup &g = group_of(stream, l); return g.seq[l]; }
+    void imu(int stream, const mskf_imu_sample &s) { int l; BatchGroup &g = group_of(stream, l); g.imu(l, s); }
+    int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t);
+    int run(int first, int n, bool threaded);
+    std::string error() const;
+
+  private:
+    int n_groups_, per_group_;
+    std::vector<std::unique_ptr<BatchGroup>> groups_;
+};
+
+}  // namespace cg

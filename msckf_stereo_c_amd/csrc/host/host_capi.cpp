@@ -1,0 +1,87 @@
+// host_capi.cpp — C entry points over the host mirror classes (cg::System, MultiRunner) for the Python
+// tests and bench.py.  This is host glue above the C-ABI of include/mskf_hip.h, not part of it.
+#include <cstring>
+#include "batch_runner.h"
+
+using namespace cg;
+
+extern "C" {
+
+void *mskfh_runner_create(int device, int n_groups, int per_group, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf) {
+    MultiRunner *r = new MultiRunner(device, n_groups, per_group, *calib, *fe, *ekf);
+    if (!r->ok()) {
+        std::fprintf(stderr, "mskfh_runner_create: %s\n", r->error().c_str());
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+void mskfh_runner_destroy(void *h) { delete (MultiRunner *)h; }
+int mskfh_runner_num_streams(void *h) { return ((MultiRunner *)h)->n_streams(); }
+const char *mskfh_runner_error(void *h) { static thread_local std::string e; e = ((MultiRunner *)h)->error(); return e.c_str(); }
+
+void mskfh_runner_imu(void *h, int stream, const mskf_imu_sample *s) { ((MultiRunner *)h)->imu(stream, *s); }
+int mskfh_runner_step(void *h, const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t) {
+    return ((MultiRunner *)h)->step(cam0, cam1, on_device, t);
+}
+void mskfh_runner_set_sequence(void *h, int stream, const uint8_t *cam0_base, const uint8_t *cam1_base, int on_device, size_t frame_bytes,
+                               int n_static, int n_loop, long long t0_ns, long long frame_dt_ns, const mskf_imu_sample *imu, int n_imu) {
+    StreamSequence &q = ((MultiRunner *)h)->sequence(stream);
+    q.cam0_base = cam0_base; q.cam1_base = cam1_base; q.on_device = on_device; q.frame_bytes = frame_bytes;
+    q.n_static = n_static; q.n_loop = n_loop; q.t0_ns = t0_ns; q.frame_dt_ns = frame_dt_ns; q.imu = imu; q.n_imu = n_imu;
+    q.imu_cursor = 0;
+}
+int mskfh_runner_run(void *h, int first, int n, int threaded) { return ((MultiRunner *)h)->run(first, n, threaded != 0); }
+void mskfh_runner_keep_trajectory(void *h, int keep) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int i = 0; i < r->n_streams(); ++i) r->system(i).msckfvio_ptr()->keepTrajectory = keep != 0;
+}
+
+// ---- per-stream inspection
+int mskfh_num_features(void *h, int stream) {
+    std::vector<ImageProcessor::FeatureIDType> ids; std::vector<int> life; std::vector<Point2f> a, b;
+    ((MultiRunner *)h)->system(stream).imgproc_ptr_->dumpCurrent(ids, life, a, b);
+    return (int)ids.size();
+}
+void mskfh_get_dump(void *h, int stream, uint64_t *ids, int32_t *lifetime, mskf_point2f *cam0, mskf_point2f *cam1, mskf_tracking_info *info) {
+    std::vector<ImageProcessor::FeatureIDType> id; std::vector<int> life; std::vector<Point2f> a, b;
+    ImageProcessor &ip = *((MultiRunner *)h)->system(stream).imgproc_ptr_;
+    ip.dumpCurrent(id, life, a, b);
+    for (size_t i = 0; i < id.size(); ++i) {
+        ids[i] = id[i]; lifetime[i] = life[i];
+        cam0[i] = mskf_point2f{a[i].x, a[i].y}; cam1[i] = mskf_point2f{b[i].x, b[i].y};
+    }
+    info->time_stamp = ip.last_tracking_info.time_stamp;
+    info->before_tracking = ip.last_tracking_info.before_tracking; info->after_tracking = ip.last_tracking_info.after_tracking;
+    info->after_matching = ip.last_tracking_info.after_matching; info->after_ransac = ip.last_tracking_info.after_ransac;
+}
+int mskfh_msg_size(void *h, int stream) { return (int)((MultiRunner *)h)->system(stream).imgproc_ptr_->feature_msg_ptr_->features.size(); }
+void mskfh_get_msg(void *h, int stream, mskf_feature_meas *out) {
+    const auto &f = ((MultiRunner *)h)->system(stream).imgproc_ptr_->feature_msg_ptr_->features;
+    static_assert(sizeof(FeatureMeasurement) == sizeof(mskf_feature_meas), "record layout");
+    std::memcpy(out, f.data(), f.size() * sizeof(mskf_feature_meas));
+}
+int mskfh_num_poses(void *h, int stream) { return (int)((MultiRunner *)h)->system(stream).msckfvio_ptr()->poses().size(); }
+void mskfh_get_poses(void *h, int stream, mskf_pose *out) {
+    const auto &p = ((MultiRunner *)h)->system(stream).msckfvio_ptr()->poses();
+    std::memcpy(out, p.data(), p.size() * sizeof(mskf_pose));
+}
+int mskfh_state_dim(void *h, int stream) { int d = 0; mskf_ekf_get_dim(((MultiRunner *)h)->system(stream).stream(), &d); return d; }
+int mskfh_get_cov(void *h, int stream, double *out, int cap) { return mskf_ekf_get_cov(((MultiRunner *)h)->system(stream).stream(), out, cap); }
+void mskfh_get_imu_state(void *h, int stream, double *out) {   // same 28-double layout as the oracle's getter
+    const IMUState &s = ((MultiRunner *)h)->system(stream).msckfvio_ptr()->imuState();
+    int k = 0;
+    for (int i = 0; i < 4; ++i) out[k++] = s.orientation.q[i];
+    for (int i = 0; i < 3; ++i) out[k++] = s.position[i];
+    for (int i = 0; i < 3; ++i) out[k++] = s.velocity[i];
+    for (int i = 0; i < 3; ++i) out[k++] = s.gyro_bias[i];
+    for (int i = 0; i < 3; ++i) out[k++] = s.acc_bias[i];
+    for (int i = 0; i < 9; ++i) out[k++] = s.R_imu_cam0.m[i];
+    for (int i = 0; i < 3; ++i) out[k++] = s.t_cam0_imu[i];
+}
+int mskfh_num_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numUpdates(); }
+long long mskfh_num_resets(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numResets(); }
+int mskfh_num_clones(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numClones(); }
+void *mskfh_group_hip_stream(void *h, int stream) { int l; return mskf_ctx_hip_stream(((MultiRunner *)h)->group_of(stream, l).ctx()); }
+
+}  // extern "C"

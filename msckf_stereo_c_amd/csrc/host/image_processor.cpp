@@ -1,0 +1,467 @@
+// image_processor.cpp — host mirror of cg::ImageProcessor; see image_processor.h.
+// Reference: msckf_core/src/image_processor.cpp (line numbers cited per function).
+#include "image_processor.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+
+namespace cg {
+
+// config_io.h:13-81 conversions + image_processor.cpp:54-72 / msckf_vio.cpp:115-125 keys
+mskf_calib calib_from_yaml(const YAML::Node &n) {
+    mskf_calib c;
+    std::memset(&c, 0, sizeof(c));
+    auto model = [](const std::string &s) { return s == "equidistant" ? MSKF_MODEL_EQUIDISTANT : MSKF_MODEL_RADTAN; };
+    auto copy = [](const std::vector<double> &v, double *dst, size_t cnt, const char *what) {
+        if (v.size() != cnt) throw YAML::Exception(std::string("yaml: wrong length for ") + what);
+        for (size_t i = 0; i < cnt; ++i) dst[i] = v[i];
+    };
+    c.cam0_model = model(n["cam0"]["distortion_model"].as<std::string>());
+    c.cam1_model = model(n["cam1"]["distortion_model"].as<std::string>());
+    copy(n["cam0"]["intrinsics"].as<std::vector<double>>(), c.cam0_intrinsics, 4, "cam0.intrinsics");
+    copy(n["cam1"]["intrinsics"].as<std::vector<double>>(), c.cam1_intrinsics, 4, "cam1.intrinsics");
+    copy(n["cam0"]["distortion_coeffs"].as<std::vector<double>>(), c.cam0_distortion, 4, "cam0.distortion_coeffs");
+    copy(n["cam1"]["distortion_coeffs"].as<std::vector<double>>(), c.cam1_distortion, 4, "cam1.distortion_coeffs");
+    copy(n["cam0"]["T_cam_imu"].as<std::vector<double>>(), c.T_cam0_imu, 16, "cam0.T_cam_imu");
+    copy(n["cam1"]["T_cn_cnm1"].as<std::vector<double>>(), c.T_cam1_cam0, 16, "cam1.T_cn_cnm1");
+    copy(n["T_imu_body"].as<std::vector<double>>(), c.T_imu_body, 16, "T_imu_body");
+    // resolution is not read by the reference (image size comes from the first image); keep it as a hint
+    if (n["cam0"]["resolution"].IsDefined()) {
+        std::vector<double> r = n["cam0"]["resolution"].as<std::vector<double>>();
+        if (r.size() == 2) { c.width = (int)r[0]; c.height = (int)r[1]; }
+    }
+    return c;
+}
+
+mskf_fe_cfg fe_cfg_from_yaml(const YAML::Node &y) {
+    mskf_fe_cfg c;
+    std::memset(&c, 0, sizeof(c));
+    c.grid_row = y["grid_row"].as<int>();
+    c.grid_col = y["grid_col"].as<int>();
+    c.grid_min_feature_num = y["grid_min_feature_num"].as<int>();
+    c.grid_max_feature_num = y["grid_max_feature_num"].as<int>();
+    c.pyramid_levels = y["pyramid_levels"].as<int>();
+    c.patch_size = y["patch_size"].as<int>();
+    c.fast_threshold = y["fast_threshold"].as<int>();
+    c.ransac_threshold = y["ransac_threshold"].as<int>();   // parsed as<int>() in the reference (:83-84, Q6)
+    c.stereo_threshold = y["stereo_threshold"].as<int>();
+    c.max_iteration = y["max_iteration"].as<int>();
+    c.track_precision = y["track_precision"].as<double>();
+    c.det_rows = 30; c.det_cols = 47;                       // CornerDetector(30, 47, thr), :132
+    c.compat_flags = MSKF_COMPAT_REFERENCE;
+    return c;
+}
+
+ImageProcessor::ImageProcessor(YAML::Node cfg_cam_imu)
+    : feature_msg_ptr_(new CameraMeasurement), cfg_cam_imu_(cfg_cam_imu), have_yaml_(true),
+      prev_features_ptr(new GridFeatures()), curr_features_ptr(new GridFeatures()) {
+    std::memset(&calib_, 0, sizeof(calib_));
+    std::memset(&cfg_, 0, sizeof(cfg_));
+    std::memset(&processor_config, 0, sizeof(processor_config));
+}
+
+ImageProcessor::ImageProcessor(const mskf_calib &calib, const mskf_fe_cfg &cfg)
+    : feature_msg_ptr_(new CameraMeasurement), calib_(calib), cfg_(cfg),
+      prev_features_ptr(new GridFeatures()), curr_features_ptr(new GridFeatures()) {
+    std::memset(&processor_config, 0, sizeof(processor_config));
+}
+
+ImageProcessor::~ImageProcessor() {
+    if (debug_.is_open()) debug_.close();
+    if (own_stream_ && stream_) mskf_stream_destroy(stream_);
+    if (own_ctx_) mskf_ctx_destroy(own_ctx_);
+}
+
+void ImageProcessor::fail(const char *what, int rc) {
+    error_ = std::string(what) + ": " + mskf_last_error();
+    std::fprintf(stderr, "ImageProcessor: %s failed (%d): %s\n", what, rc, mskf_last_error());
+}
+
+// image_processor.cpp:52-124
+bool ImageProcessor::loadParameters() {
+    if (have_yaml_) {
+        calib_ = calib_from_yaml(cfg_cam_imu_);
+        YAML::Node cfg_imgproc = YAML::LoadFile("../config/app_imgproc.yaml");   // Q16
+        cfg_ = fe_cfg_from_yaml(cfg_imgproc);
+    }
+    processor_config.grid_row = cfg_.grid_row;
+    processor_config.grid_col = cfg_.grid_col;
+    processor_config.grid_min_feature_num = cfg_.grid_min_feature_num;
+    processor_config.grid_max_feature_num = cfg_.grid_max_feature_num;
+    processor_config.pyramid_levels = cfg_.pyramid_levels;
+    processor_config.patch_size = cfg_.patch_size;
+    processor_config.fast_threshold = cfg_.fast_threshold;
+    processor_config.max_iteration = cfg_.max_iteration;
+    processor_config.track_precision = cfg_.track_precision;
+    processor_config.ransac_threshold = cfg_.ransac_threshold;
+    processor_config.stereo_threshold = cfg_.stereo_threshold;
+    // :63-72
+    hm::Rigid m4_cam0_imu = hm::Rigid::from_rowmajor16(calib_.T_cam0_imu);
+    R_cam0_imu = m4_cam0_imu.R.transpose();
+    t_cam0_imu = -(R_cam0_imu * m4_cam0_imu.t);
+    hm::Rigid m4_cam1_cam0 = hm::Rigid::from_rowmajor16(calib_.T_cam1_cam0);
+    hm::Rigid T_cam1_imu = m4_cam1_cam0 * m4_cam0_imu;
+    R_cam1_imu = T_cam1_imu.R.transpose();
+    t_cam1_imu = -(R_cam1_imu * T_cam1_imu.t);
+    return true;
+}
+
+// :126-137
+bool ImageProcessor::initialize() {
+    if (!loadParameters()) return false;
+    occupancy_.assign((size_t)cfg_.det_rows * cfg_.det_cols, 0);
+    if (have_yaml_) debug_.open("debug_imageprocessor.txt");
+    return true;
+}
+
+// :205-211
+void ImageProcessor::imuCallback(const cg::ImuConstPtr &msg) {
+    if (is_first_img) return;
+    imu_msg_buffer.push_back(*msg);
+}
+
+void ImageProcessor::phaseBegin(double time_stamp, int width, int height) {
+    if (width <= 0 || height <= 0) { width = calib_.width; height = calib_.height; }
+    cam0_curr_time = time_stamp;
+    if ((cfg_.compat_flags & MSKF_COMPAT_Q2_PREV_ALIAS) && !is_first_img) cam0_prev_time = time_stamp;  // Q2 (:192)
+    img_w = width; img_h = height;
+    if (grid_height == 0) {  // Q7: function-local statics, first image wins (:250-251)
+        grid_height = height / cfg_.grid_row;
+        grid_width = width / cfg_.grid_col;
+        det_cell_h = (height + cfg_.det_rows - 1) / cfg_.det_rows;
+        det_cell_w = (width + cfg_.det_cols - 1) / cfg_.det_cols;
+    }
+}
+
+// :139-203
+void ImageProcessor::stereoCallback(const cg::Image &cam0_img, const cg::Image &cam1_img, bool is_draw) {
+    const int w = cam0_img.image.cols(), h = cam0_img.image.rows();
+    if (!stream_) {
+        // stand-alone use (no System): own context + stream sized from the first image
+        calib_.width = w; calib_.height = h;
+        mskf_ekf_cfg e;
+        std::memset(&e, 0, sizeof(e));
+        e.max_cam_state_size = 20; e.max_stack_rows = 1500; e.noise_feature = 0.035;
+        int rc = mskf_ctx_create(0, &own_ctx_);
+        if (rc == MSKF_OK) rc = mskf_stream_create(own_ctx_, &calib_, &cfg_, &e, &stream_);
+        if (rc != MSKF_OK) { fail("mskf_stream_create", rc); return; }
+        own_stream_ = true;
+    }
+    phaseBegin(cam0_img.time_stamp, w, h);
+    int rc = mskf_fe_push_stereo(stream_, cam0_img.image.data(), cam1_img.image.data(), w, h, w, cam0_img.time_stamp);
+    if (rc != MSKF_OK) { fail("mskf_fe_push_stereo", rc); return; }
+    mskf_fe_track_args a1, a2;
+    phasePrepare1(a1);
+    rc = mskf_fe_track(stream_, &a1);
+    if (rc != MSKF_OK) { fail("mskf_fe_track", rc); return; }
+    phaseAfter1(a2);
+    if (a2.n > 0) {
+        rc = mskf_fe_track(stream_, &a2);
+        if (rc != MSKF_OK) { fail("mskf_fe_track", rc); return; }
+    }
+    phaseAfter2(is_draw);
+}
+
+static void fill_args(mskf_fe_track_args &a, int n, int do_temporal, std::vector<mskf_point2f> &in, std::vector<mskf_point2f> &o0,
+                      std::vector<mskf_point2f> &o1, std::vector<mskf_point2f> &u0, std::vector<mskf_point2f> &u1,
+                      std::vector<uint8_t> &st) {
+    std::memset(&a, 0, sizeof(a));
+    o0.resize(n); o1.resize(n); u0.resize(n); u1.resize(n); st.assign(n, 0);
+    a.n = n; a.do_temporal = do_temporal;
+    a.in_pts = in.data(); a.out0 = o0.data(); a.out1 = o1.data(); a.und0 = u0.data(); a.und1 = u1.data(); a.status = st.data();
+    a.Hpred[0] = a.Hpred[4] = a.Hpred[8] = 1.0;
+}
+
+// CornerDetector::detect_features on the device's per-cell maxima: threshold + occupancy, cell order
+void ImageProcessor::detectFeatures(std::vector<Point2f> &pts, std::vector<double> &responses) {
+    const int cells = cfg_.det_rows * cfg_.det_cols;
+    cell_max_.resize(cells);
+    int n = 0;
+    int rc = mskf_fe_get_cell_maxima(stream_, cell_max_.data(), cells, &n);
+    pts.clear(); responses.clear();
+    if (rc != MSKF_OK) { fail("mskf_fe_get_cell_maxima", rc); return; }
+    for (int i = 0; i < n; ++i) {
+        if (cell_max_[i].score > cfg_.fast_threshold * 256 && !occupancy_[i]) {
+            pts.push_back(Point2f(cell_max_[i].x, cell_max_[i].y));
+            responses.push_back((double)cell_max_[i].score / 256.0);
+        }
+    }
+    std::fill(occupancy_.begin(), occupancy_.end(), 0);
+}
+
+void ImageProcessor::setGridPosition(float x, float y) {
+    int r = (int)(y / (float)det_cell_h), c = (int)(x / (float)det_cell_w);
+    r = r < 0 ? 0 : (r >= cfg_.det_rows ? cfg_.det_rows - 1 : r);
+    c = c < 0 ? 0 : (c >= cfg_.det_cols ? cfg_.det_cols - 1 : c);
+    occupancy_[(size_t)r * cfg_.det_cols + c] = 1;
+}
+
+// :321-340  H = K R K^-1
+void ImageProcessor::computeHpred(const hm::Mat3 &R_p_c, double H[9]) const {
+    const double *intr = calib_.cam0_intrinsics;
+    hm::Mat3 K; K(0, 0) = intr[0]; K(0, 2) = intr[2]; K(1, 1) = intr[1]; K(1, 2) = intr[3]; K(2, 2) = 1.0;
+    hm::Mat3 Ki; Ki(0, 0) = 1.0 / intr[0]; Ki(0, 2) = -intr[2] / intr[0]; Ki(1, 1) = 1.0 / intr[1]; Ki(1, 2) = -intr[3] / intr[1]; Ki(2, 2) = 1.0;
+    hm::Mat3 Hm = K * R_p_c * Ki;
+    std::memcpy(H, Hm.m, sizeof(double) * 9);
+}
+
+static hm::Mat3 rodrigues(const hm::Vec3 &r) {   // cv::Rodrigues, vector -> matrix
+    const double th = hm::norm(r);
+    if (th < 2.220446049250313e-16) return hm::Mat3::identity();
+    hm::Vec3 k = r / th;
+    const double c = std::cos(th), s = std::sin(th), c1 = 1 - c;
+    hm::Mat3 R = c * hm::Mat3::identity() + s * hm::skew(k);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) += c1 * k[i] * k[j];
+    return R;
+}
+
+// :850-889
+void ImageProcessor::integrateImuData(hm::Mat3 &cam0_R_p_c, hm::Mat3 &cam1_R_p_c) {
+    size_t begin = 0;
+    while (begin < imu_msg_buffer.size()) {
+        if (imu_msg_buffer[begin].time_stamp - cam0_prev_time < -0.01) ++begin;
+        else break;
+    }
+    size_t end = begin;
+    while (end < imu_msg_buffer.size()) {
+        if (imu_msg_buffer[end].time_stamp - cam0_curr_time < 0.005) ++end;
+        else break;
+    }
+    hm::Vec3 mean_ang_vel;
+    for (size_t i = begin; i < end; ++i) mean_ang_vel = mean_ang_vel + imu_msg_buffer[i].angular_velocity;
+    if (end > begin) mean_ang_vel = mean_ang_vel * (double)(1.0f / (float)(end - begin));
+    hm::Vec3 cam0_mean = R_cam0_imu.transpose() * mean_ang_vel;
+    hm::Vec3 cam1_mean = R_cam1_imu.transpose() * mean_ang_vel;
+    const double dtime = cam0_curr_time - cam0_prev_time;   // 0 under Q2
+    cam0_R_p_c = rodrigues(cam0_mean * dtime).transpose();
+    cam1_R_p_c = rodrigues(cam1_mean * dtime).transpose();
+    imu_msg_buffer.erase(imu_msg_buffer.begin(), imu_msg_buffer.begin() + end);
+}
+
+void ImageProcessor::phasePrepare1(mskf_fe_track_args &args) {
+    if (is_first_img) {
+        // initializeFirstFrame head (:247-268): detect, stereo-match all detections
+        std::vector<Point2f> det;
+        detectFeatures(det, cand_responses_det_);
+        in_pts_.resize(det.size());
+        for (size_t i = 0; i < det.size(); ++i) in_pts_[i] = mskf_point2f{det[i].x, det[i].y};
+        fill_args(args, (int)in_pts_.size(), 0, in_pts_, out0_, out1_, und0_, und1_, status_);
+        stage_ = 1;
+        return;
+    }
+    // trackFeatures head (:352-410)
+    hm::Mat3 cam0_R_p_c, cam1_R_p_c;
+    integrateImuData(cam0_R_p_c, cam1_R_p_c);
+    t_ids_.clear(); t_lifetime_.clear(); in_pts_.clear();
+    for (const auto &item : *prev_features_ptr)
+        for (const auto &pf : item.second) {
+            t_ids_.push_back(pf.id);
+            t_lifetime_.push_back(pf.lifetime);
+            in_pts_.push_back(mskf_point2f{pf.cam0_point.x, pf.cam0_point.y});
+        }
+    fill_args(args, (int)in_pts_.size(), 1, in_pts_, out0_, out1_, und0_, und1_, status_);
+    computeHpred(cam0_R_p_c, args.Hpred);
+    stage_ = 2;
+}
+
+static bool cmpResponse(const float &a, const float &b) { return a > b; }
+
+// :270-316
+void ImageProcessor::initializeFirstFrameTail() {
+    GridFeatures grid_new_features;
+    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) grid_new_features[code] = std::vector<FeatureMetaData>(0);
+    for (size_t i = 0; i < status_.size(); ++i) {
+        if (!(status_[i] & 2)) continue;
+        FeatureMetaData nf;
+        nf.id = 0; nf.lifetime = 0;
+        nf.response = (float)cand_responses_det_[i];
+        nf.cam0_point = Point2f(out0_[i].x, out0_[i].y);
+        nf.cam1_point = Point2f(out1_[i].x, out1_[i].y);
+        nf.und0 = Point2f(und0_[i].x, und0_[i].y);
+        nf.und1 = Point2f(und1_[i].x, und1_[i].y);
+        int row = static_cast<int>(nf.cam0_point.y / grid_height);
+        int col = static_cast<int>(nf.cam0_point.x / grid_width);
+        grid_new_features[row * cfg_.grid_col + col].push_back(nf);
+    }
+    for (auto &item : grid_new_features)   // Q19: stable sort is the defined behaviour
+        std::stable_sort(item.second.begin(), item.second.end(),
+                         [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
+    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) {
+        std::vector<FeatureMetaData> &features_this_grid = (*curr_features_ptr)[code];
+        std::vector<FeatureMetaData> &new_features_this_grid = grid_new_features[code];
+        for (int k = 0; k < cfg_.grid_min_feature_num && k < (int)new_features_this_grid.size(); ++k) {
+            features_this_grid.push_back(new_features_this_grid[k]);
+            features_this_grid.back().id = next_feature_id++;
+            features_this_grid.back().lifetime = 1;
+        }
+    }
+}
+
+// :416-513
+void ImageProcessor::trackFeaturesTail() {
+    before_tracking = (int)t_ids_.size();
+    if (t_ids_.empty()) return;   // :383
+    after_tracking = 0; after_matching = 0; after_ransac = 0;
+    for (size_t i = 0; i < status_.size(); ++i) {
+        if (!(status_[i] & 1)) continue;
+        ++after_tracking;
+        if (!(status_[i] & 2)) continue;
+        ++after_matching;
+        // Q5: RANSAC disabled
+        const Point2f c0(out0_[i].x, out0_[i].y);
+        int row = static_cast<int>(c0.y / grid_height);
+        int col = static_cast<int>(c0.x / grid_width);
+        int code = row * cfg_.grid_col + col;   // Q7: col may equal grid_col
+        (*curr_features_ptr)[code].push_back(FeatureMetaData());
+        FeatureMetaData &g = (*curr_features_ptr)[code].back();
+        g.id = t_ids_[i];
+        g.response = 0.f;
+        g.lifetime = t_lifetime_[i] + 1;
+        g.cam0_point = c0;
+        g.cam1_point = Point2f(out1_[i].x, out1_[i].y);
+        g.und0 = Point2f(und0_[i].x, und0_[i].y);
+        g.und1 = Point2f(und1_[i].x, und1_[i].y);
+        ++after_ransac;
+    }
+}
+
+// :622-688
+void ImageProcessor::addNewFeaturesHead() {
+    for (const auto &features : *curr_features_ptr)
+        for (const auto &feature : features.second) {
+            const int y = static_cast<int>(feature.cam0_point.y);
+            const int x = static_cast<int>(feature.cam0_point.x);
+            setGridPosition((float)x, (float)y);
+        }
+    std::vector<Point2f> new_features;
+    detectFeatures(new_features, cand_responses_det_);
+    std::vector<std::vector<std::pair<Point2f, double>>> sieve((size_t)cfg_.grid_row * cfg_.grid_col);
+    for (size_t i = 0; i < new_features.size(); ++i) {
+        int row = static_cast<int>(new_features[i].y / grid_height);
+        int col = static_cast<int>(new_features[i].x / grid_width);
+        size_t code = (size_t)(row * cfg_.grid_col + col);
+        if (code >= sieve.size()) continue;   // the reference indexes out of bounds here (Q7); defined: dropped
+        sieve[code].push_back(std::make_pair(new_features[i], cand_responses_det_[i]));
+    }
+    in_pts_.clear(); cand_responses_sieved_.clear();
+    for (auto &item : sieve) {
+        if ((int)item.size() > cfg_.grid_max_feature_num) {
+            std::stable_sort(item.begin(), item.end(),
+                             [](const std::pair<Point2f, double> &a, const std::pair<Point2f, double> &b) { return a.second > b.second; });
+            item.erase(item.begin() + cfg_.grid_max_feature_num, item.end());
+        }
+        for (const auto &p : item) { in_pts_.push_back(mskf_point2f{p.first.x, p.first.y}); cand_responses_sieved_.push_back(p.second); }
+    }
+}
+
+// :690-750
+void ImageProcessor::addNewFeaturesTail() {
+    const bool q4 = (cfg_.compat_flags & MSKF_COMPAT_Q4_RESPONSE_INDEX) != 0;
+    GridFeatures grid_new_features;
+    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) grid_new_features[code] = std::vector<FeatureMetaData>(0);
+    for (size_t i = 0; i < status_.size(); ++i) {
+        if (!(status_[i] & 2)) continue;
+        FeatureMetaData nf;
+        nf.id = 0; nf.lifetime = 0;
+        nf.response = (float)(q4 ? cand_responses_det_[i] : cand_responses_sieved_[i]);   // Q4 (:698)
+        nf.cam0_point = Point2f(out0_[i].x, out0_[i].y);
+        nf.cam1_point = Point2f(out1_[i].x, out1_[i].y);
+        nf.und0 = Point2f(und0_[i].x, und0_[i].y);
+        nf.und1 = Point2f(und1_[i].x, und1_[i].y);
+        int row = static_cast<int>(nf.cam0_point.y / grid_height);
+        int col = static_cast<int>(nf.cam0_point.x / grid_width);
+        grid_new_features[row * cfg_.grid_col + col].push_back(nf);
+    }
+    for (auto &item : grid_new_features)
+        std::stable_sort(item.second.begin(), item.second.end(),
+                         [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
+    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) {
+        std::vector<FeatureMetaData> &features_this_grid = (*curr_features_ptr)[code];
+        std::vector<FeatureMetaData> &new_features_this_grid = grid_new_features[code];
+        if ((int)features_this_grid.size() >= cfg_.grid_min_feature_num) continue;
+        int vacancy_num = cfg_.grid_min_feature_num - (int)features_this_grid.size();
+        for (int k = 0; k < vacancy_num && k < (int)new_features_this_grid.size(); ++k) {
+            features_this_grid.push_back(new_features_this_grid[k]);
+            features_this_grid.back().id = next_feature_id++;
+            features_this_grid.back().lifetime = 1;
+        }
+    }
+}
+
+// :758-768
+void ImageProcessor::pruneGridFeatures() {
+    for (auto &item : *curr_features_ptr) {
+        auto &grid_features = item.second;
+        if ((int)grid_features.size() <= cfg_.grid_max_feature_num) continue;
+        std::stable_sort(grid_features.begin(), grid_features.end(),
+                         [](const FeatureMetaData &a, const FeatureMetaData &b) { return a.lifetime > b.lifetime; });
+        grid_features.erase(grid_features.begin() + cfg_.grid_max_feature_num, grid_features.end());
+    }
+}
+
+void ImageProcessor::phaseAfter1(mskf_fe_track_args &args2) {
+    std::memset(&args2, 0, sizeof(args2));
+    if (stage_ == 1) {
+        initializeFirstFrameTail();
+        is_first_img = false;
+        stage_ = 0;
+        return;
+    }
+    trackFeaturesTail();
+    addNewFeaturesHead();
+    fill_args(args2, (int)in_pts_.size(), 0, in_pts_, out0_, out1_, und0_, und1_, status_);
+    stage_ = 3;
+}
+
+void ImageProcessor::phaseAfter2(bool is_draw) {
+    if (stage_ == 3) {
+        addNewFeaturesTail();
+        pruneGridFeatures();
+        stage_ = 0;
+    }
+    if (is_draw) {   // :163-184
+        prev_ids_.clear();
+        for (const auto &g : *prev_features_ptr) for (const auto &f : g.second) prev_ids_.push_back(f.id);
+        prev_cam0_points_.clear(); prev_cam1_points_.clear(); curr_cam0_points_.clear(); curr_cam1_points_.clear();
+        for (const auto &g : *prev_features_ptr) for (const auto &f : g.second) { prev_cam0_points_[f.id] = f.cam0_point; prev_cam1_points_[f.id] = f.cam1_point; }
+        for (const auto &g : *curr_features_ptr) for (const auto &f : g.second) { curr_cam0_points_[f.id] = f.cam0_point; curr_cam1_points_[f.id] = f.cam1_point; }
+    }
+    publish();
+    // :192-200
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q2_PREV_ALIAS)) cam0_prev_time = cam0_curr_time;
+    prev_features_ptr = curr_features_ptr;
+    mskf_fe_swap(stream_);
+    curr_features_ptr.reset(new GridFeatures());
+    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) (*curr_features_ptr)[code] = std::vector<FeatureMetaData>(0);
+}
+
+// :1137-1182
+void ImageProcessor::publish() {
+    feature_msg_ptr_->time_stamp = cam0_curr_time;
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) feature_msg_ptr_->features.clear();
+    size_t i = 0;
+    for (const auto &g : *curr_features_ptr)
+        for (const auto &f : g.second) {
+            feature_msg_ptr_->features.push_back(FeatureMeasurement{0, 0, 0, 0, 0});   // Q1: never cleared
+            FeatureMeasurement &m = feature_msg_ptr_->features[i];
+            m.id = (unsigned int)f.id;
+            m.u0 = f.und0.x; m.v0 = f.und0.y; m.u1 = f.und1.x; m.v1 = f.und1.y;
+            ++i;
+        }
+    last_tracking_info = TrackingInfo{cam0_curr_time, before_tracking, after_tracking, after_matching, after_ransac};
+    if (debug_.is_open())
+        debug_ << std::fixed << std::setprecision(9) << cam0_curr_time << ": " << before_tracking << ", " << after_tracking << ", "
+               << after_matching << ", " << after_ransac << std::endl;
+}
+
+void ImageProcessor::dumpCurrent(std::vector<FeatureIDType> &ids, std::vector<int> &lifetime, std::vector<Point2f> &cam0,
+                                 std::vector<Point2f> &cam1) const {
+    // after phaseAfter2 the published grid is prev_features_ptr
+    ids.clear(); lifetime.clear(); cam0.clear(); cam1.clear();
+    for (const auto &g : *prev_features_ptr)
+        for (const auto &f : g.second) { ids.push_back(f.id); lifetime.push_back(f.lifetime); cam0.push_back(f.cam0_point); cam1.push_back(f.cam1_point); }
+}
+
+}  // namespace cg

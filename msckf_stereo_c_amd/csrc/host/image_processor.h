@@ -1,0 +1,141 @@
+// image_processor.h — host mirror of cg::ImageProcessor (reference msckf_core/include/image_processor.h:27-367).
+//
+// Same public surface (ctor from the camchain YAML node, initialize(), stereoCallback(), imuCallback(),
+// feature_msg_ptr_, the five id/point containers, processor_config).  All pixel work goes through the
+// C-ABI (include/mskf_hip.h): pyramids, detector maxima, pyramidal LK + stereo matching + gates run
+// as HIP kernels; this class keeps the reference's bookkeeping (grid buckets, sorting, ids, message).
+// stereoCallback() is exactly phasePush -> phasePrepare1 -> track -> phaseAfter1 -> track -> phaseAfter2;
+// BatchRunner drives the same phases for many streams with one batched device call per phase.
+#pragma once
+#include <fstream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../../include/mskf_hip.h"
+#include "cg_types.h"
+#include "yaml_lite.h"
+
+namespace cg {
+
+mskf_calib calib_from_yaml(const YAML::Node &cfg_cam_imu);
+mskf_fe_cfg fe_cfg_from_yaml(const YAML::Node &cfg_imgproc);
+
+class ImageProcessor {
+  public:
+    // reference constructor (image_processor.cpp:32-42); config paths as in the reference (Q16)
+    explicit ImageProcessor(YAML::Node cfg_cam_imu);
+    // explicit-configuration constructor used by System / BatchRunner
+    ImageProcessor(const mskf_calib &calib, const mskf_fe_cfg &cfg);
+    ImageProcessor(const ImageProcessor &) = delete;
+    ImageProcessor operator=(const ImageProcessor &) = delete;
+    ~ImageProcessor();
+
+    bool initialize();
+    void stereoCallback(const cg::Image &cam0_img, const cg::Image &cam1_img, bool is_draw = false);
+    void imuCallback(const cg::ImuConstPtr &msg);
+
+    std::shared_ptr<CameraMeasurement> feature_msg_ptr_;
+
+    typedef unsigned long long int FeatureIDType;
+    std::vector<FeatureIDType> prev_ids_;
+    std::map<FeatureIDType, cg::Point2f> prev_cam0_points_;
+    std::map<FeatureIDType, cg::Point2f> prev_cam1_points_;
+    std::map<FeatureIDType, cg::Point2f> curr_cam0_points_;
+    std::map<FeatureIDType, cg::Point2f> curr_cam1_points_;
+
+    struct ProcessorConfig {
+        int grid_row;
+        int grid_col;
+        int grid_min_feature_num;
+        int grid_max_feature_num;
+        int pyramid_levels;
+        int patch_size;
+        int fast_threshold;
+        int max_iteration;
+        double track_precision;
+        double ransac_threshold;
+        double stereo_threshold;
+    };
+    ProcessorConfig processor_config;
+
+    typedef std::shared_ptr<ImageProcessor> Ptr;
+    typedef std::shared_ptr<const ImageProcessor> ConstPtr;
+
+    // ---- device attachment + phased interface (BatchRunner)
+    void attach(mskf_stream *s) { stream_ = s; }
+    mskf_stream *stream() const { return stream_; }
+    void phaseBegin(double time_stamp, int width, int height);      // timestamps, Q2 aliasing, grid size (Q7)
+    void phasePrepare1(mskf_fe_track_args &args);                   // first frame: detections; else prev features
+    void phaseAfter1(mskf_fe_track_args &args);                     // consume results; prepare new-feature candidates
+    void phaseAfter2(bool is_draw);                                 // addNewFeatures tail, prune, publish, rotate
+    bool isFirstImage() const { return is_first_img; }
+
+    // debug / parity: live grid in flatten order
+    void dumpCurrent(std::vector<FeatureIDType> &ids, std::vector<int> &lifetime, std::vector<Point2f> &cam0,
+                     std::vector<Point2f> &cam1) const;
+    TrackingInfo last_tracking_info{0, 0, 0, 0, 0};
+    const std::string &error() const { return error_; }
+
+  private:
+    struct FeatureMetaData {
+        FeatureIDType id;
+        float response;
+        int lifetime;
+        cg::Point2f cam0_point;
+        cg::Point2f cam1_point;
+        cg::Point2f und0, und1;   // undistorted normalised coordinates (what publish() sends)
+    };
+    typedef std::map<int, std::vector<FeatureMetaData>> GridFeatures;
+
+    bool loadParameters();
+    void detectFeatures(std::vector<Point2f> &pts, std::vector<double> &responses);  // CornerDetector::detect_features
+    void setGridPosition(float x, float y);                                         // CornerDetector::set_grid_position
+    void integrateImuData(hm::Mat3 &cam0_R_p_c, hm::Mat3 &cam1_R_p_c);
+    void computeHpred(const hm::Mat3 &R_p_c, double H[9]) const;
+    void initializeFirstFrameTail();
+    void trackFeaturesTail();
+    void addNewFeaturesHead();
+    void addNewFeaturesTail();
+    void pruneGridFeatures();
+    void publish();
+    void fail(const char *what, int rc);
+
+    YAML::Node cfg_cam_imu_;
+    bool have_yaml_ = false;
+    mskf_calib calib_;
+    mskf_fe_cfg cfg_;
+    mskf_stream *stream_ = nullptr;
+    mskf_ctx *own_ctx_ = nullptr;   // only when constructed stand-alone
+    bool own_stream_ = false;
+    std::string error_;
+
+    bool is_first_img = true;
+    FeatureIDType next_feature_id = 0;   // Q3: defined as 0
+    std::vector<cg::Imu> imu_msg_buffer;
+    hm::Mat3 R_cam0_imu, R_cam1_imu;
+    hm::Vec3 t_cam0_imu, t_cam1_imu;
+    double cam0_prev_time = 0, cam0_curr_time = 0;
+    int img_w = 0, img_h = 0;
+    int grid_height = 0, grid_width = 0;
+    int det_cell_w = 0, det_cell_h = 0;
+    std::vector<uint8_t> occupancy_;
+    std::shared_ptr<GridFeatures> prev_features_ptr, curr_features_ptr;
+    int before_tracking = 0, after_tracking = 0, after_matching = 0, after_ransac = 0;
+
+    // per-frame scratch shared between phases
+    std::vector<mskf_point2f> in_pts_, out0_, out1_, und0_, und1_;
+    std::vector<uint8_t> status_;
+    std::vector<FeatureIDType> t_ids_;
+    std::vector<int> t_lifetime_;
+    std::vector<double> cand_responses_det_;     // responses in detection order (Q4)
+    std::vector<double> cand_responses_sieved_;  // responses in sieve order
+    std::vector<mskf_corner> cell_max_;
+    int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
+    std::ofstream debug_;
+};
+
+typedef ImageProcessor::Ptr ImageProcessorPtr;
+typedef ImageProcessor::ConstPtr ImageProcessorConstPtr;
+
+}  // namespace cg

@@ -1,0 +1,566 @@
+// msckf_vio.cpp — host mirror of cg::MsckfVio; see msckf_vio.h.
+// Reference: msckf_core/src/msckf_vio.cpp and msckf_core/include/feature.hpp (lines cited per function).
+#include "msckf_vio.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include "image_processor.h"
+#include "kinematics.h"
+
+namespace cg {
+
+// config/app_msckfvio.yaml keys (msckf_vio.cpp:58-128)
+mskf_ekf_cfg ekf_cfg_from_yaml(const YAML::Node &y) {
+    mskf_ekf_cfg c;
+    std::memset(&c, 0, sizeof(c));
+    c.frame_rate = y["frame_rate"].as<double>();
+    c.position_std_threshold = y["position_std_threshold"].as<double>();
+    c.rotation_threshold = y["rotation_threshold"].as<double>();
+    c.translation_threshold = y["translation_threshold"].as<double>();
+    c.tracking_rate_threshold = y["tracking_rate_threshold"].as<double>();
+    c.feature_translation_threshold = y["feature/config/translation_threshold"].as<double>();
+    c.noise_gyro = y["noise/gyro"].as<double>();
+    c.noise_acc = y["noise/acc"].as<double>();
+    c.noise_gyro_bias = y["noise/gyro_bias"].as<double>();
+    c.noise_acc_bias = y["noise/acc_bias"].as<double>();
+    c.noise_feature = y["noise/feature"].as<double>();
+    std::vector<double> v = y["initial_state/velocity"].as<std::vector<double>>();
+    for (int i = 0; i < 3 && i < (int)v.size(); ++i) c.init_velocity[i] = v[i];
+    c.cov_velocity = y["initial_covariance/velocity"].as<double>();
+    c.cov_gyro_bias = y["initial_covariance/gyro_bias"].as<double>();
+    c.cov_acc_bias = y["initial_covariance/acc_bias"].as<double>();
+    c.cov_ext_rot = y["initial_covariance/extrinsic_rotation_cov"].as<double>();
+    c.cov_ext_trans = y["initial_covariance/extrinsic_translation_cov"].as<double>();
+    c.max_cam_state_size = (int)y["max_cam_state_size"].as<double>();
+    c.chi2_mode = 0;
+    c.max_stack_rows = 1500;   // msckf_vio.cpp:1009
+    return c;
+}
+
+MsckfVio::MsckfVio(YAML::Node cfg_cam_imu) : cfg_cam_imu_(cfg_cam_imu), have_yaml_(true) {
+    std::memset(&calib_, 0, sizeof(calib_));
+    std::memset(&cfg_, 0, sizeof(cfg_));
+}
+
+MsckfVio::MsckfVio(const mskf_calib &calib, const mskf_ekf_cfg &cfg) : calib_(calib), cfg_(cfg) {}
+
+MsckfVio::~MsckfVio() {
+    if (pose_outfile_.is_open()) pose_outfile_.close();
+}
+
+void MsckfVio::fail(const char *what, int rc) {
+    error_ = std::string(what) + ": " + mskf_last_error();
+    std::fprintf(stderr, "MsckfVio: %s failed (%d): %s\n", what, rc, mskf_last_error());
+}
+
+// msckf_vio.cpp:58-162
+bool MsckfVio::loadParameters() {
+    if (have_yaml_) {
+        calib_ = calib_from_yaml(cfg_cam_imu_);
+        YAML::Node y = YAML::LoadFile("../config/app_msckfvio.yaml");   // Q16
+        cfg_ = ekf_cfg_from_yaml(y);
+    }
+    feat_translation_threshold_ = cfg_.feature_translation_threshold;
+    gyro_noise_ = cfg_.noise_gyro * cfg_.noise_gyro;            // :77-81 variance, not std
+    acc_noise_ = cfg_.noise_acc * cfg_.noise_acc;
+    gyro_bias_noise_ = cfg_.noise_gyro_bias * cfg_.noise_gyro_bias;
+    acc_bias_noise_ = cfg_.noise_acc_bias * cfg_.noise_acc_bias;
+    observation_noise_ = cfg_.noise_feature * cfg_.noise_feature;
+    state_server.imu_state.velocity = Vector3(cfg_.init_velocity[0], cfg_.init_velocity[1], cfg_.init_velocity[2]);
+    hm::Rigid T_cam0_imu = hm::Rigid::from_rowmajor16(calib_.T_cam0_imu).inverse();   // :115-119
+    state_server.imu_state.R_imu_cam0 = T_cam0_imu.R.transpose();
+    state_server.imu_state.t_cam0_imu = T_cam0_imu.t;
+    T_cam0_cam1_ = hm::Rigid::from_rowmajor16(calib_.T_cam1_cam0);                      // :121-122
+    T_imu_body_ = hm::Rigid::from_rowmajor16(calib_.T_imu_body).inverse();             // :124-125
+    return true;
+}
+
+// :102-112
+void MsckfVio::resetCov() {
+    double P0[21 * 21];
+    std::memset(P0, 0, sizeof(P0));
+    for (int i = 3; i < 6; ++i) P0[i * 21 + i] = cfg_.cov_gyro_bias;
+    for (int i = 6; i < 9; ++i) P0[i * 21 + i] = cfg_.cov_velocity;
+    for (int i = 9; i < 12; ++i) P0[i * 21 + i] = cfg_.cov_acc_bias;
+    for (int i = 15; i < 18; ++i) P0[i * 21 + i] = cfg_.cov_ext_rot;
+    for (int i = 18; i < 21; ++i) P0[i * 21 + i] = cfg_.cov_ext_trans;
+    if (stream_) {
+        int rc = mskf_ekf_reset(stream_, P0);
+        if (rc != MSKF_OK) fail("mskf_ekf_reset", rc);
+    }
+}
+
+// :164-188
+bool MsckfVio::initialize() {
+    if (!loadParameters()) return false;
+    if (!stream_) { error_ = "MsckfVio: no device stream attached"; return false; }
+    resetCov();
+    if (have_yaml_) pose_outfile_.open("pose_out.txt");
+    return error_.empty();
+}
+
+// :190-207
+void MsckfVio::imuCallback(const cg::ImuConstPtr &msg) {
+    imu_msg_buffer.push_back(*msg);
+    if (!is_gravity_set) {
+        if (imu_msg_buffer.size() < 200) return;
+        initializeGravityAndBias();
+        is_gravity_set = true;
+    }
+}
+
+// :209-241
+void MsckfVio::initializeGravityAndBias() {
+    Vector3 sum_w, sum_a;
+    for (const auto &m : imu_msg_buffer) { sum_w = sum_w + m.angular_velocity; sum_a = sum_a + m.linear_acceleration; }
+    state_server.imu_state.gyro_bias = sum_w / (double)imu_msg_buffer.size();
+    Vector3 gravity_imu = sum_a / (double)imu_msg_buffer.size();
+    const double gn = hm::norm(gravity_imu);
+    gravity_ = Vector3(0.0, 0.0, -gn);
+    kin::quaternion_of(kin::shortest_arc(gravity_imu, -gravity_).transpose(), state_server.imu_state.orientation.q);
+}
+
+// :243-304
+bool MsckfVio::resetCallback() {
+    IMUState &s = state_server.imu_state;
+    s.time = 0.0;
+    s.orientation = Quat(); s.position = Vector3(); s.velocity = Vector3(); s.gyro_bias = Vector3(); s.acc_bias = Vector3();
+    s.orientation_null = Quat(); s.position_null = Vector3(); s.velocity_null = Vector3();
+    state_server.cam_states.clear();
+    resetCov();
+    map_server.clear();
+    imu_msg_buffer.clear();
+    is_gravity_set = false;
+    is_first_img = true;
+    return true;
+}
+
+// :306-375
+void MsckfVio::featureCallback(const CameraMeasurementConstPtr &msg) {
+    mskf_ekf_update_args upd;
+    if (!phaseA(msg, upd)) return;
+    if (upd.n_feat > 0) {
+        int rc = mskf_ekf_update(stream_, &upd);
+        if (rc != MSKF_OK) { fail("mskf_ekf_update", rc); return; }
+    }
+    phaseB(upd);
+    if (upd.n_feat > 0) {
+        int rc = mskf_ekf_update(stream_, &upd);
+        if (rc != MSKF_OK) { fail("mskf_ekf_update", rc); return; }
+    }
+    phaseC();
+    if (cfg_.position_std_threshold > 0) {
+        double pv[3];
+        int rc = mskf_ekf_get_pos_var(stream_, pv);
+        if (rc != MSKF_OK) { fail("mskf_ekf_get_pos_var", rc); return; }
+        phaseD(pv);
+    }
+}
+
+bool MsckfVio::phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args &upd) {
+    std::memset(&upd, 0, sizeof(upd));
+    frame_active_ = false;
+    if (!is_gravity_set) return false;
+    if (is_first_img) { is_first_img = false; state_server.imu_state.time = msg->time_stamp; }
+    frame_active_ = true;
+    frame_time_ = msg->time_stamp;
+    batchImuProcessing(msg->time_stamp);
+    stateAugmentation(msg->time_stamp);
+    addFeatureObservations(msg);
+    buildLostFeatureUpdate(upd);
+    return true;
+}
+
+// :377-407 + the state part of processModel (:409-480); the covariance part runs on the device
+void MsckfVio::batchImuProcessing(double time_bound) {
+    int used = 0;
+    imu_steps_.clear();
+    IMUState &s = state_server.imu_state;
+    for (const auto &m : imu_msg_buffer) {
+        const double t = m.time_stamp;
+        if (t < s.time) { ++used; continue; }
+        if (t > time_bound) break;
+        // processModel
+        mskf_imu_step st;
+        const Vector3 gyro = m.angular_velocity - s.gyro_bias;
+        const Vector3 acc = m.linear_acceleration - s.acc_bias;
+        const double dtime = t - s.time;
+        st.dt = dtime;
+        const hm::Mat3 Rt = kin::rotation_of(s.orientation.q).transpose();
+        for (int i = 0; i < 3; ++i) { st.gyro[i] = gyro[i]; st.acc[i] = acc[i]; }
+        std::memcpy(st.R_t, Rt.m, sizeof(st.R_t));
+        predictNewState(dtime, gyro, acc);
+        const hm::Mat3 R_kk_1 = kin::rotation_of(s.orientation_null.q);
+        const hm::Mat3 Phi00 = kin::rotation_of(s.orientation.q) * R_kk_1.transpose();
+        std::memcpy(st.Phi00, Phi00.m, sizeof(st.Phi00));
+        const Vector3 u = R_kk_1 * gravity_;
+        const Vector3 sv = (1.0 / hm::dot(u, u)) * u;
+        const Vector3 w1 = hm::skew(s.velocity_null - s.velocity) * gravity_;
+        const Vector3 w2 = hm::skew(dtime * s.velocity_null + s.position_null - s.position) * gravity_;
+        for (int i = 0; i < 3; ++i) { st.u[i] = u[i]; st.s[i] = sv[i]; st.w1[i] = w1[i]; st.w2[i] = w2[i]; }
+        imu_steps_.push_back(st);
+        s.orientation_null = s.orientation;
+        s.position_null = s.position;
+        s.velocity_null = s.velocity;
+        s.time = t;
+        ++used;
+    }
+    s.id = next_state_id_++;
+    imu_msg_buffer.erase(imu_msg_buffer.begin(), imu_msg_buffer.begin() + used);
+    if (!imu_steps_.empty()) {
+        int rc = mskf_ekf_propagate_imu(stream_, (int)imu_steps_.size(), imu_steps_.data());
+        if (rc != MSKF_OK) fail("mskf_ekf_propagate_imu", rc);
+    }
+}
+
+// :482-531
+void MsckfVio::predictNewState(double dt, const Vector3 &gyro, const Vector3 &acc) {
+    const double gn = hm::norm(gyro);
+    double Om[4][4] = {{0}};
+    const hm::Mat3 ms = -hm::skew(gyro);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Om[i][j] = ms(i, j); Om[i][3] = gyro[i]; Om[3][i] = -gyro[i]; }
+    double *q = state_server.imu_state.orientation.q;
+    Vector3 &v = state_server.imu_state.velocity;
+    Vector3 &p = state_server.imu_state.position;
+    auto apply = [&](double cI, double cO, double post, double *o) {
+        for (int i = 0; i < 4; ++i) {
+            double s = 0;
+            for (int j = 0; j < 4; ++j) s += ((i == j ? cI : 0.0) + cO * Om[i][j]) * q[j];
+            o[i] = s * post;
+        }
+    };
+    double dq_dt[4], dq_dt2[4];
+    if (gn > 1e-5) {
+        apply(std::cos(gn * dt * 0.5), 1 / gn * std::sin(gn * dt * 0.5), 1.0, dq_dt);
+        apply(std::cos(gn * dt * 0.25), 1 / gn * std::sin(gn * dt * 0.25), 1.0, dq_dt2);
+    } else {
+        apply(1.0, 0.5 * dt, std::cos(gn * dt * 0.5), dq_dt);
+        apply(1.0, 0.25 * dt, std::cos(gn * dt * 0.25), dq_dt2);
+    }
+    const hm::Mat3 dR_dt_t = kin::rotation_of(dq_dt).transpose();
+    const hm::Mat3 dR_dt2_t = kin::rotation_of(dq_dt2).transpose();
+    const Vector3 &g = gravity_;
+    const Vector3 k1_v_dot = kin::rotation_of(q).transpose() * acc + g;
+    const Vector3 k1_p_dot = v;
+    const Vector3 k1_v = v + k1_v_dot * dt / 2;
+    const Vector3 k2_v_dot = dR_dt2_t * acc + g;
+    const Vector3 k2_p_dot = k1_v;
+    const Vector3 k2_v = v + k2_v_dot * dt / 2;
+    const Vector3 k3_v_dot = dR_dt2_t * acc + g;
+    const Vector3 k3_p_dot = k2_v;
+    const Vector3 k3_v = v + k3_v_dot * dt;
+    const Vector3 k4_v_dot = dR_dt_t * acc + g;
+    const Vector3 k4_p_dot = k3_v;
+    for (int i = 0; i < 4; ++i) q[i] = dq_dt[i];
+    kin::normalize4(q);
+    v = v + dt / 6 * (k1_v_dot + 2 * k2_v_dot + 2 * k3_v_dot + k4_v_dot);
+    p = p + dt / 6 * (k1_p_dot + 2 * k2_p_dot + 2 * k3_p_dot + k4_p_dot);
+}
+
+// :533-585
+void MsckfVio::stateAugmentation(double time) {
+    const hm::Mat3 &R_i_c = state_server.imu_state.R_imu_cam0;
+    const Vector3 &t_c_i = state_server.imu_state.t_cam0_imu;
+    const hm::Mat3 R_w_i = kin::rotation_of(state_server.imu_state.orientation.q);
+    const hm::Mat3 R_w_c = R_i_c * R_w_i;
+    const Vector3 t_c_w = state_server.imu_state.position + R_w_i.transpose() * t_c_i;
+    CAMState &cs = state_server.cam_states[state_server.imu_state.id];
+    cs.id = state_server.imu_state.id;
+    cs.time = time;
+    kin::quaternion_of(R_w_c, cs.orientation.q);
+    cs.position = t_c_w;
+    cs.orientation_null = cs.orientation;
+    cs.position_null = cs.position;
+
+    double J[6 * 21];
+    std::memset(J, 0, sizeof(J));
+    const hm::Mat3 sk = hm::skew(R_w_i.transpose() * t_c_i);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { J[i * 21 + j] = R_i_c(i, j); J[(3 + i) * 21 + j] = sk(i, j); }
+        J[i * 21 + 15 + i] = 1.0;
+        J[(3 + i) * 21 + 12 + i] = 1.0;
+        J[(3 + i) * 21 + 18 + i] = 1.0;
+    }
+    int rc = mskf_ekf_augment(stream_, J);
+    if (rc != MSKF_OK) fail("mskf_ekf_augment", rc);
+}
+
+// :587-608
+void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
+    const StateIDType state_id = state_server.imu_state.id;
+    const int curr_feature_num = (int)map_server.size();
+    int tracked = 0;
+    for (const auto &f : msg->features) {
+        const FeatureIDType fid = (FeatureIDType)f.id;
+        auto it = map_server.find(fid);
+        if (it == map_server.end()) {
+            Feature &nf = map_server[fid];
+            nf.id = fid;
+            nf.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
+        } else {
+            it->second.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
+            ++tracked;
+        }
+    }
+    tracking_rate = static_cast<double>(tracked) / static_cast<double>(curr_feature_num);   // Q18: 0/0 = NaN on the first frame
+}
+
+// feature.hpp:257-287
+bool MsckfVio::checkMotion(const Feature &f) const {
+    const CAMState &c0 = state_server.cam_states.find(f.observations.begin()->first)->second;
+    const CAMState &c1 = state_server.cam_states.find((--f.observations.end())->first)->second;
+    const hm::Mat3 R0 = kin::rotation_of(c0.orientation.q).transpose();
+    const auto &z = f.observations.begin()->second;
+    Vector3 dir(z[0], z[1], 1.0);
+    dir = dir / hm::norm(dir);
+    dir = R0 * dir;
+    const Vector3 tr = c1.position - c0.position;
+    const double par = hm::dot(tr, dir);
+    const Vector3 orth = tr - par * dir;
+    return hm::norm(orth) > feat_translation_threshold_;
+}
+
+void MsckfVio::packClones() {
+    clones_.clear();
+    for (const auto &kv : state_server.cam_states) {
+        mskf_clone_state c;
+        for (int i = 0; i < 4; ++i) { c.q[i] = kv.second.orientation.q[i]; c.q_null[i] = kv.second.orientation_null.q[i]; }
+        for (int i = 0; i < 3; ++i) { c.p[i] = kv.second.position[i]; c.p_null[i] = kv.second.position_null[i]; }
+        clones_.push_back(c);
+    }
+}
+
+void MsckfVio::finishArgs(mskf_ekf_update_args &upd, int dof_offset, int apply_cap) {
+    std::memset(&upd, 0, sizeof(upd));
+    upd.n_clones = (int)clones_.size();
+    upd.n_feat = (int)feats_.size();
+    upd.n_obs = (int)obs_clone_.size();
+    upd.dof_offset = dof_offset;
+    upd.apply_row_cap = apply_cap;
+    for (int i = 0; i < 3; ++i) upd.gravity[i] = gravity_[i];
+    delta_x_.assign(21 + 6 * clones_.size(), 0.0);
+    gamma_.assign(feats_.size() + 1, 0.0);
+    feat_status_.assign(feats_.size() + 1, 0);
+    rows_out_ = 0;
+    upd.clones = clones_.data();
+    upd.features = feats_.data();
+    upd.obs_clone = obs_clone_.data();
+    upd.obs_z = obs_z_.data();
+    upd.delta_x = delta_x_.data();
+    upd.feat_status = feat_status_.data();
+    upd.gamma = gamma_.data();
+    upd.rows_out = &rows_out_;
+}
+
+// removeLostFeatures, selection part (:937-984)
+void MsckfVio::buildLostFeatureUpdate(mskf_ekf_update_args &upd) {
+    feats_.clear(); feat_ids_.clear(); obs_clone_.clear(); obs_z_.clear();
+    std::vector<FeatureIDType> invalid_ids;
+    const StateIDType cur = state_server.imu_state.id;
+    // clone id -> index in state order
+    std::map<StateIDType, int> clone_index;
+    { int k = 0; for (const auto &kv : state_server.cam_states) clone_index[kv.first] = k++; }
+    for (auto &kv : map_server) {
+        Feature &feature = kv.second;
+        if (feature.observations.find(cur) != feature.observations.end()) continue;
+        if (feature.observations.size() < 3) { invalid_ids.push_back(feature.id); continue; }
+        int needs_init = 0;
+        if (!feature.is_initialized) {
+            if (!checkMotion(feature)) { invalid_ids.push_back(feature.id); continue; }
+            needs_init = 1;   // Feature::initializePosition runs on the device; an invalid result drops the feature there
+        }
+        mskf_ekf_feature f;
+        std::memset(&f, 0, sizeof(f));
+        f.obs_start = (int)obs_clone_.size();
+        for (const auto &m : feature.observations) {
+            auto ci = clone_index.find(m.first);
+            if (ci == clone_index.end()) continue;   // feature.hpp:302-304
+            obs_clone_.push_back(ci->second);
+            for (int i = 0; i < 4; ++i) obs_z_.push_back(m.second[i]);
+        }
+        f.n_obs = (int)obs_clone_.size() - f.obs_start;
+        f.needs_init = needs_init; f.init_start = f.obs_start; f.n_init = f.n_obs;
+        for (int i = 0; i < 3; ++i) f.position[i] = feature.position[i];
+        feats_.push_back(f);
+        feat_ids_.push_back(feature.id);
+    }
+    for (const auto &id : invalid_ids) map_server.erase(id);
+    packClones();
+    finishArgs(upd, -1, 1);   // Q12 dof = #obs - 1, Q13 row cap
+}
+
+// measurementUpdate, state part (:862-894)
+void MsckfVio::applyCorrection(const std::vector<double> &dx) {
+    IMUState &s = state_server.imu_state;
+    double dq[4];
+    kin::small_angle(Vector3(dx[0], dx[1], dx[2]), dq);
+    kin::multiply(dq, s.orientation.q, s.orientation.q);
+    for (int i = 0; i < 3; ++i) {
+        s.gyro_bias[i] += dx[3 + i];
+        s.velocity[i] += dx[6 + i];
+        s.acc_bias[i] += dx[9 + i];
+        s.position[i] += dx[12 + i];
+    }
+    kin::small_angle(Vector3(dx[15], dx[16], dx[17]), dq);
+    s.R_imu_cam0 = kin::rotation_of(dq) * s.R_imu_cam0;
+    for (int i = 0; i < 3; ++i) s.t_cam0_imu[i] += dx[18 + i];
+    int ci = 0;
+    for (auto &kv : state_server.cam_states) {
+        const double *d = &dx[21 + 6 * ci];
+        kin::small_angle(Vector3(d[0], d[1], d[2]), dq);
+        kin::multiply(dq, kv.second.orientation.q, kv.second.orientation.q);
+        for (int i = 0; i < 3; ++i) kv.second.position[i] += d[3 + i];
+        ++ci;
+    }
+    ++n_update_;
+}
+
+void MsckfVio::phaseB(mskf_ekf_update_args &upd) {
+    // tail of removeLostFeatures (:1016-1021)
+    if (!feats_.empty()) {
+        if (rows_out_ > 0) applyCorrection(delta_x_);
+        for (const auto &fid : feat_ids_) map_server.erase(fid);
+    }
+    buildPruneUpdate(upd);
+}
+
+// :1026-1071
+void MsckfVio::findRedundantCamStates(std::vector<StateIDType> &rm) {
+    auto key_it = state_server.cam_states.end();
+    for (int i = 0; i < 4; ++i) --key_it;
+    auto cam_it = key_it; ++cam_it;
+    auto first_it = state_server.cam_states.begin();
+    const Vector3 key_position = key_it->second.position;
+    const hm::Mat3 key_rotation = kin::rotation_of(key_it->second.orientation.q);
+    for (int i = 0; i < 2; ++i) {
+        const Vector3 position = cam_it->second.position;
+        const hm::Mat3 rotation = kin::rotation_of(cam_it->second.orientation.q);
+        const double distance = hm::norm(position - key_position);
+        const double angle = kin::angle_of(rotation * key_rotation.transpose());
+        if (angle < cfg_.rotation_threshold && distance < cfg_.translation_threshold && tracking_rate > cfg_.tracking_rate_threshold) {
+            rm.push_back(cam_it->first);
+            ++cam_it;
+        } else {
+            rm.push_back(first_it->first);
+            ++first_it;
+        }
+    }
+    std::sort(rm.begin(), rm.end());
+}
+
+// pruneCamStateBuffer, selection part (:1073-1153)
+void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
+    feats_.clear(); feat_ids_.clear(); obs_clone_.clear(); obs_z_.clear();
+    rm_cam_state_ids_.clear();
+    prune_pending_ = false;
+    std::memset(&upd, 0, sizeof(upd));
+    if ((int)state_server.cam_states.size() < cfg_.max_cam_state_size) return;
+    prune_pending_ = true;
+    findRedundantCamStates(rm_cam_state_ids_);
+    std::map<StateIDType, int> clone_index;
+    { int k = 0; for (const auto &kv : state_server.cam_states) clone_index[kv.first] = k++; }
+    for (auto &item : map_server) {
+        Feature &feature = item.second;
+        std::vector<StateIDType> inv;
+        for (const auto &cid : rm_cam_state_ids_) if (feature.observations.find(cid) != feature.observations.end()) inv.push_back(cid);
+        if (inv.empty()) continue;
+        if (inv.size() == 1) { feature.observations.erase(inv[0]); continue; }
+        int needs_init = 0;
+        if (!feature.is_initialized) {
+            if (!checkMotion(feature)) {
+                for (const auto &cid : inv) feature.observations.erase(cid);
+                continue;
+            }
+            needs_init = 1;
+        }
+        mskf_ekf_feature f;
+        std::memset(&f, 0, sizeof(f));
+        if (needs_init) {   // triangulation uses ALL observations of the feature (feature.hpp:298-320)
+            f.init_start = (int)obs_clone_.size();
+            for (const auto &m : feature.observations) {
+                auto ci = clone_index.find(m.first);
+                if (ci == clone_index.end()) continue;
+                obs_clone_.push_back(ci->second);
+                for (int i = 0; i < 4; ++i) obs_z_.push_back(m.second[i]);
+            }
+            f.n_init = (int)obs_clone_.size() - f.init_start;
+        }
+        f.obs_start = (int)obs_clone_.size();
+        for (const auto &cid : inv) {   // the Jacobian block uses only the clones being removed (:1143)
+            obs_clone_.push_back(clone_index[cid]);
+            const auto &z = feature.observations[cid];
+            for (int i = 0; i < 4; ++i) obs_z_.push_back(z[i]);
+        }
+        f.n_obs = (int)inv.size();
+        f.needs_init = needs_init;
+        for (int i = 0; i < 3; ++i) f.position[i] = feature.position[i];
+        feats_.push_back(f);
+        feat_ids_.push_back(feature.id);
+    }
+    packClones();
+    finishArgs(upd, 0, 0);   // Q12 dof = #involved, no row cap in the pruning path
+}
+
+void MsckfVio::phaseC() {
+    if (!frame_active_) return;
+    if (prune_pending_) {
+        // tail of pruneCamStateBuffer (:1100-1181)
+        for (size_t j = 0; j < feats_.size(); ++j) {
+            Feature &feature = map_server[feat_ids_[j]];
+            if (feats_[j].needs_init && (feat_status_[j] & 1)) {
+                feature.is_initialized = true;
+                feature.position = Vector3(feats_[j].position[0], feats_[j].position[1], feats_[j].position[2]);
+            }
+            for (const auto &cid : rm_cam_state_ids_) feature.observations.erase(cid);
+        }
+        if (!feats_.empty() && rows_out_ > 0) applyCorrection(delta_x_);
+        for (const auto &cid : rm_cam_state_ids_) {
+            const int seq = (int)std::distance(state_server.cam_states.begin(), state_server.cam_states.find(cid));
+            int rc = mskf_ekf_remove_clone(stream_, seq);
+            if (rc != MSKF_OK) fail("mskf_ekf_remove_clone", rc);
+            state_server.cam_states.erase(cid);
+        }
+        prune_pending_ = false;
+    }
+    publish(frame_time_);
+}
+
+// :1186-1236
+void MsckfVio::phaseD(const double pos_var[3]) {
+    if (!frame_active_ || cfg_.position_std_threshold <= 0) return;
+    const double sx = std::sqrt(pos_var[0]), sy = std::sqrt(pos_var[1]), sz = std::sqrt(pos_var[2]);
+    if (sx < cfg_.position_std_threshold && sy < cfg_.position_std_threshold && sz < cfg_.position_std_threshold) return;
+    ++online_reset_counter_;
+    state_server.cam_states.clear();
+    map_server.clear();
+    resetCov();
+}
+
+// :1238-1305
+void MsckfVio::publish(double time_stamp) {
+    const IMUState &s = state_server.imu_state;
+    const hm::Rigid T_i_w(kin::rotation_of(s.orientation.q).transpose(), s.position);
+    const hm::Rigid T_b_w = T_imu_body_ * T_i_w * T_imu_body_.inverse();
+    mskf_pose pose;
+    pose.time_stamp = time_stamp;
+    for (int i = 0; i < 3; ++i) pose.p[i] = T_b_w.t[i];
+    kin::hamilton_of(T_b_w.R, pose.q);
+    if (keepTrajectory) {
+        poses_.push_back(pose);
+        path_.push_back(T_b_w.t);
+        for (const auto &item : map_server) {
+            if (!item.second.is_initialized) continue;
+            const Vector3 fp = T_imu_body_.R * item.second.position;
+            points3d_.push_back(Point3f((float)fp[0], (float)fp[1], (float)fp[2]));
+        }
+    } else {
+        if (poses_.empty()) poses_.push_back(pose); else poses_[0] = pose;
+    }
+    if (pose_outfile_.is_open()) {
+        pose_outfile_ << std::fixed << time_stamp << " " << pose.p[0] << " " << pose.p[1] << " " << pose.p[2] << " " << pose.q[0] << " "
+                      << pose.q[1] << " " << pose.q[2] << " " << pose.q[3] << std::endl;   // TUM format, Q15
+    }
+}
+
+}  // namespace cg

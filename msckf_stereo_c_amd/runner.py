@@ -1,0 +1,176 @@
+"""Python driver of the host mirror classes (cg::System / MultiRunner, csrc/host) — the product path.
+
+Everything below the binding is C++ above the C-ABI and HIP kernels below it; nothing here computes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import MskfError
+from .ctypes_types import FEATURE_MEAS, POINT2F, POSE, Calib, EkfCfg, FeCfg, ImuSample, TrackingInfo
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+IMU_SAMPLE = np.dtype([("t", "<f8"), ("w", "<f8", 3), ("a", "<f8", 3)])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = os.path.join(_HERE, "_build", "libmskf_host.so")
+        if not os.path.exists(p):
+            raise MskfError("libmskf_host.so is not built (run python -m msckf_stereo_c_amd.build); there is no CPU fallback")
+        L = C.CDLL(p)
+        L.mskfh_runner_create.restype = C.c_void_p
+        L.mskfh_runner_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Calib), C.POINTER(FeCfg), C.POINTER(EkfCfg)]
+        L.mskfh_runner_destroy.argtypes = [C.c_void_p]
+        L.mskfh_runner_error.restype = C.c_char_p
+        L.mskfh_runner_error.argtypes = [C.c_void_p]
+        L.mskfh_runner_imu.argtypes = [C.c_void_p, C.c_int, C.POINTER(ImuSample)]
+        L.mskfh_runner_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.mskfh_runner_set_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                                C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
+        L.mskfh_runner_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mskfh_runner_keep_trajectory.argtypes = [C.c_void_p, C.c_int]
+        for name in ("mskfh_num_features", "mskfh_msg_size", "mskfh_num_poses", "mskfh_state_dim", "mskfh_num_updates",
+                     "mskfh_num_clones"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, name).restype = C.c_int
+        L.mskfh_num_resets.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_num_resets.restype = C.c_longlong
+        L.mskfh_get_dump.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(TrackingInfo)]
+        L.mskfh_get_msg.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mskfh_get_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mskfh_get_cov.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.mskfh_get_imu_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mskfh_group_hip_stream.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_group_hip_stream.restype = C.c_void_p
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Runner:
+    """n_groups x per_group independent VIO streams on one GPU."""
+
+    def __init__(self, calib, fe_cfg, ekf_cfg, n_groups=1, per_group=1, device=0):
+        self.L = lib()
+        self.calib, self.fe_cfg, self.ekf_cfg = calib, fe_cfg, ekf_cfg
+        self.n = n_groups * per_group
+        self.n_groups, self.per_group = n_groups, per_group
+        self.h = self.L.mskfh_runner_create(device, n_groups, per_group, C.byref(calib), C.byref(fe_cfg), C.byref(ekf_cfg))
+        if not self.h:
+            raise MskfError("could not create the runner (no GPU / HIP library?): see stderr")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.mskfh_runner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MskfError("runner status %d: %s" % (rc, self.L.mskfh_runner_error(self.h).decode()))
+
+    def imu(self, stream, sample):
+        self.L.mskfh_runner_imu(self.h, stream, C.byref(sample))
+
+    def step(self, cam0_list, cam1_list, times):
+        """One frame for every stream from host images (numpy u8 arrays)."""
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in cam0_list]
+        b = [np.ascontiguousarray(x, dtype=np.uint8) for x in cam1_list]
+        pa = (C.c_void_p * self.n)(*[x.ctypes.data for x in a])
+        pb = (C.c_void_p * self.n)(*[x.ctypes.data for x in b])
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        self._chk(self.L.mskfh_runner_step(self.h, pa, pb, 0, _p(t)))
+
+    def set_sequence(self, stream, cam0_base_ptr, cam1_base_ptr, on_device, frame_bytes, n_static, n_loop, t0_ns, frame_dt_ns, imu):
+        imu = np.ascontiguousarray(imu, dtype=IMU_SAMPLE)
+        self._keep.append(imu)
+        self.L.mskfh_runner_set_sequence(self.h, stream, cam0_base_ptr, cam1_base_ptr, int(on_device), frame_bytes, n_static, n_loop,
+                                         t0_ns, frame_dt_ns, _p(imu), len(imu))
+
+    def run(self, first, n, threaded=True):
+        self._chk(self.L.mskfh_runner_run(self.h, first, n, int(threaded)))
+
+    def keep_trajectory(self, keep):
+        self.L.mskfh_runner_keep_trajectory(self.h, int(keep))
+
+    def hip_stream(self, stream=0):
+        return self.L.mskfh_group_hip_stream(self.h, stream)
+
+    # ---- inspection
+    def dump(self, stream=0):
+        n = self.L.mskfh_num_features(self.h, stream)
+        ids = np.zeros(n, np.uint64)
+        life = np.zeros(n, np.int32)
+        c0 = np.zeros(n, POINT2F)
+        c1 = np.zeros(n, POINT2F)
+        info = TrackingInfo()
+        self.L.mskfh_get_dump(self.h, stream, _p(ids), _p(life), _p(c0), _p(c1), C.byref(info))
+        return ids, life, c0, c1, info
+
+    def msg(self, stream=0):
+        n = self.L.mskfh_msg_size(self.h, stream)
+        out = np.zeros(n, FEATURE_MEAS)
+        if n:
+            self.L.mskfh_get_msg(self.h, stream, _p(out))
+        return out
+
+    def poses(self, stream=0):
+        n = self.L.mskfh_num_poses(self.h, stream)
+        out = np.zeros(n, POSE)
+        if n:
+            self.L.mskfh_get_poses(self.h, stream, _p(out))
+        return out
+
+    def cov(self, stream=0):
+        d = self.L.mskfh_state_dim(self.h, stream)
+        P = np.zeros((d, d))
+        self._chk(self.L.mskfh_get_cov(self.h, stream, _p(P), P.size))
+        return P
+
+    def imu_state(self, stream=0):
+        out = np.zeros(28)
+        self.L.mskfh_get_imu_state(self.h, stream, _p(out))
+        return out
+
+    def num_updates(self, stream=0):
+        return self.L.mskfh_num_updates(self.h, stream)
+
+    def num_resets(self, stream=0):
+        return self.L.mskfh_num_resets(self.h, stream)
+
+    def num_clones(self, stream=0):
+        return self.L.mskfh_num_clones(self.h, stream)
+
+
+class StreamView:
+    """Adapter so that oracle_py.Synth.feed() can drive one stream of a Runner with the reference
+    harness call order (imu_callback xN, stereo_callback, backend_callback)."""
+
+    def __init__(self, runner):
+        assert runner.n == 1
+        self.r = runner
+        self._pending = None
+
+    def imu(self, s):
+        self.r.imu(0, s)
+
+    def stereo(self, cam0, cam1, t):
+        self._pending = (cam0, cam1, t)
+
+    def backend(self):
+        cam0, cam1, t = self._pending
+        self.r.step([cam0], [cam1], [t])
