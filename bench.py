@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X hot path (stereo KLT front-end + MSCKF update) on synthetic
+EuRoC-shaped streams.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (for N > 1 launched by torch.distributed.run, one rank per GPU, RCCL only for the
+barrier and the max/sum aggregation: the streams are independent units, no data-path collective).
+A "step" is one stereo frame of EVERY stream of the batch: full front-end (pyramids, detector, temporal
+LK, stereo LK, gates) + back-end (IMU propagation, augmentation, triangulation, Jacobians, gating, QR,
+Kalman update, clone pruning).  Inputs (rendered stereo pairs) are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SURVEY.md §8(d) algorithmic work per unit
+LK_BYTES_PER_TRACK = 4 * (17 * 17 + 16 * 16)      # 4 levels x (17x17 template + 16x16 search footprint) u8
+HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6                           # FP64 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "64")), help="VIO streams per GPU")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "4")), help="host thread groups per GPU")
+    ap.add_argument("--unique", type=int, default=4, help="distinct rendered sequences per GPU (streams cycle over them)")
+    ap.add_argument("--width", type=int, default=752)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--clones", type=int, default=30)
+    ap.add_argument("--grid", type=str, default="8x10x4x5", help="rows x cols x min x max features per cell")
+    ap.add_argument("--prime", type=int, default=75, help="untimed frames before warmup: gravity init + clone window fill")
+    ap.add_argument("--loop", type=int, default=100, help="frames per trajectory period")
+    ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def make_cfgs(args):
+    from msckf_stereo_c_amd.ctypes_types import default_ekf_cfg, default_fe_cfg
+    r, c, mn, mx = (int(x) for x in args.grid.split("x"))
+    return default_fe_cfg(grid_row=r, grid_col=c, grid_min=mn, grid_max=mx), default_ekf_cfg(max_cam_state_size=args.clones)
+
+
+def render_sequences(oracle_py, args, rank, n_keys):
+    """Pre-render `unique` looping stereo sequences on the host (threads; the generator releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    syns = [oracle_py.Synth(seed=0x5EED0000 + 64 * rank + u, width=args.width, height=args.height, n_static=25, n_loop=args.loop)
+            for u in range(args.unique)]
+    frames = np.empty((args.unique, 2, n_keys, args.height, args.width), np.uint8)
+
+    def job(uk):
+        u, k = uk
+        a, b = syns[u].render(k)
+        frames[u, 0, k] = a
+        frames[u, 1, k] = b
+        syns[u]._cache.clear()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
+        list(ex.map(job, [(u, k) for u in range(args.unique) for k in range(n_keys)]))
+    return syns, frames
+
+
+def imu_array(syn, n):
+    from msckf_stereo_c_amd.runner import IMU_SAMPLE
+    out = np.zeros(n, IMU_SAMPLE)
+    for j in range(n):
+        s = syn.imu(j)
+        out[j] = (s.time_stamp, tuple(s.angular_velocity), tuple(s.linear_acceleration))
+    return out
+
+
+def cpu_baseline(oracle_py, syn, fe, ekf, prime, frames):
+    """The CPU oracle (a port: the reference itself cannot be built here) on ONE stream, one core."""
+    osys = oracle_py.OracleSystem(syn.calib, fe, ekf)
+    syn.feed(osys, prime)
+    t0 = time.perf_counter()
+    syn.feed(osys, frames, start=prime)
+    dt = time.perf_counter() - t0
+    return frames / dt, dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from msckf_stereo_c_amd import build, runner as R
+    build.build_all()
+    from oracle import oracle_py            # synthetic generator + (rank 0) the cpu_baseline leg only
+    oracle_py.build()
+
+    fe, ekf = make_cfgs(args)
+    per_group = max(1, args.streams // args.groups)
+    n_groups = max(1, args.streams // per_group)
+    n_streams = n_groups * per_group
+    n_keys = 25 + args.loop
+    total_frames = args.prime + args.warmup + args.steps
+
+    t_r0 = time.perf_counter()
+    syns, frames = render_sequences(oracle_py, args, rank, n_keys)
+    render_s = time.perf_counter() - t_r0
+    d_frames = torch.from_numpy(frames).cuda(local_rank)      # resident in HBM before the timed region
+    frame_bytes = args.width * args.height
+    calib = syns[0].calib
+    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank)
+    run.keep_trajectory(False)
+    imus = [imu_array(s, (total_frames + 3) * 10 + 20) for s in syns]
+    base = d_frames.data_ptr()
+    for s in range(n_streams):
+        u = s % args.unique
+        cam0 = base + (u * 2 + 0) * n_keys * frame_bytes
+        cam1 = base + (u * 2 + 1) * n_keys * frame_bytes
+        run.set_sequence(s, cam0, cam1, True, frame_bytes, 25, args.loop, 1403715273262142976, 50000000, imus[u])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    run.run(0, args.prime)                       # untimed: gravity/bias init, clone window fills, steady state
+    run.run(args.prime, args.warmup)             # W untimed warmup steps
+    run.set_timing(True)
+    run.get_timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    run.run(args.prime + args.warmup, args.steps)   # EXACTLY K timed steps
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = run.get_timing(reset=True)
+    run.set_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([n_streams * args.steps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        frames_total = float(cnt.item())
+    else:
+        frames_total = float(n_streams * args.steps)
+
+    # sanity of the workload actually processed (steady state reached, filter alive)
+    n_feat = len(run.dump(0)[0])
+    n_clones = run.num_clones(0)
+    n_upd = run.num_updates(0)
+
+    if rank == 0:
+        value = frames_total / elapsed
+        # ---- roofline of the dominant kernel (largest HIP-event time inside the timed region)
+        dom = max(timing, key=lambda k: timing[k][0])
+        ms, launches, units = timing[dom]
+        avg_s = ms * 1e-3 / max(launches, 1)
+        if dom in ("k_ekf_feature_blocks", "k_ekf_qr", "k_ekf_update"):
+            achieved = units / max(launches, 1) / avg_s / 1e12           # units = algorithmic FP64 flops
+            roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
+        else:
+            per_unit = {"k_lk_points": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
+            achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+        roof["avg_launch_us"] = avg_s * 1e6
+        roof["units_per_launch"] = units / max(launches, 1)
+        kernels = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)} for k, v in timing.items()}
+        out = {
+            "metric": "stereo frames/sec/node on EuRoC-shape input", "value": value, "unit": "stereo frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Single MI355X: %dx%d stereo, %d cam clones, grid %s (%d features/frame), 200 Hz IMU; "
+                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups)"
+                                   % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups),
+                       "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
+                       "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1)},
+            "roofline": roof, "kernels": kernels,
+        }
+        if not args.no_cpu and world == 1 and args.cpu_frames > 0:
+            fps, dt = cpu_baseline(oracle_py, syns[0], fe, ekf, args.prime, args.cpu_frames)
+            out["cpu_baseline"] = {"value": fps, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d frames of one %dx%d stream after %d priming frames, CPU oracle (-O3, 1 thread), %.1f s"
+                                             % (args.cpu_frames, args.width, args.height, args.prime, dt)}
+        print(json.dumps(out))
+    run.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

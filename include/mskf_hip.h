@@ -46,6 +46,17 @@ int mskf_ctx_sync(mskf_ctx *ctx);
 /* the HIP stream of this context as a void* (hipStream_t), for event timing by the caller */
 void *mskf_ctx_hip_stream(mskf_ctx *ctx);
 
+/* Optional per-kernel timing with HIP events recorded on the context's own stream (bench / roofline).
+ * `units` are the algorithmic work units of a launch (LK: point tracks; pyramid: output pixels;
+ * EKF kernels: streams).  Disabled by default; enabling costs two event records per launch. */
+enum {
+    MSKF_K_PYR = 0, MSKF_K_DETECT, MSKF_K_LK, MSKF_K_EKF_PROPAGATE, MSKF_K_EKF_AUGMENT, MSKF_K_EKF_FEATURES,
+    MSKF_K_EKF_CAP, MSKF_K_EKF_QR, MSKF_K_EKF_UPDATE, MSKF_K_EKF_REMOVE, MSKF_K_COUNT
+};
+int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
+/* arrays of MSKF_K_COUNT entries: accumulated milliseconds, launches and units since the last reset */
+int mskf_ctx_get_timing(mskf_ctx *ctx, double *ms, long long *launches, long long *units, int reset);
+
 int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
                        mskf_stream **out);
 void mskf_stream_destroy(mskf_stream *s);

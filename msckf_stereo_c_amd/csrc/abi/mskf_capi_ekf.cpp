@@ -9,7 +9,10 @@ extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st);
-void ekf_launch_update(const EkfStreamDev *d, int n, int max_feat, int max_m, int max_d, hipStream_t st);
+void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, hipStream_t st);
+void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_qr(const EkfStreamDev *d, int n, int max_m, hipStream_t st);
+void ekf_launch_kalman(const EkfStreamDev *d, int n, hipStream_t st);
 }
 
 namespace {
@@ -206,7 +209,11 @@ extern "C" int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_im
     MSKF_HIPCHK(hipMemcpyAsync(X->d_small, X->h_small, bytes, hipMemcpyHostToDevice, ctx->stream));
     MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
     X->small_pending = true;
-    ekf_launch_propagate((const EkfStreamDev *)X->d_small, 1, ctx->stream);
+    {
+        const int ts = mskf_t_begin(ctx, MSKF_K_EKF_PROPAGATE);
+        ekf_launch_propagate((const EkfStreamDev *)X->d_small, 1, ctx->stream);
+        mskf_t_end(ctx, ts, 1);
+    }
     MSKF_HIPCHK(hipGetLastError());
     return MSKF_OK;
 }
@@ -223,6 +230,7 @@ extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *con
                                      sizeof(double), 3, hipMemcpyDeviceToHost, ctx->stream));
     }
     MSKF_HIPCHK(hipStreamSynchronize(ctx->stream));
+    mskf_t_collect(ctx);
     return MSKF_OK;
 }
 
@@ -251,7 +259,11 @@ extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {
     MSKF_HIPCHK(hipMemcpyAsync(X->d_small + off, X->h_small + off, bytes, hipMemcpyHostToDevice, ctx->stream));
     MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
     X->small_pending = true;
-    ekf_launch_augment((const EkfStreamDev *)(X->d_small + off), 1, ctx->stream);
+    {
+        const int ts = mskf_t_begin(ctx, MSKF_K_EKF_AUGMENT);
+        ekf_launch_augment((const EkfStreamDev *)(X->d_small + off), 1, ctx->stream);
+        mskf_t_end(ctx, ts, 1);
+    }
     MSKF_HIPCHK(hipGetLastError());
     E.d += 6;
     return MSKF_OK;
@@ -275,7 +287,11 @@ extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
     MSKF_HIPCHK(hipMemcpyAsync(X->d_small, X->h_small, bytes, hipMemcpyHostToDevice, ctx->stream));
     MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
     X->small_pending = true;
-    ekf_launch_remove_clone((const EkfStreamDev *)X->d_small, (double *const *)(X->d_small + sizeof(EkfStreamDev)), 1, ctx->stream);
+    {
+        const int ts = mskf_t_begin(ctx, MSKF_K_EKF_REMOVE);
+        ekf_launch_remove_clone((const EkfStreamDev *)X->d_small, (double *const *)(X->d_small + sizeof(EkfStreamDev)), 1, ctx->stream);
+        mskf_t_end(ctx, ts, 1);
+    }
     MSKF_HIPCHK(hipGetLastError());
     std::swap(E.P, X->P_alt);
     E.d -= 6;
@@ -289,6 +305,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
     int max_feat = 0, max_m = 0, max_d = 0;
+    double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, total; size_t o_dx, o_gamma, o_rows, o_status, o_total; int m_total; };
     std::vector<Lay> lay(n);
     for (int i = 0; i < n; ++i) {
@@ -306,6 +323,13 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             if (f.n_obs < 2 || f.n_obs > E.max_clones || f.obs_start < 0 || f.obs_start + f.n_obs > a.n_obs) return MSKF_ERR_INVALID;
             if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
             m_total += 4 * f.n_obs - 3;
+            const double nj = 4.0 * f.n_obs - 3.0, M = f.n_obs, dd = E.d;
+            fl_feat += 2.0 * nj * (4.0 * M) * (6.0 * M) + 2.0 * nj * dd * dd + 2.0 * nj * nj * dd;
+        }
+        if (a.n_feat > 0) {
+            const double dd = E.d, mm = m_total;
+            if (m_total > E.d) fl_qr += 2.0 * mm * dd * dd - (2.0 / 3.0) * dd * dd * dd;
+            fl_upd += (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0) * dd * dd * dd;
         }
         if (m_total > kMaxRows) { mskf_set_error("stacked Jacobian exceeds the row capacity"); return MSKF_ERR_CAPACITY; }
         L.m_total = m_total;
@@ -371,7 +395,19 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     }
     if (max_feat > 0) {
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-        ekf_launch_update(ctx->ekf_desc.d, n, max_feat, max_m, max_d, st);
+        int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
+        ekf_launch_features(ctx->ekf_desc.d, n, max_feat, st);
+        mskf_t_end(ctx, ts, (long long)fl_feat);
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
+        ekf_launch_cap(ctx->ekf_desc.d, n, st);
+        mskf_t_end(ctx, ts, n);
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_QR);
+        ekf_launch_qr(ctx->ekf_desc.d, n, max_m, st);
+        mskf_t_end(ctx, ts, (long long)fl_qr);
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_UPDATE);
+        ekf_launch_kalman(ctx->ekf_desc.d, n, st);
+        mskf_t_end(ctx, ts, (long long)fl_upd);
+        (void)max_d;
         MSKF_HIPCHK(hipGetLastError());
     }
     for (int i = 0; i < n; ++i) {
@@ -382,6 +418,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         MSKF_HIPCHK(hipMemcpyAsync(E.h_arena + L.feats, E.d_arena + L.feats, sizeof(EkfFeatDev) * (size_t)args[i].n_feat, hipMemcpyDeviceToHost, st));
     }
     MSKF_HIPCHK(hipStreamSynchronize(st));
+    mskf_t_collect(ctx);
     for (int i = 0; i < n; ++i) {
         mskf_ekf_update_args &a = args[i];
         EkfStreamState &E = streams[i]->ekf_state;

@@ -31,6 +31,8 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    mskf_t_collect(c);
+    for (auto &e : c->t_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (int i = 0; i < 3; ++i) c->desc[i].release();
     c->jobs.release();
     c->ekf_desc.release();
@@ -41,6 +43,56 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
 extern "C" int mskf_ctx_sync(mskf_ctx *c) {
     if (!c) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    mskf_t_collect(c);
+    return MSKF_OK;
+}
+
+int mskf_t_begin(mskf_ctx *c, int kind) {
+    if (!c->timing) return -1;
+    TimingSlot t;
+    if (!c->t_pool.empty()) { t.a = c->t_pool.back().first; t.b = c->t_pool.back().second; c->t_pool.pop_back(); }
+    else {
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
+    }
+    t.kind = kind; t.units = 0;
+    (void)hipEventRecord(t.a, c->stream);
+    c->t_pending.push_back(t);
+    return (int)c->t_pending.size() - 1;
+}
+void mskf_t_end(mskf_ctx *c, int slot, long long units) {
+    if (slot < 0) return;
+    (void)hipEventRecord(c->t_pending[slot].b, c->stream);
+    c->t_pending[slot].units = units;
+}
+void mskf_t_collect(mskf_ctx *c) {
+    for (auto &t : c->t_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            c->t_ms[t.kind] += ms; c->t_launches[t.kind] += 1; c->t_units[t.kind] += t.units;
+        }
+        c->t_pool.push_back({t.a, t.b});
+    }
+    c->t_pending.clear();
+}
+
+extern "C" int mskf_ctx_set_timing(mskf_ctx *c, int enable) {
+    if (!c) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(c->device));
+    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    mskf_t_collect(c);
+    c->timing = enable != 0;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ctx_get_timing(mskf_ctx *c, double *ms, long long *launches, long long *units, int reset) {
+    if (!c || !ms || !launches || !units) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(c->device));
+    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    mskf_t_collect(c);
+    for (int k = 0; k < MSKF_K_COUNT; ++k) {
+        ms[k] = c->t_ms[k]; launches[k] = c->t_launches[k]; units[k] = c->t_units[k];
+        if (reset) { c->t_ms[k] = 0; c->t_launches[k] = 0; c->t_units[k] = 0; }
+    }
     return MSKF_OK;
 }
 
@@ -182,12 +234,23 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
             max_dw[l] = std::max(max_dw[l], s->lw[l]); max_dh[l] = std::max(max_dh[l], s->lh[l]);
         }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(PyrJob) * (size_t)n * 2 * (MSKF_LEVELS - 1), hipMemcpyHostToDevice, st));
-    for (int l = 1; l < MSKF_LEVELS; ++l)
+    for (int l = 1; l < MSKF_LEVELS; ++l) {
+        long long px = 0;
+        for (int i = 0; i < n; ++i) px += 2LL * streams[i]->lw[l] * streams[i]->lh[l];
+        const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
         fe_launch_pyr_down(ctx->jobs.d + (size_t)(l - 1) * 2 * n, 2 * n, max_dw[l], max_dh[l], st);
+        mskf_t_end(ctx, ts, px);
+    }
     // detector per-cell maxima on cam0 level 0
     for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-    fe_launch_detect(ctx->desc[0].d, n, max_cells, st);
+    {
+        long long px = 0;
+        for (int i = 0; i < n; ++i) px += (long long)streams[i]->w * streams[i]->h;
+        const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
+        fe_launch_detect(ctx->desc[0].d, n, max_cells, st);
+        mskf_t_end(ctx, ts, px);
+    }
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         MSKF_HIPCHK(hipMemcpyAsync(s->cell_max.h, s->cell_max.d, sizeof(mskf_corner) * (size_t)s->fe.det_rows * s->fe.det_cols,
@@ -271,7 +334,9 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     }
     if (max_pts > 0) {
         MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+        const int ts_lk = mskf_t_begin(ctx, MSKF_K_LK);
         fe_launch_lk(ctx->desc[1].d, n, max_pts, st);
+        mskf_t_end(ctx, ts_lk, 0);
         for (int i = 0; i < n; ++i) {
             mskf_stream *s = streams[i];
             const size_t np = (size_t)args[i].n;
@@ -284,6 +349,17 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
         }
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipStreamSynchronize(st));
+        if (ts_lk >= 0) {
+            // units of the LK launch = point tracks executed: temporal (n) + stereo (tracked), or stereo only (n)
+            long long tracks = 0;
+            for (int i = 0; i < n; ++i) {
+                const size_t np = (size_t)args[i].n;
+                tracks += (long long)np;
+                if (args[i].do_temporal) for (size_t k = 0; k < np; ++k) tracks += (streams[i]->status.h[k] & 1);
+            }
+            ctx->t_pending[ts_lk].units = tracks;
+        }
+        mskf_t_collect(ctx);
         for (int i = 0; i < n; ++i) {
             mskf_stream *s = streams[i];
             const mskf_fe_track_args &a = args[i];

@@ -47,7 +47,14 @@ struct PinnedDev {  // a pinned host array with a device twin
     }
 };
 
+struct TimingSlot { hipEvent_t a, b; int kind; long long units; };
+
 struct mskf_ctx {
+    bool timing = false;
+    std::vector<TimingSlot> t_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pool;
+    double t_ms[MSKF_K_COUNT] = {0};
+    long long t_launches[MSKF_K_COUNT] = {0}, t_units[MSKF_K_COUNT] = {0};
     int device = 0;
     hipStream_t stream = nullptr;
     PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
@@ -82,6 +89,10 @@ struct mskf_stream {
     void *ekf_extra = nullptr;
 };
 
+// timing helpers: t_begin records the start event and returns a slot index (or -1), t_end records the stop event
+int mskf_t_begin(mskf_ctx *c, int kind);
+void mskf_t_end(mskf_ctx *c, int slot, long long units);
+void mskf_t_collect(mskf_ctx *c);   // call after the stream has been synchronised
 void fill_pyr(const mskf_stream *s, int idx, PyrDev &p);
 int mskf_ekf_stream_init(mskf_stream *s);
 void mskf_ekf_stream_free(mskf_stream *s);

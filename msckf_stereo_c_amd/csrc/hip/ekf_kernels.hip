@@ -772,13 +772,14 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunc
 void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d, dst);
 }
-void ekf_launch_update(const EkfStreamDev *d, int n, int max_feat, int max_m, int max_d, hipStream_t st) {
+void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, hipStream_t st) {
     const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
     hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), 0, st, d);
-    hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d);
+}
+void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d); }
+void ekf_launch_qr(const EkfStreamDev *d, int n, int max_m, hipStream_t st) {
     const size_t lds = (size_t)(max_m + 32 + 4 * 256 + 8) * sizeof(double);
     hipLaunchKernelGGL(k_ekf_qr, dim3(1, n), dim3(QR_WG), lds, st, d);
-    hipLaunchKernelGGL(k_ekf_update, dim3(1, n), dim3(UP_WG), 0, st, d);
-    (void)max_d;
 }
+void ekf_launch_kalman(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_update, dim3(1, n), dim3(UP_WG), 0, st, d); }
 }

@@ -55,6 +55,8 @@ class MultiRunner {
     MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf);
     bool ok() const;
     int n_streams() const { return n_groups_ * per_group_; }
+    int n_groups() const { return n_groups_; }
+    BatchGroup &group(int g) { return *groups_[g]; }
     BatchGroup &group_of(int stream, int &local) { local = stream % per_group_; return *groups_[stream / per_group_]; }
     System &system(int stream) { int l; BatchGroup &g = group_of(stream, l); return g.system(l); }
     StreamSequence &sequence(int stream) { int l; BatchGroup &g = group_of(stream, l); return g.seq[l]; }

@@ -37,6 +37,21 @@ void mskfh_runner_keep_trajectory(void *h, int keep) {
     for (int i = 0; i < r->n_streams(); ++i) r->system(i).msckfvio_ptr()->keepTrajectory = keep != 0;
 }
 
+void mskfh_runner_set_timing(void *h, int enable) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int g = 0; g < r->n_groups(); ++g) mskf_ctx_set_timing(r->group(g).ctx(), enable);
+}
+// sums over groups; arrays of MSKF_K_COUNT
+void mskfh_runner_get_timing(void *h, double *ms, long long *launches, long long *units, int reset) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] = 0; launches[k] = 0; units[k] = 0; }
+    for (int g = 0; g < r->n_groups(); ++g) {
+        double m[MSKF_K_COUNT]; long long l[MSKF_K_COUNT], u[MSKF_K_COUNT];
+        if (mskf_ctx_get_timing(r->group(g).ctx(), m, l, u, reset) != MSKF_OK) continue;
+        for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] += m[k]; launches[k] += l[k]; units[k] += u[k]; }
+    }
+}
+
 // ---- per-stream inspection
 int mskfh_num_features(void *h, int stream) {
     std::vector<ImageProcessor::FeatureIDType> ids; std::vector<int> life; std::vector<Point2f> a, b;

@@ -45,6 +45,8 @@ def lib():
         L.mskfh_get_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mskfh_get_cov.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.mskfh_get_imu_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mskfh_runner_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mskfh_group_hip_stream.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_group_hip_stream.restype = C.c_void_p
         _LIB = L
@@ -106,6 +108,21 @@ class Runner:
 
     def keep_trajectory(self, keep):
         self.L.mskfh_runner_keep_trajectory(self.h, int(keep))
+
+    KERNELS = ["k_pyr_down", "k_detect_cells", "k_lk_points", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
+               "k_ekf_cap", "k_ekf_qr", "k_ekf_update", "k_ekf_remove_clone"]
+
+    def set_timing(self, enable):
+        self.L.mskfh_runner_set_timing(self.h, int(enable))
+
+    def get_timing(self, reset=True):
+        """Per-kernel HIP-event timing accumulated on the groups' own streams: {kernel: (ms, launches, units)}."""
+        k = len(self.KERNELS)
+        ms = np.zeros(k)
+        launches = np.zeros(k, np.int64)
+        units = np.zeros(k, np.int64)
+        self.L.mskfh_runner_get_timing(self.h, _p(ms), _p(launches), _p(units), int(reset))
+        return {n: (float(ms[i]), int(launches[i]), int(units[i])) for i, n in enumerate(self.KERNELS)}
 
     def hip_stream(self, stream=0):
         return self.L.mskfh_group_hip_stream(self.h, stream)
