@@ -48,10 +48,10 @@ void *mskf_ctx_hip_stream(mskf_ctx *ctx);
 
 /* Optional per-kernel timing with HIP events recorded on the context's own stream (bench / roofline).
  * `units` are the algorithmic work units of a launch (LK: point tracks; pyramid: output pixels;
- * EKF kernels: streams).  Disabled by default; enabling costs two event records per launch. */
+ * EKF feature / GEMM / Cholesky / TRSM kernels: algorithmic FP64 flops; others: streams).  Disabled by default; enabling costs two event records per launch. */
 enum {
     MSKF_K_PYR = 0, MSKF_K_DETECT, MSKF_K_LK, MSKF_K_EKF_PROPAGATE, MSKF_K_EKF_AUGMENT, MSKF_K_EKF_FEATURES,
-    MSKF_K_EKF_CAP, MSKF_K_EKF_QR, MSKF_K_EKF_UPDATE, MSKF_K_EKF_REMOVE, MSKF_K_COUNT
+    MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_COUNT
 };
 int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
 /* arrays of MSKF_K_COUNT entries: accumulated milliseconds, launches and units since the last reset */

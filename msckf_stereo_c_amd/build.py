@@ -20,6 +20,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unus
 HIP_SRCS = [
     "hip/fe_kernels.hip",
     "hip/ekf_kernels.hip",
+    "hip/ekf_linalg.hip",
     "abi/mskf_capi_fe.cpp",
     "abi/mskf_capi_ekf.cpp",
 ]

@@ -11,8 +11,11 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
-void ekf_launch_qr(const EkfStreamDev *d, int n, int max_m, hipStream_t st);
-void ekf_launch_kalman(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
+void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
+void ekf_launch_rthin(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
+void ekf_launch_dx(const EkfStreamDev *d, int n, hipStream_t st);
 }
 
 namespace {
@@ -65,6 +68,7 @@ int mskf_ekf_stream_init(mskf_stream *s) {
     if ((rc = dev_alloc(&E.P, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.T, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.S, pl)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.W, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.gate_T, (size_t)EKF_SLOTS * E.nmax * E.ld)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.chi2, 128)) != MSKF_OK) return rc;
@@ -81,7 +85,7 @@ int mskf_ekf_stream_init(mskf_stream *s) {
 
 void mskf_ekf_stream_free(mskf_stream *s) {
     EkfStreamState &E = s->ekf_state;
-    double *ptrs[] = {E.P, E.T, E.S, E.gate_T, E.gate_S, E.chi2, E.Hs, E.rs};
+    double *ptrs[] = {E.P, E.T, E.S, E.W, E.gate_T, E.gate_S, E.chi2, E.Hs, E.rs};
     for (double *p : ptrs) if (p) (void)hipFree(p);
     if (E.h_arena) (void)hipHostFree(E.h_arena);
     if (E.d_arena) (void)hipFree(E.d_arena);
@@ -109,7 +113,7 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
     D.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
     D.qc[2] = s->ekf.noise_acc * s->ekf.noise_acc;
     D.qc[3] = s->ekf.noise_acc_bias * s->ekf.noise_acc_bias;
-    D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.gate_T = E.gate_T; D.gate_S = E.gate_S; D.nmax = E.nmax;
+    D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.W = E.W; D.gate_T = E.gate_T; D.gate_S = E.gate_S; D.nmax = E.nmax;
     hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
     std::memcpy(D.R_c0_c1, T01.R.m, sizeof(D.R_c0_c1));
     for (int i = 0; i < 3; ++i) D.t_c0_c1[i] = T01.t[i];
@@ -401,12 +405,37 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);
         mskf_t_end(ctx, ts, n);
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_QR);
-        ekf_launch_qr(ctx->ekf_desc.d, n, max_m, st);
+        // QR compression as Gram + semidefinite Cholesky, then the Kalman update (ekf_linalg.hip)
+        enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
+        const double d3 = fl_upd / (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0);     // sum of d^3 over the launch
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
         mskf_t_end(ctx, ts, (long long)fl_qr);
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_UPDATE);
-        ekf_launch_kalman(ctx->ekf_desc.d, n, st);
-        mskf_t_end(ctx, ts, (long long)fl_upd);
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
+        ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
+        mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
+        ekf_launch_rthin(ctx->ekf_desc.d, n, st);
+        mskf_t_end(ctx, ts, n);
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
+        mskf_t_end(ctx, ts, (long long)(2.0 * d3));
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_S2, max_d, st);
+        mskf_t_end(ctx, ts, (long long)(2.0 * d3));
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
+        ekf_launch_chol(ctx->ekf_desc.d, n, 1, max_d, st);
+        mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
+        ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
+        mskf_t_end(ctx, ts, (long long)(2.0 * d3));
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
+        ekf_launch_dx(ctx->ekf_desc.d, n, st);
+        mskf_t_end(ctx, ts, n);
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
+        mskf_t_end(ctx, ts, (long long)(4.0 * d3));
+        (void)max_m;
         (void)max_d;
         MSKF_HIPCHK(hipGetLastError());
     }

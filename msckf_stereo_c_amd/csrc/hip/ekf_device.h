@@ -32,8 +32,9 @@ struct EkfStreamDev {
     const double *obs_z;                 // n_obs x 4
     double *Hs;               // m_total x ld stacked (null-space projected) Jacobian, failed blocks zeroed
     double *rs;               // m_total
-    double *T;                // ld x ld work (H P, then Y = L^-1 H P)
-    double *S;                // ld x ld work
+    double *T;                // ld x ld work: T = R P, then Y = L^-1 [T | Q^T r]
+    double *S;                // ld x ld work: Gram matrix [H|r]^T [H|r], then its Cholesky factor L = R^T (+ the Q^T r row)
+    double *W;                // ld x ld work: S = T R^T + sigma^2 I, then its Cholesky factor
     double *gate_T;           // EKF_SLOTS x (nmax x ld)
     double *gate_S;           // EKF_SLOTS x (nmax x nmax)
     int nmax;                 // 4 * max_clones
@@ -53,7 +54,7 @@ struct EkfStreamDev {
 struct EkfStreamState {       // host-side bookkeeping of the device buffers of one stream
     int max_clones = 0, ld = 0, d = EKF_IMU_DIM;
     int max_rows = 0, max_feat = 0, max_obs = 0, nmax = 0;
-    double *P = nullptr, *Hs = nullptr, *rs = nullptr, *T = nullptr, *S = nullptr, *gate_T = nullptr, *gate_S = nullptr;
+    double *P = nullptr, *Hs = nullptr, *rs = nullptr, *T = nullptr, *S = nullptr, *W = nullptr, *gate_T = nullptr, *gate_S = nullptr;
     double *chi2 = nullptr;
     // per-update staging: one pinned+device arena, laid out by the host
     char *h_arena = nullptr, *d_arena = nullptr;

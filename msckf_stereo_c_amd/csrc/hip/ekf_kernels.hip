@@ -6,8 +6,7 @@
 //  k_ekf_feature_blocks : Feature::initializePosition (feature.hpp:289-450), measurementJacobian
 //                         (:610-677), featureJacobian null-space projection (:679-775), gatingTest (:909-935)
 //  k_ekf_cap            : stacking order + 1500-row cap          (:1003-1010)
-//  k_ekf_qr             : QR compression of the stacked Jacobian (:795-811)
-//  k_ekf_update         : gain, state correction vector, covariance update (:831-904)
+//  (ekf_linalg.hip)     : QR compression (:795-811) as Gram + Cholesky, gain / correction / covariance update (:831-904)
 //
 // All arithmetic is FP64.  The covariance P stays resident in HBM (ld x ld, row-major, exactly
 // symmetric by construction); one workgroup handles one VIO stream (or one feature of one
@@ -524,8 +523,11 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
             }
             Hrow0[(size_t)(i - 3) * ld + c] = v;
         }
-        for (int i = 3 + tid; i < rows; i += WG)
-            r0[i - 3] = sr[i] - sCoef[6 * M][0] * sV[0][i] - sCoef[6 * M][1] * sV[1][i] - sCoef[6 * M][2] * sV[2][i];
+        for (int i = 3 + tid; i < rows; i += WG) {
+            const double rv = sr[i] - sCoef[6 * M][0] * sV[0][i] - sCoef[6 * M][1] * sV[1][i] - sCoef[6 * M][2] * sV[2][i];
+            r0[i - 3] = rv;
+            Hrow0[(size_t)(i - 3) * ld + d] = rv;   // column d of the stacked matrix carries the residual ([H | r])
+        }
         __syncthreads();
         // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
         const int kc = 6 * M;                     // compact columns
@@ -633,138 +635,6 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
     }
 }
 
-// ------------------------------------------------------------------------------------ QR
-// Unblocked Householder QR of [Hs | rs] (m x d | m), in place, one workgroup per stream.
-#define QR_WG 1024
-__global__ __launch_bounds__(QR_WG) void k_ekf_qr(const EkfStreamDev *streams) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    const int m = S.m_total, d = S.d, ld = S.ld;
-    if (S.rows_out[0] <= 0) return;       // nothing stacked
-    if (m <= d) { if (threadIdx.x == 0) S.rows_out[1] = m; return; }
-    double *H = S.Hs, *r = S.rs;
-    extern __shared__ double s_dyn[];     // v[m], then red[16 + d + 1]
-    double *sv = s_dyn;
-    double *sRed = s_dyn + m;
-    double *sDot = sRed + 32;
-    const int tid = threadIdx.x;
-    const int ncols_t = 256;              // threads along columns
-    const int tx = tid % ncols_t, ty = tid / ncols_t;   // 4 row groups
-    for (int k = 0; k < d && k < m - 1; ++k) {
-        double part = 0;
-        for (int i = k + tid; i < m; i += QR_WG) { const double x = H[(size_t)i * ld + k]; part += x * x; }
-        const double nrm = sqrt(block_sum(part, sRed));
-        if (nrm == 0.0) continue;         // uniform
-        const double x0 = H[(size_t)k * ld + k];
-        const double alpha = x0 > 0 ? -nrm : nrm;
-        __syncthreads();
-        for (int i = k + tid; i < m; i += QR_WG) sv[i] = (i == k) ? x0 - alpha : H[(size_t)i * ld + k];
-        __syncthreads();
-        double pv = 0;
-        for (int i = k + tid; i < m; i += QR_WG) pv += sv[i] * sv[i];
-        const double vn = block_sum(pv, sRed);
-        if (vn == 0.0) continue;
-        const double beta = 2.0 / vn;
-        // trailing columns k..d-1 and the residual (column index d)
-        for (int c0 = k; c0 <= d; c0 += ncols_t) {
-            const int c = c0 + tx;
-            double pd = 0;
-            if (c <= d) {
-                if (c < d) { for (int i = k + ty; i < m; i += 4) pd += sv[i] * H[(size_t)i * ld + c]; }
-                else { for (int i = k + ty; i < m; i += 4) pd += sv[i] * r[i]; }
-            }
-            __syncthreads();
-            sDot[ty * ncols_t + tx] = pd;
-            __syncthreads();
-            if (c <= d) {
-                const double sdot = (sDot[tx] + sDot[ncols_t + tx] + sDot[2 * ncols_t + tx] + sDot[3 * ncols_t + tx]) * beta;
-                if (c < d) { for (int i = k + ty; i < m; i += 4) H[(size_t)i * ld + c] -= sdot * sv[i]; }
-                else { for (int i = k + ty; i < m; i += 4) r[i] -= sdot * sv[i]; }
-            }
-            __syncthreads();
-        }
-    }
-    if (tid == 0) S.rows_out[1] = d;
-}
-
-// ------------------------------------------------------------------------------------ update
-// With H = first nr rows of Hs (upper-trapezoidal after QR):  T = H P, S = T H^T + s2 I = L L^T,
-// Y = L^-1 T, delta_x = Y^T L^-1 r, P <- P - Y^T Y  (== (I - K H) P, symmetric by construction).
-#define UP_WG 1024
-__global__ __launch_bounds__(UP_WG) void k_ekf_update(const EkfStreamDev *streams) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    const int d = S.d, ld = S.ld;
-    const int tid = threadIdx.x;
-    if (S.rows_out[0] <= 0) { for (int i = tid; i < d; i += UP_WG) S.delta_x[i] = 0.0; return; }
-    const int nr = S.rows_out[1];
-    const bool tri = S.m_total > d;       // H upper triangular
-    double *P = S.P, *T = S.T, *Sm = S.S;
-    const double *H = S.Hs;
-    __shared__ double sRed[32];
-    // T = H P
-    for (int idx = tid; idx < nr * d; idx += UP_WG) {
-        const int i = idx / d, c = idx - i * d;
-        const double *h = H + (size_t)i * ld;
-        double s = 0;
-        for (int k = tri ? i : 0; k < d; ++k) s += h[k] * P[(size_t)k * ld + c];
-        T[(size_t)i * ld + c] = s;
-    }
-    __syncthreads();
-    // S = T H^T + sigma2 I (lower)
-    for (int idx = tid; idx < nr * nr; idx += UP_WG) {
-        const int i = idx / nr, j = idx - i * nr;
-        if (j > i) continue;
-        const double *h = H + (size_t)j * ld;
-        const double *t = T + (size_t)i * ld;
-        double s = 0;
-        for (int k = tri ? j : 0; k < d; ++k) s += t[k] * h[k];
-        if (i == j) s += S.sigma2;
-        Sm[(size_t)i * ld + j] = s;
-    }
-    __syncthreads();
-    // Cholesky, right-looking
-    for (int k = 0; k < nr; ++k) {
-        const double lkk = sqrt(Sm[(size_t)k * ld + k]);
-        __syncthreads();
-        for (int i = k + tid; i < nr; i += UP_WG) Sm[(size_t)i * ld + k] = (i == k) ? lkk : Sm[(size_t)i * ld + k] / lkk;
-        __syncthreads();
-        const int rem = nr - k - 1;
-        for (int idx = tid; idx < rem * rem; idx += UP_WG) {
-            const int a = idx / rem + k + 1, b = idx % rem + k + 1;
-            if (b <= a) Sm[(size_t)a * ld + b] -= Sm[(size_t)a * ld + k] * Sm[(size_t)b * ld + k];
-        }
-        __syncthreads();
-    }
-    // Y = L^-1 T (one thread per column, in place in T); column d holds w = L^-1 r
-    for (int c = tid; c <= d; c += UP_WG) {
-        for (int i = 0; i < nr; ++i) {
-            double s = (c < d) ? T[(size_t)i * ld + c] : S.rs[i];
-            const double *L = Sm + (size_t)i * ld;
-            if (c < d) { for (int p = 0; p < i; ++p) s -= L[p] * T[(size_t)p * ld + c]; }
-            else { for (int p = 0; p < i; ++p) s -= L[p] * S.rs[p]; }
-            s /= L[i];
-            if (c < d) T[(size_t)i * ld + c] = s; else S.rs[i] = s;
-        }
-    }
-    __syncthreads();
-    // delta_x = Y^T w
-    for (int c = tid; c < d; c += UP_WG) {
-        double s = 0;
-        for (int i = 0; i < nr; ++i) s += T[(size_t)i * ld + c] * S.rs[i];
-        S.delta_x[c] = s;
-    }
-    // P <- P - Y^T Y (lower triangle computed, mirrored)
-    for (int idx = tid; idx < d * d; idx += UP_WG) {
-        const int a = idx / d, b = idx - a * d;
-        if (b > a) continue;
-        double s = 0;
-        for (int i = 0; i < nr; ++i) s += T[(size_t)i * ld + a] * T[(size_t)i * ld + b];
-        const double v = P[(size_t)a * ld + b] - s;
-        P[(size_t)a * ld + b] = v;
-        P[(size_t)b * ld + a] = v;
-    }
-    (void)sRed;
-}
-
 // ------------------------------------------------------------------------------------ launchers
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_propagate, dim3(1, n), dim3(WG), 0, st, d); }
@@ -777,9 +647,4 @@ void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, hipStream_t
     hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), 0, st, d);
 }
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d); }
-void ekf_launch_qr(const EkfStreamDev *d, int n, int max_m, hipStream_t st) {
-    const size_t lds = (size_t)(max_m + 32 + 4 * 256 + 8) * sizeof(double);
-    hipLaunchKernelGGL(k_ekf_qr, dim3(1, n), dim3(QR_WG), lds, st, d);
-}
-void ekf_launch_kalman(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_update, dim3(1, n), dim3(UP_WG), 0, st, d); }
 }

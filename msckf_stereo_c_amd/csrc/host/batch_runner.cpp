@@ -52,6 +52,7 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
     for (int i = 0; i < n; ++i) {
         systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
         systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
+        systems_[i]->msckfvio_ptr()->setZeroTailHint(systems_[i]->imgproc_ptr_->feature_msg_ptr_.get(), systems_[i]->imgproc_ptr_->zeroTailStart());
     }
     // ---- back-end (System::backend_callback for every stream)
     std::vector<mskf_stream *> sub_s;

@@ -450,6 +450,8 @@ void ImageProcessor::publish() {
             m.u0 = f.und0.x; m.v0 = f.und0.y; m.u1 = f.und1.x; m.v1 = f.und1.y;
             ++i;
         }
+    if (i > max_published_) max_published_ = i;
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) max_published_ = i;
     last_tracking_info = TrackingInfo{cam0_curr_time, before_tracking, after_tracking, after_matching, after_ransac};
     if (debug_.is_open())
         debug_ << std::fixed << std::setprecision(9) << cam0_curr_time << ": " << before_tracking << ", " << after_tracking << ", "

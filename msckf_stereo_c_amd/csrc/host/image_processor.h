@@ -70,6 +70,8 @@ class ImageProcessor {
     void phaseAfter1(mskf_fe_track_args &args);                     // consume results; prepare new-feature candidates
     void phaseAfter2(bool is_draw);                                 // addNewFeatures tail, prune, publish, rotate
     bool isFirstImage() const { return is_first_img; }
+    // records [zeroTailStart(), features.size()) of feature_msg_ptr_ were pushed but never written (Q1)
+    size_t zeroTailStart() const { return max_published_; }
 
     // debug / parity: live grid in flatten order
     void dumpCurrent(std::vector<FeatureIDType> &ids, std::vector<int> &lifetime, std::vector<Point2f> &cam0,
@@ -131,6 +133,7 @@ class ImageProcessor {
     std::vector<double> cand_responses_det_;     // responses in detection order (Q4)
     std::vector<double> cand_responses_sieved_;  // responses in sieve order
     std::vector<mskf_corner> cell_max_;
+    size_t max_published_ = 0;
     int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
     std::ofstream debug_;
 };

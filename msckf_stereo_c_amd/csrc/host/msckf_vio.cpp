@@ -287,11 +287,19 @@ void MsckfVio::stateAugmentation(double time) {
 }
 
 // :587-608
+// Q1: the message is never cleared, so behind the live entries it carries stale entries and then a
+// growing tail of value-initialised records (id 0, zero coordinates).  Every tail record does the same
+// thing (observation (0,0,0,0) for feature 0 at this state id), so when the producer told us where the
+// tail starts (setZeroTailHint) it is collapsed: first record processed normally, the remaining T-1
+// only bump tracked_feature_num exactly as the reference's loop would.  No hint -> plain loop.
 void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
     const StateIDType state_id = state_server.imu_state.id;
     const int curr_feature_num = (int)map_server.size();
-    int tracked = 0;
-    for (const auto &f : msg->features) {
+    long long tracked = 0;
+    size_t n_full = msg->features.size();
+    if (zero_tail_msg_ == msg.get() && zero_tail_start_ < n_full) n_full = zero_tail_start_ + 1;
+    for (size_t k = 0; k < n_full; ++k) {
+        const FeatureMeasurement &f = msg->features[k];
         const FeatureIDType fid = (FeatureIDType)f.id;
         auto it = map_server.find(fid);
         if (it == map_server.end()) {
@@ -303,6 +311,7 @@ void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
             ++tracked;
         }
     }
+    tracked += (long long)(msg->features.size() - n_full);
     tracking_rate = static_cast<double>(tracked) / static_cast<double>(curr_feature_num);   // Q18: 0/0 = NaN on the first frame
 }
 

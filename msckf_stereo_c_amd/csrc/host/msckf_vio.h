@@ -86,6 +86,8 @@ class MsckfVio {
     // phase D: online reset decision from the position variances (msckf_vio.cpp:1186-1236)
     void phaseD(const double pos_var[3]);
     bool frameActive() const { return frame_active_; }
+    // optional: records [start, size) of `msg` are untouched value-initialised records (Q1 tail)
+    void setZeroTailHint(const CameraMeasurement *msg, size_t start) { zero_tail_msg_ = msg; zero_tail_start_ = start; }
 
     const std::vector<mskf_pose> &poses() const { return poses_; }
     const IMUState &imuState() const { return state_server.imu_state; }
@@ -158,6 +160,8 @@ class MsckfVio {
     int32_t rows_out_ = 0;
     std::vector<StateIDType> rm_cam_state_ids_;
     bool prune_pending_ = false;
+    const CameraMeasurement *zero_tail_msg_ = nullptr;
+    size_t zero_tail_start_ = 0;
     std::ofstream pose_outfile_;
 };
 

@@ -62,6 +62,7 @@ void System::imu_callback(const cg::ImuConstPtr &msg) {
 // system.cpp:50-54
 void System::backend_callback() {
     if (!ok_) return;
+    if (feature_msg_ptr_ == imgproc_ptr_->feature_msg_ptr_) msckfvio_ptr_->setZeroTailHint(feature_msg_ptr_.get(), imgproc_ptr_->zeroTailStart());
     msckfvio_ptr_->featureCallback(feature_msg_ptr_);
     if (copy_draw_buffers) {
         path_to_draw_ = msckfvio_ptr_->get_path();
