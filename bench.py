@@ -140,12 +140,14 @@ def main():
     run.run(args.prime, args.warmup)             # W untimed warmup steps
     run.set_timing(True)
     run.get_timing(reset=True)
+    run.get_phases(reset=True)
     barrier()
     t0 = time.perf_counter()
     run.run(args.prime + args.warmup, args.steps)   # EXACTLY K timed steps
     barrier()
     elapsed = time.perf_counter() - t0
     timing = run.get_timing(reset=True)
+    phases = run.get_phases(reset=True)
     run.set_timing(False)
 
     if world > 1:
@@ -191,6 +193,7 @@ def main():
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
                        "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1)},
             "roofline": roof, "kernels": kernels,
+            "host_phases_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in phases.items()},
         }
         if not args.no_cpu and world == 1 and args.cpu_frames > 0:
             fps, dt = cpu_baseline(oracle_py, syns[0], fe, ekf, args.prime, args.cpu_frames)

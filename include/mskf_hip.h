@@ -60,6 +60,7 @@ int mskf_ctx_get_timing(mskf_ctx *ctx, double *ms, long long *launches, long lon
 int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
                        mskf_stream **out);
 void mskf_stream_destroy(mskf_stream *s);
+mskf_ctx *mskf_stream_ctx(mskf_stream *s);
 
 /* ------------------------------------------------------------------ front-end
  * Replaces, inside cg::ImageProcessor::stereoCallback (image_processor.cpp:139-203):
@@ -156,6 +157,10 @@ typedef struct mskf_imu_step {
 
 int mskf_ekf_reset(mskf_stream *s, const double *P0 /* 21x21 row-major */);
 int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_imu_step *steps);
+/* One fused launch for many streams: IMU propagation over n_steps[i] samples followed (J[i] != NULL) by the
+ * state augmentation.  Equivalent to mskf_ekf_propagate_imu + mskf_ekf_augment per stream. */
+int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *n_steps,
+                           const mskf_imu_step *const *steps, const double *const *J);
 /* position variances P(12,12), P(13,13), P(14,14) for onlineReset (msckf_vio.cpp:1194-1196). Synchronises. */
 int mskf_ekf_get_pos_var(mskf_stream *s, double out[3]);
 int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out /* 3n */);
@@ -164,6 +169,9 @@ int mskf_ekf_augment(mskf_stream *s, const double *J /* 6x21 */);
 int mskf_ekf_update(mskf_stream *s, mskf_ekf_update_args *args);
 int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args);
 int mskf_ekf_remove_clone(mskf_stream *s, int clone_index);
+/* Remove up to two clones per stream in one launch: idx[2*i], idx[2*i+1] are clone indices in the CURRENT
+ * state order (distinct; -1 = none).  Equivalent to mskf_ekf_remove_clone calls (msckf_vio.cpp:1161-1181). */
+int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *idx);
 int mskf_ekf_get_dim(mskf_stream *s, int *d);
 int mskf_ekf_get_cov(mskf_stream *s, double *P, int capacity /* doubles */);
 int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d);

@@ -8,8 +8,8 @@
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
-void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st);
-void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, hipStream_t st);
+void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
@@ -69,7 +69,7 @@ int mskf_ekf_stream_init(mskf_stream *s) {
     if ((rc = dev_alloc(&E.T, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.S, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.W, pl)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.gate_T, (size_t)EKF_SLOTS * E.nmax * E.ld)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.gate_T, 64)) != MSKF_OK) return rc;   // unused since the block-structured gate (kept for the descriptor)
     if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.chi2, 128)) != MSKF_OK) return rc;
     double tab[100];
@@ -108,6 +108,7 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
     D.sigma2 = s->ekf.noise_feature * s->ekf.noise_feature;   // msckf_vio.cpp:74,81
     D.max_stack_rows = s->ekf.max_stack_rows;
     D.chi2 = E.chi2;
+    D.remove_index = D.remove_index2 = -1;
     // continuous_noise_cov diagonal blocks: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:70-80, 174-178)
     D.qc[0] = s->ekf.noise_gyro * s->ekf.noise_gyro;
     D.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
@@ -222,6 +223,60 @@ extern "C" int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_im
     return MSKF_OK;
 }
 
+extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *n_steps,
+                                      const mskf_imu_step *const *steps, const double *const *J) {
+    if (!ctx || n <= 0 || !streams || !n_steps || !steps || !J) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
+    for (int i = 0; i < n; ++i) {
+        if (!streams[i] || streams[i]->ctx != ctx || n_steps[i] < 0 || (n_steps[i] && !steps[i])) return MSKF_ERR_INVALID;
+        bytes += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64) + align_up(sizeof(double) * 6 * EKF_IMU_DIM, 64);
+    }
+    if (!ctx->pred_done) MSKF_HIPCHK(hipEventCreateWithFlags(&ctx->pred_done, hipEventDisableTiming));
+    if (ctx->pred_pending) { MSKF_HIPCHK(hipEventSynchronize(ctx->pred_done)); ctx->pred_pending = false; }
+    if (bytes > ctx->pred_arena.cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        int rc = ctx->pred_arena.ensure(bytes);
+        if (rc != MSKF_OK) return rc;
+    }
+    char *h = ctx->pred_arena.h, *dv = ctx->pred_arena.d;
+    EkfStreamDev *D = (EkfStreamDev *)h;
+    size_t off = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        EkfStreamState &E = s->ekf_state;
+        base_desc(s, D[i]);
+        D[i].n_steps = n_steps[i];
+        if (n_steps[i] > 0) {
+            std::memcpy(h + off, steps[i], sizeof(mskf_imu_step) * (size_t)n_steps[i]);
+            D[i].imu_steps = (const mskf_imu_step *)(dv + off);
+            off += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64);
+            any = true;
+        }
+        if (J[i]) {
+            if (E.d + 6 > EKF_IMU_DIM + 6 * E.max_clones) { mskf_set_error("clone capacity exceeded"); return MSKF_ERR_CAPACITY; }
+            std::memcpy(h + off, J[i], sizeof(double) * 6 * EKF_IMU_DIM);
+            D[i].J = (const double *)(dv + off);
+            off += align_up(sizeof(double) * 6 * EKF_IMU_DIM, 64);
+            any = true;
+        }
+    }
+    if (!any) return MSKF_OK;
+    MSKF_HIPCHK(hipMemcpyAsync(dv, h, off, hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipEventRecord(ctx->pred_done, st));
+    ctx->pred_pending = true;
+    {
+        const int ts = mskf_t_begin(ctx, MSKF_K_EKF_PROPAGATE);
+        ekf_launch_propagate((const EkfStreamDev *)dv, n, st);
+        mskf_t_end(ctx, ts, n);
+    }
+    MSKF_HIPCHK(hipGetLastError());
+    for (int i = 0; i < n; ++i) if (J[i]) streams[i]->ekf_state.d += 6;
+    return MSKF_OK;
+}
+
 extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out) {
     if (!ctx || n <= 0 || !streams || !out) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
@@ -273,33 +328,61 @@ extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {
     return MSKF_OK;
 }
 
-extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
-    if (!s) return MSKF_ERR_INVALID;
-    EkfStreamState &E = s->ekf_state;
-    const int n_clones = (E.d - EKF_IMU_DIM) / 6;
-    if (clone_index < 0 || clone_index >= n_clones) return MSKF_ERR_INVALID;
-    EkfExtra *X = extra_of(s);
-    mskf_ctx *ctx = s->ctx;
+extern "C" int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *idx) {
+    if (!ctx || n <= 0 || !streams || !idx) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
-    const size_t bytes = sizeof(EkfStreamDev) + sizeof(double *);
-    int rc = small_begin(s, X, bytes);
-    if (rc != MSKF_OK) return rc;
-    EkfStreamDev *D = (EkfStreamDev *)X->h_small;
-    base_desc(s, *D);
-    D->remove_index = clone_index;
-    *(double **)(X->h_small + sizeof(EkfStreamDev)) = X->P_alt;
-    MSKF_HIPCHK(hipMemcpyAsync(X->d_small, X->h_small, bytes, hipMemcpyHostToDevice, ctx->stream));
-    MSKF_HIPCHK(hipEventRecord(X->small_done, ctx->stream));
-    X->small_pending = true;
+    hipStream_t st = ctx->stream;
+    const size_t bytes = sizeof(EkfStreamDev) * (size_t)n;
+    if (!ctx->pred_done) MSKF_HIPCHK(hipEventCreateWithFlags(&ctx->pred_done, hipEventDisableTiming));
+    if (ctx->pred_pending) { MSKF_HIPCHK(hipEventSynchronize(ctx->pred_done)); ctx->pred_pending = false; }
+    if (bytes > ctx->pred_arena.cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        int rc = ctx->pred_arena.ensure(bytes);
+        if (rc != MSKF_OK) return rc;
+    }
+    EkfStreamDev *D = (EkfStreamDev *)ctx->pred_arena.h;
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
+        EkfStreamState &E = s->ekf_state;
+        EkfExtra *X = extra_of(s);
+        const int nc = (E.d - EKF_IMU_DIM) / 6;
+        int a = idx[2 * i], b = idx[2 * i + 1];
+        if (a < 0 && b >= 0) std::swap(a, b);
+        if (b >= 0 && b < a) std::swap(a, b);
+        if (a >= nc || b >= nc || (a >= 0 && a == b)) return MSKF_ERR_INVALID;
+        base_desc(s, D[i]);
+        D[i].remove_index = a; D[i].remove_index2 = b; D[i].P_dst = X->P_alt;
+        any |= a >= 0;
+    }
+    if (!any) return MSKF_OK;
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.d, ctx->pred_arena.h, bytes, hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipEventRecord(ctx->pred_done, st));
+    ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_REMOVE);
-        ekf_launch_remove_clone((const EkfStreamDev *)X->d_small, (double *const *)(X->d_small + sizeof(EkfStreamDev)), 1, ctx->stream);
-        mskf_t_end(ctx, ts, 1);
+        ekf_launch_remove_clone((const EkfStreamDev *)ctx->pred_arena.d, n, st);
+        mskf_t_end(ctx, ts, n);
     }
     MSKF_HIPCHK(hipGetLastError());
-    std::swap(E.P, X->P_alt);
-    E.d -= 6;
+    for (int i = 0; i < n; ++i) {
+        const EkfStreamDev &Di = D[i];
+        if (Di.remove_index < 0) continue;
+        EkfStreamState &E = streams[i]->ekf_state;
+        std::swap(E.P, extra_of(streams[i])->P_alt);
+        E.d -= Di.remove_index2 >= 0 ? 12 : 6;
+    }
     return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
+    if (!s) return MSKF_ERR_INVALID;
+    const int nc = (s->ekf_state.d - EKF_IMU_DIM) / 6;
+    if (clone_index < 0 || clone_index >= nc) return MSKF_ERR_INVALID;
+    mskf_stream *ss[1] = {s};
+    const int32_t idx[2] = {clone_index, -1};
+    return mskf_ekf_remove_clones_batch(s->ctx, 1, ss, idx);
 }
 
 extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args) {
@@ -308,7 +391,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     hipStream_t st = ctx->stream;
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
-    int max_feat = 0, max_m = 0, max_d = 0;
+    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, total; size_t o_dx, o_gamma, o_rows, o_status, o_total; int m_total; };
     std::vector<Lay> lay(n);
@@ -327,6 +410,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             if (f.n_obs < 2 || f.n_obs > E.max_clones || f.obs_start < 0 || f.obs_start + f.n_obs > a.n_obs) return MSKF_ERR_INVALID;
             if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
             m_total += 4 * f.n_obs - 3;
+            max_frows = std::max(max_frows, 4 * f.n_obs);
             const double nj = 4.0 * f.n_obs - 3.0, M = f.n_obs, dd = E.d;
             fl_feat += 2.0 * nj * (4.0 * M) * (6.0 * M) + 2.0 * nj * dd * dd + 2.0 * nj * nj * dd;
         }
@@ -400,7 +484,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     if (max_feat > 0) {
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
-        ekf_launch_features(ctx->ekf_desc.d, n, max_feat, st);
+        ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, st);
         mskf_t_end(ctx, ts, (long long)fl_feat);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);

@@ -34,8 +34,11 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     mskf_t_collect(c);
     for (auto &e : c->t_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (int i = 0; i < 3; ++i) c->desc[i].release();
+    c->cell_arena.release(); c->trk_in.release(); c->trk_out.release();
     c->jobs.release();
     c->ekf_desc.release();
+    c->pred_arena.release();
+    if (c->pred_done) (void)hipEventDestroy(c->pred_done);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -136,13 +139,6 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
     // point capacity: every live grid slot plus every detector cell
     const int det_cells = fe->det_rows * fe->det_cols;
     s->pt_cap = (fe->grid_row + 1) * (fe->grid_col + 1) * (fe->grid_max_feature_num + 1) + det_cells + 64;
-    if (rc == MSKF_OK) rc = s->in_pts.ensure(s->pt_cap);
-    if (rc == MSKF_OK) rc = s->out0.ensure(s->pt_cap);
-    if (rc == MSKF_OK) rc = s->out1.ensure(s->pt_cap);
-    if (rc == MSKF_OK) rc = s->und0.ensure(s->pt_cap);
-    if (rc == MSKF_OK) rc = s->und1.ensure(s->pt_cap);
-    if (rc == MSKF_OK) rc = s->status.ensure(s->pt_cap);
-    if (rc == MSKF_OK) rc = s->cell_max.ensure(det_cells);
     if (rc == MSKF_OK) rc = mskf_ekf_stream_init(s);
     if (rc != MSKF_OK) { mskf_stream_destroy(s); return rc; }
 
@@ -173,13 +169,13 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
     return MSKF_OK;
 }
 
+extern "C" mskf_ctx *mskf_stream_ctx(mskf_stream *s) { return s ? s->ctx : nullptr; }
+
 extern "C" void mskf_stream_destroy(mskf_stream *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (int i = 0; i < 3; ++i) if (s->pyr[i]) (void)hipFree(s->pyr[i]);
-    s->in_pts.release(); s->out0.release(); s->out1.release(); s->und0.release(); s->und1.release();
-    s->status.release(); s->cell_max.release();
     mskf_ekf_stream_free(s);
     auto &v = s->ctx->streams;
     for (size_t i = 0; i < v.size(); ++i) if (v[i] == s) { v.erase(v.begin() + i); break; }
@@ -195,10 +191,8 @@ static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
     std::memcpy(d.R01, s->R01, sizeof(d.R01));
     std::memcpy(d.E, s->E, sizeof(d.E));
     d.epi_thresh = s->epi_thresh;
-    d.in_pts = s->in_pts.d; d.out0 = s->out0.d; d.out1 = s->out1.d; d.und0 = s->und0.d; d.und1 = s->und1.d;
-    d.status = s->status.d;
     d.det_rows = s->fe.det_rows; d.det_cols = s->fe.det_cols; d.cell_w = s->det_cw; d.cell_h = s->det_ch;
-    d.cell_max = s->cell_max.d;
+    d.cell_max = (mskf_corner *)(s->ctx->cell_arena.d + s->cell_off);
 }
 
 extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
@@ -211,6 +205,14 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
     rc = ctx->desc[0].ensure(n);
     if (rc != MSKF_OK) return rc;
     int max_cells = 0;
+    {
+        size_t cell_bytes = 0;
+        for (int i = 0; i < n; ++i) { if (!streams[i] || streams[i]->ctx != ctx) return MSKF_ERR_INVALID; cell_bytes += sizeof(mskf_corner) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
+        if (cell_bytes > ctx->cell_arena.cap) { MSKF_HIPCHK(hipStreamSynchronize(st)); rc = ctx->cell_arena.ensure(cell_bytes); if (rc != MSKF_OK) return rc; }
+        ++ctx->push_gen;
+        size_t off = 0;
+        for (int i = 0; i < n; ++i) { streams[i]->cell_off = off; streams[i]->push_gen = ctx->push_gen; off += sizeof(mskf_corner) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
+    }
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         if (!s || s->ctx != ctx || !cam0[i] || !cam1[i]) return MSKF_ERR_INVALID;
@@ -251,10 +253,10 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
         fe_launch_detect(ctx->desc[0].d, n, max_cells, st);
         mskf_t_end(ctx, ts, px);
     }
-    for (int i = 0; i < n; ++i) {
-        mskf_stream *s = streams[i];
-        MSKF_HIPCHK(hipMemcpyAsync(s->cell_max.h, s->cell_max.d, sizeof(mskf_corner) * (size_t)s->fe.det_rows * s->fe.det_cols,
-                                   hipMemcpyDeviceToHost, st));
+    {
+        size_t cell_bytes = 0;
+        for (int i = 0; i < n; ++i) cell_bytes += sizeof(mskf_corner) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols;
+        MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
     }
     MSKF_HIPCHK(hipGetLastError());
     return MSKF_OK;
@@ -301,8 +303,10 @@ extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int cap
     if (capacity < n) return MSKF_ERR_CAPACITY;
     if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    if (s->push_gen != s->ctx->push_gen) { mskf_set_error("cell maxima are stale: another push happened on this context"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    std::memcpy(out, s->cell_max.h, sizeof(mskf_corner) * (size_t)n);
+    mskf_t_collect(s->ctx);
+    std::memcpy(out, s->ctx->cell_arena.h + s->cell_off, sizeof(mskf_corner) * (size_t)n);
     *n_out = n;
     return MSKF_OK;
 }
@@ -314,6 +318,8 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     int rc = ctx->desc[1].ensure(n);
     if (rc != MSKF_OK) return rc;
     int max_pts = 0;
+    size_t in_bytes = 0, out_bytes = 0;
+    std::vector<size_t> in_off(n), out_off(n);
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         const mskf_fe_track_args &a = args[i];
@@ -321,57 +327,58 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
         if (a.n > s->pt_cap) { mskf_set_error("too many points for this stream"); return MSKF_ERR_CAPACITY; }
         if (a.n > 0 && (!a.in_pts || !a.out0 || !a.out1 || !a.und0 || !a.und1 || !a.status)) return MSKF_ERR_INVALID;
         if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
+        in_off[i] = in_bytes; out_off[i] = out_bytes;
+        const size_t np = (size_t)a.n;
+        in_bytes += (sizeof(mskf_point2f) * np + 63) & ~(size_t)63;
+        out_bytes += (4 * sizeof(mskf_point2f) * np + np + 63) & ~(size_t)63;   // out0 out1 und0 und1 status
+        max_pts = std::max(max_pts, a.n);
+    }
+    if (max_pts <= 0) return MSKF_OK;
+    if (in_bytes > ctx->trk_in.cap || out_bytes > ctx->trk_out.cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        if ((rc = ctx->trk_in.ensure(in_bytes)) != MSKF_OK) return rc;
+        if ((rc = ctx->trk_out.ensure(out_bytes)) != MSKF_OK) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        const mskf_fe_track_args &a = args[i];
+        const size_t np = (size_t)a.n;
         FeStreamDev &d = ctx->desc[1].h[i];
         fill_fe_desc(s, d);
         d.n_pts = a.n;
         d.do_temporal = a.do_temporal;
         std::memcpy(d.Hpred, a.Hpred, sizeof(d.Hpred));
-        if (a.n > 0) {
-            std::memcpy(s->in_pts.h, a.in_pts, sizeof(mskf_point2f) * (size_t)a.n);
-            MSKF_HIPCHK(hipMemcpyAsync(s->in_pts.d, s->in_pts.h, sizeof(mskf_point2f) * (size_t)a.n, hipMemcpyHostToDevice, st));
-        }
-        max_pts = std::max(max_pts, a.n);
+        if (np) std::memcpy(ctx->trk_in.h + in_off[i], a.in_pts, sizeof(mskf_point2f) * np);
+        d.in_pts = (const mskf_point2f *)(ctx->trk_in.d + in_off[i]);
+        char *o = ctx->trk_out.d + out_off[i];
+        d.out0 = (mskf_point2f *)o; d.out1 = d.out0 + np; d.und0 = d.out1 + np; d.und1 = d.und0 + np;
+        d.status = (uint8_t *)(d.und1 + np);
     }
-    if (max_pts > 0) {
-        MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-        const int ts_lk = mskf_t_begin(ctx, MSKF_K_LK);
-        fe_launch_lk(ctx->desc[1].d, n, max_pts, st);
-        mskf_t_end(ctx, ts_lk, 0);
-        for (int i = 0; i < n; ++i) {
-            mskf_stream *s = streams[i];
-            const size_t np = (size_t)args[i].n;
-            if (!np) continue;
-            MSKF_HIPCHK(hipMemcpyAsync(s->out0.h, s->out0.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
-            MSKF_HIPCHK(hipMemcpyAsync(s->out1.h, s->out1.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
-            MSKF_HIPCHK(hipMemcpyAsync(s->und0.h, s->und0.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
-            MSKF_HIPCHK(hipMemcpyAsync(s->und1.h, s->und1.d, sizeof(mskf_point2f) * np, hipMemcpyDeviceToHost, st));
-            MSKF_HIPCHK(hipMemcpyAsync(s->status.h, s->status.d, np, hipMemcpyDeviceToHost, st));
-        }
-        MSKF_HIPCHK(hipGetLastError());
-        MSKF_HIPCHK(hipStreamSynchronize(st));
-        if (ts_lk >= 0) {
-            // units of the LK launch = point tracks executed: temporal (n) + stereo (tracked), or stereo only (n)
-            long long tracks = 0;
-            for (int i = 0; i < n; ++i) {
-                const size_t np = (size_t)args[i].n;
-                tracks += (long long)np;
-                if (args[i].do_temporal) for (size_t k = 0; k < np; ++k) tracks += (streams[i]->status.h[k] & 1);
-            }
-            ctx->t_pending[ts_lk].units = tracks;
-        }
-        mskf_t_collect(ctx);
-        for (int i = 0; i < n; ++i) {
-            mskf_stream *s = streams[i];
-            const mskf_fe_track_args &a = args[i];
-            const size_t np = (size_t)a.n;
-            if (!np) continue;
-            std::memcpy(a.out0, s->out0.h, sizeof(mskf_point2f) * np);
-            std::memcpy(a.out1, s->out1.h, sizeof(mskf_point2f) * np);
-            std::memcpy(a.und0, s->und0.h, sizeof(mskf_point2f) * np);
-            std::memcpy(a.und1, s->und1.h, sizeof(mskf_point2f) * np);
-            std::memcpy(a.status, s->status.h, np);
-        }
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_in.d, ctx->trk_in.h, in_bytes, hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    const int ts_lk = mskf_t_begin(ctx, MSKF_K_LK);
+    fe_launch_lk(ctx->desc[1].d, n, max_pts, st);
+    mskf_t_end(ctx, ts_lk, 0);
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
+    MSKF_HIPCHK(hipGetLastError());
+    MSKF_HIPCHK(hipStreamSynchronize(st));
+    long long tracks = 0;
+    for (int i = 0; i < n; ++i) {
+        const mskf_fe_track_args &a = args[i];
+        const size_t np = (size_t)a.n;
+        if (!np) continue;
+        const char *o = ctx->trk_out.h + out_off[i];
+        std::memcpy(a.out0, o, sizeof(mskf_point2f) * np);
+        std::memcpy(a.out1, o + sizeof(mskf_point2f) * np, sizeof(mskf_point2f) * np);
+        std::memcpy(a.und0, o + 2 * sizeof(mskf_point2f) * np, sizeof(mskf_point2f) * np);
+        std::memcpy(a.und1, o + 3 * sizeof(mskf_point2f) * np, sizeof(mskf_point2f) * np);
+        std::memcpy(a.status, o + 4 * sizeof(mskf_point2f) * np, np);
+        // units of the LK launch = point tracks executed: temporal (n) + stereo (tracked), or stereo only (n)
+        tracks += (long long)np;
+        if (a.do_temporal) for (size_t k = 0; k < np; ++k) tracks += (a.status[k] & 1);
     }
+    if (ts_lk >= 0) ctx->t_pending[ts_lk].units = tracks;
+    mskf_t_collect(ctx);
     return MSKF_OK;
 }
 

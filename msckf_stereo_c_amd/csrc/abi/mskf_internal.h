@@ -58,8 +58,14 @@ struct mskf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
+    PinnedDev<char> cell_arena;       // per-cell maxima of every stream of the last push batch (one D2H copy)
+    PinnedDev<char> trk_in, trk_out;  // input points / results of every stream of a track batch (one copy each way)
+    unsigned long long push_gen = 0;
     PinnedDev<PyrJob> jobs;
     PinnedDev<EkfStreamDev> ekf_desc;
+    PinnedDev<char> pred_arena;          // descriptors + IMU steps + J of mskf_ekf_predict_batch
+    hipEvent_t pred_done = nullptr;
+    bool pred_pending = false;
     std::vector<mskf_stream *> streams;
 };
 
@@ -77,9 +83,8 @@ struct mskf_stream {
     int i_prev0 = 0, i_curr0 = 1, i_curr1 = 2;
     bool has_curr = false;
     int pt_cap = 0;
-    PinnedDev<mskf_point2f> in_pts, out0, out1, und0, und1;
-    PinnedDev<uint8_t> status;
-    PinnedDev<mskf_corner> cell_max;
+    size_t cell_off = 0;              // slice of ctx->cell_arena
+    unsigned long long push_gen = 0;
     CamDev cam0, cam1;
     double R01[9], E[9], epi_thresh = 0;
     int det_cw = 0, det_ch = 0;

@@ -5,7 +5,7 @@
 #include "../../../include/mskf_hip.h"
 
 #define EKF_IMU_DIM 21
-#define EKF_SLOTS 32          // feature workgroups per stream and launch (each loops over its features)
+#define EKF_SLOTS 64          // feature workgroups per stream and launch (each loops over its features)
 
 // Per feature of one update (device copy of mskf_ekf_feature + row offset of its block)
 struct EkfFeatDev {
@@ -48,7 +48,9 @@ struct EkfStreamDev {
     double qc[4];             // continuous noise variances: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:174-178)
     int n_steps;
     const double *J;          // 6 x 21
-    int remove_index;         // clone to delete
+    int remove_index;         // clone to delete (-1 = none)
+    int remove_index2;        // second clone to delete, > remove_index (-1 = none)
+    double *P_dst;            // destination of the out-of-place clone removal
 };
 
 struct EkfStreamState {       // host-side bookkeeping of the device buffers of one stream

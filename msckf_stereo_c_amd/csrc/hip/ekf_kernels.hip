@@ -51,16 +51,19 @@ __device__ __forceinline__ void mat3t_vec(const double *A, const double *v, doub
     for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
 }
 
-// ------------------------------------------------------------------------------------ propagate
-// P_II <- sym(Phi P_II Phi^T + Q);  P_IC <- Phi P_IC;  P_CI <- P_IC^T     (per IMU step)
+// ------------------------------------------------------------------------------------ propagate (+ augment)
+// Per IMU step: P_II <- sym(Phi P_II Phi^T + Q) (in LDS); the clone cross terms are propagated once with the
+// composed transition  P_IC <- (Phi_n ... Phi_1) P_IC  (one pass over P instead of one per IMU sample),
+// P_CI <- P_IC^T.  With S.J set the state augmentation (rows/cols [d, d+6) = J [P_II P_IC], corner
+// sym(J P_II J^T)) is fused into the same pass.
 __global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_steps <= 0) return;
+    if (S.n_steps <= 0 && !S.J) return;
     double *P = S.P;
     const int d = S.d, ld = S.ld, N = EKF_IMU_DIM;
-    __shared__ double sPhi[N * N], sQ[N * N], sP[N * N], sT[N * N];
+    __shared__ double sPhi[N * N], sQ[N * N], sP[N * N], sT[N * N], sTot[N * N], sJ[6 * N], sC[6 * N];
     const int tid = threadIdx.x;
-    for (int i = tid; i < N * N; i += WG) sP[i] = P[(size_t)(i / N) * ld + (i % N)];
+    for (int i = tid; i < N * N; i += WG) { sP[i] = P[(size_t)(i / N) * ld + (i % N)]; sTot[i] = (i / N == i % N) ? 1.0 : 0.0; }
     for (int step = 0; step < S.n_steps; ++step) {
         __syncthreads();
         if (S.imu_steps) {
@@ -123,11 +126,13 @@ __global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *stream
             for (int i = tid; i < N * N; i += WG) { sPhi[i] = PhiQ[i]; sQ[i] = PhiQ[N * N + i]; }
         }
         __syncthreads();
+        double t0 = 0, t1 = 0;   // Phi * Tot, elements tid and tid + WG
         for (int i = tid; i < N * N; i += WG) {
             const int r = i / N, c = i % N;
-            double s = 0;
-            for (int k = 0; k < N; ++k) s += sPhi[r * N + k] * sP[k * N + c];
+            double s = 0, st2 = 0;
+            for (int k = 0; k < N; ++k) { s += sPhi[r * N + k] * sP[k * N + c]; st2 += sPhi[r * N + k] * sTot[k * N + c]; }
             sT[i] = s;
+            if (i < WG) t0 = st2; else t1 = st2;
         }
         __syncthreads();
         double x0 = 0, x1 = 0;  // each thread owns elements tid and tid+WG (N*N = 441 <= 512)
@@ -141,23 +146,47 @@ __global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *stream
                 if (e == 0) x0 = v; else x1 = v;
             }
         }
-        // P_IC columns
-        for (int c = N + tid; c < d; c += WG) {
-            double col[N];
-            for (int k = 0; k < N; ++k) col[k] = P[(size_t)k * ld + c];
-            for (int r = 0; r < N; ++r) {
-                double s = 0;
-                for (int k = 0; k < N; ++k) s += sPhi[r * N + k] * col[k];
-                P[(size_t)r * ld + c] = s;
-                P[(size_t)c * ld + r] = s;
-            }
-        }
         __syncthreads();
-        if (tid < N * N) sP[tid] = x0;
-        if (tid + WG < N * N) sP[tid + WG] = x1;
+        if (tid < N * N) { sP[tid] = x0; sTot[tid] = t0; }
+        if (tid + WG < N * N) { sP[tid + WG] = x1; sTot[tid + WG] = t1; }
     }
     __syncthreads();
+    if (S.J) for (int i = tid; i < 6 * N; i += WG) sJ[i] = S.J[i];
+    __syncthreads();
+    // one pass over the clone columns: P_IC <- Tot P_IC (and its mirror), augmentation rows from the new column
+    for (int c = tid; c < d; c += WG) {
+        double col[N];
+        if (c < N) { for (int k = 0; k < N; ++k) col[k] = sP[k * N + c]; }
+        else {
+            double old[N];
+            for (int k = 0; k < N; ++k) old[k] = P[(size_t)k * ld + c];
+            for (int r = 0; r < N; ++r) {
+                double s = 0;
+                for (int k = 0; k < N; ++k) s += sTot[r * N + k] * old[k];
+                col[r] = s;
+            }
+            if (S.n_steps > 0) for (int r = 0; r < N; ++r) { P[(size_t)r * ld + c] = col[r]; P[(size_t)c * ld + r] = col[r]; }
+        }
+        if (S.J) {
+            for (int r = 0; r < 6; ++r) {
+                double s = 0;
+                for (int k = 0; k < N; ++k) s += sJ[r * N + k] * col[k];
+                P[(size_t)(d + r) * ld + c] = s;
+                P[(size_t)c * ld + (d + r)] = s;
+                if (c < N) sC[r * N + c] = s;
+            }
+        }
+    }
     for (int i = tid; i < N * N; i += WG) P[(size_t)(i / N) * ld + (i % N)] = sP[i];
+    if (S.J) {
+        __syncthreads();
+        if (tid < 36) {
+            const int r = tid / 6, c = tid % 6;
+            double s = 0, st = 0;
+            for (int k = 0; k < N; ++k) { s += sC[r * N + k] * sJ[c * N + k]; st += sC[c * N + k] * sJ[r * N + k]; }
+            P[(size_t)(d + r) * ld + (d + c)] = (s + st) / 2.0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ augment
@@ -192,17 +221,19 @@ __global__ __launch_bounds__(WG) void k_ekf_augment(const EkfStreamDev *streams)
 }
 
 // ------------------------------------------------------------------------------------ remove clone
-// out-of-place: Pdst <- P with rows/cols [s0, s0+6) removed
-__global__ __launch_bounds__(WG) void k_ekf_remove_clone(const EkfStreamDev *streams, double *const *dst) {
+// out-of-place: P_dst <- P with the rows/cols of one or two clones removed
+__global__ __launch_bounds__(WG) void k_ekf_remove_clone(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
+    if (S.remove_index < 0 || !S.P_dst) return;
     const int d = S.d, ld = S.ld;
     const int s0 = EKF_IMU_DIM + 6 * S.remove_index;
-    double *Pd = dst[blockIdx.y];
-    const int dn = d - 6;
+    const int s1 = S.remove_index2 >= 0 ? EKF_IMU_DIM + 6 * S.remove_index2 : (1 << 30);
+    const int dn = d - (S.remove_index2 >= 0 ? 12 : 6);
     for (int idx = blockIdx.x * WG + threadIdx.x; idx < dn * dn; idx += gridDim.x * WG) {
         const int i = idx / dn, j = idx - i * dn;
-        const int si = i < s0 ? i : i + 6, sj = j < s0 ? j : j + 6;
-        Pd[(size_t)i * ld + j] = S.P[(size_t)si * ld + sj];
+        int si = i < s0 ? i : i + 6; if (si >= s1) si += 6;
+        int sj = j < s0 ? j : j + 6; if (sj >= s1) sj += 6;
+        S.P_dst[(size_t)i * ld + j] = S.P[(size_t)si * ld + sj];
     }
 }
 
@@ -359,8 +390,11 @@ __device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, Tri
     return !bad;
 }
 
-// LDS budget of k_ekf_feature_blocks (bytes): Hf 6K + Hx 12K + r 2K + V 6K + coef 9K + tri 17K ~ 52K
-__global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *streams) {
+// LDS: static Hf 6K + Hx 12K + r 2K + V 6K + coef 9K ~ 36K; dynamic arena = max(triangulation scratch,
+// lds_rows^2 doubles for the gating matrix M) — M lives in LDS when 4 n_obs <= lds_rows (<= 120 rows = 112.5 KiB),
+// otherwise in the per-slot global scratch gate_S.
+#define GATE_LDS_ROWS 120
+__global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *streams, int lds_rows) {
     const EkfStreamDev &S = streams[blockIdx.y];
     const int tid = threadIdx.x;
     const int d = S.d, ld = S.ld;
@@ -372,7 +406,9 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
     __shared__ double sBeta[3], sVV[3];  // beta_k ; v2.v1, v3.v1, v3.v2
     __shared__ int sObsOfClone[MAX_CLONES_DEV];
     __shared__ int sCloneOfObs[MAX_CLONES_DEV];
-    __shared__ TriScratch sTri;
+    extern __shared__ double s_arena[];
+    TriScratch &sTri = *reinterpret_cast<TriScratch *>(s_arena);
+    __shared__ double sW[4 * MAX_CLONES_DEV];
     __shared__ double sPos[3];
     __shared__ int sValid;
     __shared__ double sRed[8];
@@ -530,70 +566,88 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
         }
         __syncthreads();
         // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
-        const int kc = 6 * M;                     // compact columns
-        double *Tc = S.gate_T + (size_t)blockIdx.x * S.nmax * ld;      // n x kc (row stride kc)
-        double *Sg = S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax;  // n x n
+        // H = A^T H_xj with H_xj block diagonal (4x6 per observation), so H P H^T = A^T Mm A with
+        // Mm[a][b] = H_a P_ab H_b^T (4x4 blocks from 6x6 blocks of P), and A^T . A = rows/cols 3.. of Q^T . Q.
+        double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax);
         const double *P = S.P;
-        for (int idx = tid; idx < n * kc; idx += WG) {
-            const int i = idx / kc, b = idx - i * kc;
-            const int colb = EKF_IMU_DIM + 6 * sCloneOfObs[b / 6] + (b % 6);
-            const double *hrow = Hrow0 + (size_t)i * ld;
-            double s = 0;
-            for (int a = 0; a < kc; ++a) {
-                const int cola = EKF_IMU_DIM + 6 * sCloneOfObs[a / 6] + (a % 6);
-                s += hrow[cola] * P[(size_t)cola * ld + colb];
+        for (int pr = tid; pr < M * M; pr += WG) {
+            const int a = pr / M, b = pr - a * M;
+            if (b > a) continue;
+            const int ca = EKF_IMU_DIM + 6 * sCloneOfObs[a], cb = EKF_IMU_DIM + 6 * sCloneOfObs[b];
+            double Pab[6][6];
+            for (int u = 0; u < 6; ++u) for (int v = 0; v < 6; ++v) Pab[u][v] = P[(size_t)(ca + u) * ld + cb + v];
+            double HP[4][6];
+            for (int i = 0; i < 4; ++i) for (int v = 0; v < 6; ++v) {
+                double t = 0;
+                for (int u = 0; u < 6; ++u) t += sHx[4 * a + i][u] * Pab[u][v];
+                HP[i][v] = t;
             }
-            Tc[idx] = s;
+            for (int i = 0; i < 4; ++i) for (int jj = 0; jj < 4; ++jj) {
+                double t = 0;
+                for (int v = 0; v < 6; ++v) t += HP[i][v] * sHx[4 * b + jj][v];
+                Mm[(size_t)(4 * a + i) * rows + 4 * b + jj] = t;
+                Mm[(size_t)(4 * b + jj) * rows + 4 * a + i] = t;
+            }
         }
         __syncthreads();
-        for (int idx = tid; idx < n * n; idx += WG) {
-            const int i = idx / n, i2 = idx - i * n;
-            if (i2 > i) continue;
-            const double *h2 = Hrow0 + (size_t)i2 * ld;
-            double s = 0;
-            for (int b = 0; b < kc; ++b) {
-                const int colb = EKF_IMU_DIM + 6 * sCloneOfObs[b / 6] + (b % 6);
-                s += Tc[(size_t)i * kc + b] * h2[colb];
+        // two-sided reflectors: Mm <- Q_k^T Mm Q_k, Q_k = I - beta_k v_k v_k^T  (Mm symmetric)
+        for (int k = 0; k < 3; ++k) {
+            const double beta = sBeta[k];
+            if (beta == 0.0) continue;     // uniform
+            for (int i = tid; i < rows; i += WG) {
+                double t = 0;
+                const double *mi = Mm + (size_t)i * rows;
+                for (int c = 0; c < rows; ++c) t += mi[c] * sV[k][c];
+                sW[i] = t;
             }
-            if (i == i2) s += S.sigma2;
-            Sg[(size_t)i * n + i2] = s;
+            __syncthreads();
+            double pa = 0;
+            for (int i = tid; i < rows; i += WG) pa += sV[k][i] * sW[i];
+            const double alpha = block_sum(pa, sRed);
+            const double b2a = beta * beta * alpha;
+            for (int e = tid; e < rows * rows; e += WG) {
+                const int i = e / rows, c = e - i * rows;
+                Mm[e] += -beta * (sV[k][i] * sW[c] + sW[i] * sV[k][c]) + b2a * sV[k][i] * sV[k][c];
+            }
+            __syncthreads();
         }
+        // S = Mm[3:,3:] + sigma^2 I ; in-place Cholesky (lower) on the sub-matrix view, forward solve, gamma
+        double *Sg = Mm + (size_t)3 * rows + 3;    // row stride `rows`
+        for (int i = tid; i < n; i += WG) Sg[(size_t)i * rows + i] += S.sigma2;
         __syncthreads();
-        // in-place Cholesky (lower) of Sg, right-looking, then forward solve L y = r, gamma = y.y
         bool pd_ok = true;
         for (int k = 0; k < n; ++k) {
-            const double dk = Sg[(size_t)k * n + k];
+            const double dk = Sg[(size_t)k * rows + k];
             if (!(dk > 0)) { pd_ok = false; break; }
-            const double lkk = sqrt(dk);
+            const double inv = 1.0 / sqrt(dk);
             __syncthreads();
-            for (int i = k + tid; i < n; i += WG) Sg[(size_t)i * n + k] = (i == k) ? lkk : Sg[(size_t)i * n + k] / lkk;
+            for (int i = k + tid; i < n; i += WG) Sg[(size_t)i * rows + k] *= inv;   // column k: l_kk = sqrt(dk), l_ik = a_ik / l_kk
             __syncthreads();
             const int rem = n - k - 1;
             for (int idx = tid; idx < rem * rem; idx += WG) {
                 const int a = idx / rem + k + 1, b = idx % rem + k + 1;
-                if (b <= a) Sg[(size_t)a * n + b] -= Sg[(size_t)a * n + k] * Sg[(size_t)b * n + k];
+                if (b <= a) Sg[(size_t)a * rows + b] -= Sg[(size_t)a * rows + k] * Sg[(size_t)b * rows + k];
             }
             __syncthreads();
         }
         double gamma = 1e300;
         if (pd_ok) {
-            // y in Tc[0..n)
-            __syncthreads();
-            for (int i = tid; i < n; i += WG) Tc[i] = r0[i];
+            // forward solve L y = r_o (y in sW), one wave; gamma = y . y
+            for (int i = tid; i < n; i += WG) sW[i] = r0[i];
             __syncthreads();
             if (tid < 64) {
                 for (int i = 0; i < n; ++i) {
                     double part = 0;
-                    for (int p = tid; p < i; p += 64) part += Sg[(size_t)i * n + p] * Tc[p];
+                    for (int p = tid; p < i; p += 64) part += Sg[(size_t)i * rows + p] * sW[p];
                     part = wave_sum(part);
-                    if (tid == 0) Tc[i] = (Tc[i] - part) / Sg[(size_t)i * n + i];
+                    if (tid == 0) sW[i] = (sW[i] - part) / Sg[(size_t)i * rows + i];
                     __builtin_amdgcn_wave_barrier();
                     __threadfence_block();
                 }
             }
             __syncthreads();
             double pg = 0;
-            for (int i = tid; i < n; i += WG) pg += Tc[i] * Tc[i];
+            for (int i = tid; i < n; i += WG) pg += sW[i] * sW[i];
             gamma = block_sum(pg, sRed);
         }
         const int dof = M + S.dof_offset;
@@ -639,12 +693,21 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_propagate, dim3(1, n), dim3(WG), 0, st, d); }
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_augment, dim3(1, n), dim3(WG), 0, st, d); }
-void ekf_launch_remove_clone(const EkfStreamDev *d, double *const *dst, int n, hipStream_t st) {
-    hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d, dst);
+void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);
 }
-void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, hipStream_t st) {
+void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st) {
     const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
-    hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), 0, st, d);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GATE_LDS_ROWS * GATE_LDS_ROWS * (int)sizeof(double));
+        attr_set = true;
+    }
+    const int lds_rows = max_rows <= GATE_LDS_ROWS ? max_rows : GATE_LDS_ROWS;
+    size_t lds = (size_t)lds_rows * lds_rows * sizeof(double);
+    if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
+    hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
 }
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d); }
 }

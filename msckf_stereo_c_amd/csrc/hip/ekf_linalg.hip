@@ -218,6 +218,114 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
     }
 }
 
+// ------------------------------------------------------------------------------------ LDS-resident Cholesky
+// Same factorisation with the active block held in LDS in packed lower form (row i at i(i+1)/2).
+// Structure used: the 21 IMU columns of every stacked Jacobian are zero (H_x only touches clone columns,
+// msckf_vio.cpp:698,713), so rows/cols [0,21) of G = [H|r]^T[H|r] are exactly zero (pivots skipped, L = 0)
+// and rows/cols [0,21) of S = T R^T + sigma^2 I are sigma^2 I (L = sigma I).  Only the trailing
+// (d-21) x (d-21) block is factorised: <= 180 rows for 30 clones = 127 KiB packed + an 8-wide panel.
+#define LNB 8
+#define CHOL_LDS_MAX_ROWS 181     // active rows incl. the extra Q^T r row
+__global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    if (S.n_feat <= 0) return;
+    double *A = which == 0 ? S.S : S.W;
+    const int off = EKF_IMU_DIM, lda = S.ld;
+    const int n = S.d - off;                       // active columns
+    const int nt = n + (which == 0 ? 1 : 0);       // rows incl. the extra row
+    const bool semidef = which == 0;
+    extern __shared__ double s_dyn[];
+    double *sM = s_dyn;                            // packed lower, nt rows
+    double *sPan = s_dyn + (size_t)nt * (nt + 1) / 2;   // [nt][LNB]
+    __shared__ double s_tol, s_mx[16];
+    const int tid = threadIdx.x;
+    // load (row-wise, coalesced along j)
+    for (int e = tid; e < nt * nt; e += 1024) {
+        const int i = e / nt, j = e - i * nt;
+        if (j <= i) sM[(size_t)i * (i + 1) / 2 + j] = A[(size_t)(off + i) * lda + off + j];
+    }
+    __syncthreads();
+    if (semidef) {
+        double mx = 0;
+        for (int i = tid; i < n; i += 1024) mx = fmax(mx, sM[(size_t)i * (i + 1) / 2 + i]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, s_mx[i]); s_tol = m * (double)S.d * 2.220446049250313e-16; }
+    } else if (tid == 0) s_tol = 0.0;
+    __syncthreads();
+    const double tol = s_tol;
+    for (int kb = 0; kb < n; kb += LNB) {
+        const int nb = min(LNB, n - kb);
+        // 1. diagonal block, in place in sM, by wave 0
+        if (tid < 64) {
+            for (int j = 0; j < nb; ++j) {
+                const double piv = sM[(size_t)(kb + j) * (kb + j + 1) / 2 + kb + j];
+                const bool skip = !(piv > tol);
+                const double l = skip ? 0.0 : sqrt(piv);
+                const double inv = skip ? 0.0 : 1.0 / l;
+                __builtin_amdgcn_wave_barrier();
+                if (tid >= j && tid < nb) {
+                    double *p = &sM[(size_t)(kb + tid) * (kb + tid + 1) / 2 + kb + j];
+                    *p = (tid == j) ? l : (*p) * inv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // (i, c) with j < c <= i < nb
+                if (tid < LNB * LNB) {
+                    const int i = tid / LNB, cc = tid % LNB;
+                    if (cc > j && cc <= i && i < nb) {
+                        const size_t ri = (size_t)(kb + i) * (kb + i + 1) / 2 + kb, rc = (size_t)(kb + cc) * (kb + cc + 1) / 2 + kb;
+                        sM[ri + cc] -= sM[ri + j] * sM[rc + j];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        // 2. panel rows below: x L11^T = a
+        const int r0 = kb + nb;
+        for (int i = r0 + tid; i < nt; i += 1024) {
+            double *row = &sM[(size_t)i * (i + 1) / 2 + kb];
+            double x[LNB];
+#pragma unroll
+            for (int j = 0; j < LNB; ++j) {
+                double s2 = (j < nb) ? row[j] : 0.0;
+                const size_t rj = (size_t)(kb + j) * (kb + j + 1) / 2 + kb;
+#pragma unroll
+                for (int cc = 0; cc < j; ++cc) s2 -= x[cc] * ((j < nb) ? sM[rj + cc] : 0.0);
+                const double ljj = (j < nb) ? sM[rj + j] : 0.0;
+                x[j] = (j < nb && ljj != 0.0) ? s2 / ljj : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < LNB; ++j) { if (j < nb) row[j] = x[j]; sPan[(size_t)(i - r0) * LNB + j] = x[j]; }
+        }
+        __syncthreads();
+        // 3. trailing update (lower part; the extra row only against columns < n)
+        const int rem = nt - r0, remc = n - r0;
+        for (int e = tid; e < rem * remc; e += 1024) {
+            const int a = e / remc, b = e - a * remc;
+            if (b > a) continue;
+            const double *pa = sPan + (size_t)a * LNB, *pb = sPan + (size_t)b * LNB;
+            double s2 = 0;
+#pragma unroll
+            for (int cc = 0; cc < LNB; ++cc) s2 += pa[cc] * pb[cc];
+            sM[(size_t)(r0 + a) * (r0 + a + 1) / 2 + r0 + b] -= s2;
+        }
+        __syncthreads();
+    }
+    // store back; the trivial IMU block: L = 0 (Gram) or sigma I (S)
+    for (int e = tid; e < nt * nt; e += 1024) {
+        const int i = e / nt, j = e - i * nt;
+        if (j <= i && j < n) A[(size_t)(off + i) * lda + off + j] = sM[(size_t)i * (i + 1) / 2 + j];
+    }
+    const double l0 = semidef ? 0.0 : sqrt(S.sigma2);
+    const int rows_all = S.d + (which == 0 ? 1 : 0);
+    for (int e = tid; e < rows_all * off; e += 1024) {
+        const int i = e / off, j = e - i * off;
+        if (j <= i) A[(size_t)i * lda + j] = (i == j) ? l0 : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------ r_thin column
 // column d of T <- row d of L (= (Q^T r)^T), so the TRSM carries w = L2^-1 Q^T r along
 __global__ __launch_bounds__(256) void k_ekf_rthin(const EkfStreamDev *streams) {
@@ -301,6 +409,18 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
     hipLaunchKernelGGL(k_ekf_gemm, dim3(t * t, n), dim3(256), 0, st, d, mode);
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
+    const int nt = max_d - EKF_IMU_DIM + 1;
+    if (nt <= CHOL_LDS_MAX_ROWS) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_LDS_MAX_ROWS * LNB) * sizeof(double)));
+            attr_set = true;
+        }
+        const size_t lds = ((size_t)nt * (nt + 1) / 2 + (size_t)nt * LNB) * sizeof(double);
+        hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(1024), lds, st, d, which);
+        return;
+    }
     const size_t lds = (size_t)(CNB * (CNB + 1) + (size_t)(max_d + 2) * CNB) * sizeof(double);
     hipLaunchKernelGGL(k_ekf_chol, dim3(1, n), dim3(256), lds, st, d, which);
 }

@@ -1,5 +1,6 @@
 // batch_runner.cpp — see batch_runner.h.
 #include "batch_runner.h"
+#include <chrono>
 #include <cstring>
 
 namespace cg {
@@ -36,6 +37,8 @@ void BatchGroup::imu(int i, const mskf_imu_sample &s) {
 int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw) {
     const int n = size();
     if (!ok_ || n == 0) return MSKF_ERR_INVALID;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](int ph) { auto t = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t - tp).count(); tp = t; };
     // ---- front-end (System::stereo_callback for every stream)
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams_[i];
@@ -45,15 +48,21 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
         ip.phaseBegin(t[i], 0, 0);
     }
     BR_CHK(mskf_fe_push_stereo_batch(ctx_, n, streams_.data(), cam0, cam1, on_device));
+    lap(PH_PUSH);
     for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phasePrepare1(a1_[i]);
+    lap(PH_PREP1);
     BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a1_.data()));
+    lap(PH_TRACK1);
     for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phaseAfter1(a2_[i]);
+    lap(PH_AFTER1);
     BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a2_.data()));
+    lap(PH_TRACK2);
     for (int i = 0; i < n; ++i) {
         systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
         systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
         systems_[i]->msckfvio_ptr()->setZeroTailHint(systems_[i]->imgproc_ptr_->feature_msg_ptr_.get(), systems_[i]->imgproc_ptr_->zeroTailStart());
     }
+    lap(PH_AFTER2);
     // ---- back-end (System::backend_callback for every stream)
     std::vector<mskf_stream *> sub_s;
     std::vector<mskf_ekf_update_args> sub_a;
@@ -65,15 +74,44 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
         return mskf_ekf_update_batch(ctx_, (int)sub_s.size(), sub_s.data(), sub_a.data());
     };
     bool any = false;
-    for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->phaseA(systems_[i]->feature_msg(), u_[i]);
+    for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->phaseA(systems_[i]->feature_msg(), u_[i], true);
+    if (any) {
+        std::vector<int32_t> ns(n);
+        std::vector<const mskf_imu_step *> sp(n);
+        std::vector<const double *> jp(n);
+        for (int i = 0; i < n; ++i) {
+            MsckfVio &v = *systems_[i]->msckfvio_ptr();
+            const bool act = v.frameActive();
+            ns[i] = act ? (int)v.predictSteps().size() : 0;
+            sp[i] = ns[i] ? v.predictSteps().data() : nullptr;
+            jp[i] = act ? v.predictJ() : nullptr;
+        }
+        BR_CHK(mskf_ekf_predict_batch(ctx_, n, streams_.data(), ns.data(), sp.data(), jp.data()));
+    }
+    lap(PH_EKF_A);
     if (!any) return MSKF_OK;
     BR_CHK(run_updates());
+    lap(PH_UPD1);
     for (int i = 0; i < n; ++i) if (systems_[i]->msckfvio_ptr()->frameActive()) systems_[i]->msckfvio_ptr()->phaseB(u_[i]); else std::memset(&u_[i], 0, sizeof(u_[i]));
+    lap(PH_EKF_B);
     BR_CHK(run_updates());
-    for (int i = 0; i < n; ++i) systems_[i]->msckfvio_ptr()->phaseC();
+    lap(PH_UPD2);
+    {
+        std::vector<int32_t> rm(2 * (size_t)n, -1);
+        bool any_rm = false;
+        for (int i = 0; i < n; ++i) {
+            MsckfVio &v = *systems_[i]->msckfvio_ptr();
+            v.phaseC(true);
+            rm[2 * i] = v.pendingRemovals()[0]; rm[2 * i + 1] = v.pendingRemovals()[1];
+            any_rm |= rm[2 * i] >= 0;
+        }
+        if (any_rm) BR_CHK(mskf_ekf_remove_clones_batch(ctx_, n, streams_.data(), rm.data()));
+    }
+    lap(PH_EKF_C);
     std::vector<double> pv(3 * (size_t)n);
     BR_CHK(mskf_ekf_get_pos_var_batch(ctx_, n, streams_.data(), pv.data()));
     for (int i = 0; i < n; ++i) systems_[i]->msckfvio_ptr()->phaseD(&pv[3 * i]);
+    lap(PH_POSVAR);
     return MSKF_OK;
 }
 
@@ -86,6 +124,7 @@ static double ns_to_sec(long long ns) {   // apps/run_euroc_single_thread.cpp:16
 int BatchGroup::run(int first, int n_frames) {
     const int n = size();
     for (int k = first; k < first + n_frames; ++k) {
+        auto t_imu0 = std::chrono::steady_clock::now();
         for (int i = 0; i < n; ++i) {
             StreamSequence &q = seq[i];
             if (!q.cam0_base || !q.imu) { error_ = "no sequence attached"; return MSKF_ERR_INVALID; }
@@ -103,6 +142,7 @@ int BatchGroup::run(int first, int n_frames) {
             p1_[i] = q.cam1_base + (size_t)key * q.frame_bytes;
             t_[i] = t_img;
         }
+        phase_s[PH_IMU] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_imu0).count();
         int rc = step(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
         if (rc != MSKF_OK) return rc;
     }

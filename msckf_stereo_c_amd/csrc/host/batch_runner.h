@@ -37,6 +37,8 @@ class BatchGroup {
     std::vector<StreamSequence> seq;
     mskf_ctx *ctx() const { return ctx_; }
     const std::string &error() const { return error_; }
+    enum { PH_PUSH = 0, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_IMU, PH_COUNT };
+    double phase_s[PH_COUNT] = {0};   // wall seconds per phase of step() (host bookkeeping vs device calls)
 
   private:
     mskf_ctx *ctx_ = nullptr;

@@ -52,6 +52,14 @@ void mskfh_runner_get_timing(void *h, double *ms, long long *launches, long long
     }
 }
 
+// wall seconds per step() phase summed over groups (BatchGroup::PH_*), optionally reset
+void mskfh_runner_get_phases(void *h, double *out, int reset) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int k = 0; k < BatchGroup::PH_COUNT; ++k) out[k] = 0;
+    for (int g = 0; g < r->n_groups(); ++g)
+        for (int k = 0; k < BatchGroup::PH_COUNT; ++k) { out[k] += r->group(g).phase_s[k]; if (reset) r->group(g).phase_s[k] = 0; }
+}
+
 // ---- per-stream inspection
 int mskfh_num_features(void *h, int stream) {
     std::vector<ImageProcessor::FeatureIDType> ids; std::vector<int> life; std::vector<Point2f> a, b;

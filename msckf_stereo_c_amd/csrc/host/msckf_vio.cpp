@@ -158,9 +158,12 @@ void MsckfVio::featureCallback(const CameraMeasurementConstPtr &msg) {
     }
 }
 
-bool MsckfVio::phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args &upd) {
+bool MsckfVio::phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args &upd, bool defer_device) {
     std::memset(&upd, 0, sizeof(upd));
     frame_active_ = false;
+    defer_device_ = defer_device;
+    have_J_ = false;
+    imu_steps_.clear();
     if (!is_gravity_set) return false;
     if (is_first_img) { is_first_img = false; state_server.imu_state.time = msg->time_stamp; }
     frame_active_ = true;
@@ -208,7 +211,7 @@ void MsckfVio::batchImuProcessing(double time_bound) {
     }
     s.id = next_state_id_++;
     imu_msg_buffer.erase(imu_msg_buffer.begin(), imu_msg_buffer.begin() + used);
-    if (!imu_steps_.empty()) {
+    if (!imu_steps_.empty() && !defer_device_) {
         int rc = mskf_ekf_propagate_imu(stream_, (int)imu_steps_.size(), imu_steps_.data());
         if (rc != MSKF_OK) fail("mskf_ekf_propagate_imu", rc);
     }
@@ -273,8 +276,9 @@ void MsckfVio::stateAugmentation(double time) {
     cs.orientation_null = cs.orientation;
     cs.position_null = cs.position;
 
-    double J[6 * 21];
-    std::memset(J, 0, sizeof(J));
+    double *J = J_;
+    have_J_ = true;
+    std::memset(J, 0, sizeof(J_));
     const hm::Mat3 sk = hm::skew(R_w_i.transpose() * t_c_i);
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) { J[i * 21 + j] = R_i_c(i, j); J[(3 + i) * 21 + j] = sk(i, j); }
@@ -282,8 +286,10 @@ void MsckfVio::stateAugmentation(double time) {
         J[(3 + i) * 21 + 12 + i] = 1.0;
         J[(3 + i) * 21 + 18 + i] = 1.0;
     }
-    int rc = mskf_ekf_augment(stream_, J);
-    if (rc != MSKF_OK) fail("mskf_ekf_augment", rc);
+    if (!defer_device_) {
+        int rc = mskf_ekf_augment(stream_, J);
+        if (rc != MSKF_OK) fail("mskf_ekf_augment", rc);
+    }
 }
 
 // :587-608
@@ -511,7 +517,8 @@ void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
     finishArgs(upd, 0, 0);   // Q12 dof = #involved, no row cap in the pruning path
 }
 
-void MsckfVio::phaseC() {
+void MsckfVio::phaseC(bool defer_device) {
+    pending_rm_[0] = pending_rm_[1] = -1;
     if (!frame_active_) return;
     if (prune_pending_) {
         // tail of pruneCamStateBuffer (:1100-1181)
@@ -524,11 +531,17 @@ void MsckfVio::phaseC() {
             for (const auto &cid : rm_cam_state_ids_) feature.observations.erase(cid);
         }
         if (!feats_.empty() && rows_out_ > 0) applyCorrection(delta_x_);
+        // indices of both clones in the state order BEFORE either is erased (:1161-1181 removes them one by one)
+        int k = 0;
         for (const auto &cid : rm_cam_state_ids_) {
-            const int seq = (int)std::distance(state_server.cam_states.begin(), state_server.cam_states.find(cid));
-            int rc = mskf_ekf_remove_clone(stream_, seq);
-            if (rc != MSKF_OK) fail("mskf_ekf_remove_clone", rc);
-            state_server.cam_states.erase(cid);
+            if (k < 2) pending_rm_[k++] = (int)std::distance(state_server.cam_states.begin(), state_server.cam_states.find(cid));
+        }
+        for (const auto &cid : rm_cam_state_ids_) state_server.cam_states.erase(cid);
+        if (!defer_device) {
+            mskf_stream *ss[1] = {stream_};
+            int rc = mskf_ekf_remove_clones_batch(mskf_stream_ctx(stream_), 1, ss, pending_rm_);
+            if (rc != MSKF_OK) fail("mskf_ekf_remove_clones_batch", rc);
+            pending_rm_[0] = pending_rm_[1] = -1;
         }
         prune_pending_ = false;
     }

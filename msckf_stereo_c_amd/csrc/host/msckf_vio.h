@@ -78,11 +78,17 @@ class MsckfVio {
     void attach(mskf_stream *s) { stream_ = s; }
     mskf_stream *stream() const { return stream_; }
     // phase A: IMU propagation, augmentation, observations; fills the lost-feature update (n_feat may be 0)
-    bool phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args &upd);
+    // defer_device: do not issue the propagation / augmentation here; the caller batches them from
+    // predictSteps() / predictJ() with mskf_ekf_predict_batch before running the update
+    bool phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args &upd, bool defer_device = false);
+    const std::vector<mskf_imu_step> &predictSteps() const { return imu_steps_; }
+    const double *predictJ() const { return have_J_ ? J_ : nullptr; }
     // phase B: apply the lost-feature update, then prepare the pruning update (n_feat may be 0)
     void phaseB(mskf_ekf_update_args &upd);
     // phase C: apply the pruning update, delete clones, publish; returns false if nothing ran this frame
-    void phaseC();
+    // defer_device: the caller removes the clones listed in pendingRemovals() with mskf_ekf_remove_clones_batch
+    void phaseC(bool defer_device = false);
+    const int32_t *pendingRemovals() const { return pending_rm_; }   // two clone indices (current state order) or -1
     // phase D: online reset decision from the position variances (msckf_vio.cpp:1186-1236)
     void phaseD(const double pos_var[3]);
     bool frameActive() const { return frame_active_; }
@@ -160,6 +166,9 @@ class MsckfVio {
     int32_t rows_out_ = 0;
     std::vector<StateIDType> rm_cam_state_ids_;
     bool prune_pending_ = false;
+    bool defer_device_ = false, have_J_ = false;
+    double J_[6 * 21];
+    int32_t pending_rm_[2] = {-1, -1};
     const CameraMeasurement *zero_tail_msg_ = nullptr;
     size_t zero_tail_start_ = 0;
     std::ofstream pose_outfile_;

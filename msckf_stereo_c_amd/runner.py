@@ -47,6 +47,7 @@ def lib():
         L.mskfh_get_imu_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mskfh_runner_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_runner_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mskfh_runner_get_phases.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mskfh_group_hip_stream.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_group_hip_stream.restype = C.c_void_p
         _LIB = L
@@ -123,6 +124,15 @@ class Runner:
         units = np.zeros(k, np.int64)
         self.L.mskfh_runner_get_timing(self.h, _p(ms), _p(launches), _p(units), int(reset))
         return {n: (float(ms[i]), int(launches[i]), int(units[i])) for i, n in enumerate(self.KERNELS)}
+
+    PHASES = ["push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "ekf_A", "update1", "ekf_B", "update2",
+              "ekf_C", "posvar", "imu_feed"]
+
+    def get_phases(self, reset=True):
+        """Wall seconds per BatchGroup::step phase, summed over groups (host bookkeeping vs device calls)."""
+        out = np.zeros(len(self.PHASES))
+        self.L.mskfh_runner_get_phases(self.h, _p(out), int(reset))
+        return {n: float(out[i]) for i, n in enumerate(self.PHASES)}
 
     def hip_stream(self, stream=0):
         return self.L.mskfh_group_hip_stream(self.h, stream)
