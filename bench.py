@@ -33,8 +33,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "64")), help="VIO streams per GPU")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "4")), help="host thread groups per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "256")), help="VIO streams per GPU")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "16")), help="host thread groups per GPU")
     ap.add_argument("--unique", type=int, default=4, help="distinct rendered sequences per GPU (streams cycle over them)")
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--height", type=int, default=480)
@@ -150,15 +150,8 @@ def main():
     phases = run.get_phases(reset=True)
     run.set_timing(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([n_streams * args.steps], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        frames_total = float(cnt.item())
-    else:
-        frames_total = float(n_streams * args.steps)
+    from msckf_stereo_c_amd.dist_util import aggregate_throughput
+    elapsed, frames_total = aggregate_throughput(elapsed, n_streams * args.steps, world, device="cuda")
 
     # sanity of the workload actually processed (steady state reached, filter alive)
     n_feat = len(run.dump(0)[0])

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
                 x[j] = (j < nb && ljj != 0.0) ? s2 / ljj : 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < LNB; ++j) { if (j < nb) row[j] = x[j]; sPan[(size_t)(i - r0) * LNB + j] = x[j]; }
+            for (int j = 0; j < LNB; ++j) { if (j < nb) row[j] = x[j]; sPan[(size_t)j * nt + (i - r0)] = x[j]; }
         }
         __syncthreads();
         // 3. trailing update (lower part; the extra row only against columns < n)
@@ -305,10 +305,9 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
         for (int e = tid; e < rem * remc; e += 1024) {
             const int a = e / remc, b = e - a * remc;
             if (b > a) continue;
-            const double *pa = sPan + (size_t)a * LNB, *pb = sPan + (size_t)b * LNB;
             double s2 = 0;
 #pragma unroll
-            for (int cc = 0; cc < LNB; ++cc) s2 += pa[cc] * pb[cc];
+            for (int cc = 0; cc < LNB; ++cc) s2 += sPan[(size_t)cc * nt + a] * sPan[(size_t)cc * nt + b];
             sM[(size_t)(r0 + a) * (r0 + a + 1) / 2 + r0 + b] -= s2;
         }
         __syncthreads();
@@ -335,7 +334,8 @@ __global__ __launch_bounds__(256) void k_ekf_rthin(const EkfStreamDev *streams) 
 }
 
 // ------------------------------------------------------------------------------------ TRSM
-// Y = L^-1 B in place, L = lower Cholesky factor in S.W (d x d), B = S.T (d x (d+1)); 32-column strips
+// Y = L^-1 B in place, L = lower Cholesky factor in S.W (d x d), B = S.T (d x (d+1)).  One workgroup per
+// 32-column strip; the strip (d x 32 doubles) stays in LDS for the whole solve, L is staged 16 rows at a time.
 #define TS_COLS 32
 #define TS_RB 16
 __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
@@ -347,10 +347,13 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     const double *L = S.W;
     double *B = S.T;
     extern __shared__ double s_dyn[];
-    double *sL = s_dyn;                        // [TS_RB][n] row block of L (columns < ib + TS_RB)
-    double *sX = s_dyn + (size_t)TS_RB * (n + 1);   // [TS_RB][TS_COLS]
+    double *sL = s_dyn;                              // [TS_RB][n + 1] row block of L
+    double *sY = s_dyn + (size_t)TS_RB * (n + 1);    // [n][TS_COLS] the strip
     const int tid = threadIdx.x, c = tid & 31, r8 = tid >> 5;
-    const bool col_ok = (c0 + c) < ncols;
+    for (int e = tid; e < n * TS_COLS; e += 256) {
+        const int i = e >> 5, cc = e & 31;
+        sY[e] = (c0 + cc < ncols) ? B[(size_t)i * ld + c0 + cc] : 0.0;
+    }
     for (int ib = 0; ib < n; ib += TS_RB) {
         const int nb = min(TS_RB, n - ib);
         __syncthreads();
@@ -359,35 +362,40 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
             sL[(size_t)i * (n + 1) + p] = L[(size_t)(ib + i) * ld + p];
         }
         __syncthreads();
-        // GEMM part: rows r8 and r8 + 8 of the block
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int i = r8 + 8 * h;
-            double s = 0.0;
-            if (i < nb && col_ok) {
-                s = B[(size_t)(ib + i) * ld + c0 + c];
-                const double *li = sL + (size_t)i * (n + 1);
-                for (int p = 0; p < ib; ++p) s -= li[p] * B[(size_t)p * ld + c0 + c];
+        // GEMM part: rows r8 and r8 + 8 of the block against all previous rows of the strip
+        double acc0 = 0.0, acc1 = 0.0;
+        {
+            const double *l0 = sL + (size_t)r8 * (n + 1), *l1 = sL + (size_t)(r8 + 8) * (n + 1);
+            for (int p = 0; p < ib; ++p) {
+                const double y = sY[p * TS_COLS + c];
+                acc0 += l0[p] * y;
+                acc1 += l1[p] * y;
             }
-            sX[i * TS_COLS + c] = s;
         }
+        if (r8 < nb) sY[(ib + r8) * TS_COLS + c] -= acc0;
+        if (r8 + 8 < nb) sY[(ib + r8 + 8) * TS_COLS + c] -= acc1;
         __syncthreads();
         // in-block forward substitution, one thread per column
-        if (tid < TS_COLS && (c0 + tid) < ncols) {
+        if (tid < TS_COLS) {
             double x[TS_RB];
 #pragma unroll
             for (int j = 0; j < TS_RB; ++j) {
                 x[j] = 0.0;
                 if (j < nb) {
-                    double s = sX[j * TS_COLS + tid];
+                    double s2 = sY[(ib + j) * TS_COLS + tid];
                     const double *lj = sL + (size_t)j * (n + 1) + ib;
 #pragma unroll
-                    for (int cc = 0; cc < j; ++cc) s -= lj[cc] * x[cc];
-                    x[j] = (lj[j] != 0.0) ? s / lj[j] : 0.0;
-                    B[(size_t)(ib + j) * ld + c0 + tid] = x[j];
+                    for (int cc = 0; cc < j; ++cc) s2 -= lj[cc] * x[cc];
+                    x[j] = (lj[j] != 0.0) ? s2 / lj[j] : 0.0;
+                    sY[(ib + j) * TS_COLS + tid] = x[j];
                 }
             }
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * TS_COLS; e += 256) {
+        const int i = e >> 5, cc = e & 31;
+        if (c0 + cc < ncols) B[(size_t)i * ld + c0 + cc] = sY[e];
     }
 }
 
@@ -427,7 +435,9 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
 void ekf_launch_rthin(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_rthin, dim3(1, n), dim3(256), 0, st, d); }
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
-    const size_t lds = (size_t)(TS_RB * (max_d + 1) + TS_RB * TS_COLS) * sizeof(double);
+    const size_t lds = (size_t)(TS_RB * (max_d + 1) + (size_t)max_d * TS_COLS) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_ekf_trsm, dim3(strips, n), dim3(256), lds, st, d);
 }
 void ekf_launch_dx(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_dx, dim3(1, n), dim3(256), 0, st, d); }

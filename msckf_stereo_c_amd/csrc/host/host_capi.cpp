@@ -16,6 +16,20 @@ void *mskfh_runner_create(int device, int n_groups, int per_group, const mskf_ca
     }
     return r;
 }
+// parse the three YAML files the reference reads (Q16 paths relative to config_dir); 0 on success
+int mskfh_load_configs(const char *config_dir, mskf_calib *calib, mskf_fe_cfg *fe, mskf_ekf_cfg *ekf) {
+    try {
+        const std::string d(config_dir);
+        *calib = calib_from_yaml(YAML::LoadFile(d + "/camchain-imucam-euroc.yaml"));
+        *fe = fe_cfg_from_yaml(YAML::LoadFile(d + "/app_imgproc.yaml"));
+        *ekf = ekf_cfg_from_yaml(YAML::LoadFile(d + "/app_msckfvio.yaml"));
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "mskfh_load_configs: %s\n", e.what());
+        return -1;
+    }
+}
+
 void mskfh_runner_destroy(void *h) { delete (MultiRunner *)h; }
 int mskfh_runner_num_streams(void *h) { return ((MultiRunner *)h)->n_streams(); }
 const char *mskfh_runner_error(void *h) { static thread_local std::string e; e = ((MultiRunner *)h)->error(); return e.c_str(); }

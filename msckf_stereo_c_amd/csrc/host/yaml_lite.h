@@ -65,30 +65,36 @@ inline std::vector<std::string> split_seq(const std::string &body) {
 }  // namespace detail
 
 inline Node Load(std::istream &in) {
+    // comment-stripped, non-empty lines
+    std::vector<std::string> lines;
+    {
+        std::string line;
+        while (std::getline(in, line)) {
+            size_t hash = line.find('#');
+            if (hash != std::string::npos) line = line.substr(0, hash);
+            if (!detail::trim(line).empty()) lines.push_back(line);
+        }
+    }
     Node root;
     root.child("__root__");  // mark defined
     struct Level { int indent; Node node; };
     std::vector<Level> stack;
     stack.push_back({-1, root});
-    std::string line;
-    while (std::getline(in, line)) {
-        size_t hash = line.find('#');
-        if (hash != std::string::npos) line = line.substr(0, hash);
-        if (detail::trim(line).empty()) continue;
+    for (size_t li = 0; li < lines.size(); ++li) {
+        const std::string &line = lines[li];
         int indent = (int)line.find_first_not_of(' ');
         std::string t = detail::trim(line);
         size_t colon = t.find(':');
         if (colon == std::string::npos) throw Exception("yaml: expected 'key: value' in '" + t + "'");
         std::string key = detail::trim(t.substr(0, colon));
         std::string val = detail::trim(t.substr(colon + 1));
+        // a flow sequence may start on the following line ("key:" newline "[ ... ]")
+        if (val.empty() && li + 1 < lines.size() && detail::trim(lines[li + 1])[0] == '[') val = detail::trim(lines[++li]);
         // gather a multi-line flow sequence
         if (!val.empty() && val[0] == '[') {
             while (val.find(']') == std::string::npos) {
-                std::string more;
-                if (!std::getline(in, more)) throw Exception("yaml: unterminated '[' for key " + key);
-                size_t h2 = more.find('#');
-                if (h2 != std::string::npos) more = more.substr(0, h2);
-                val += " " + detail::trim(more);
+                if (li + 1 >= lines.size()) throw Exception("yaml: unterminated '[' for key " + key);
+                val += " " + detail::trim(lines[++li]);
             }
         }
         while (stack.size() > 1 && stack.back().indent >= indent) stack.pop_back();
