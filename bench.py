@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "256")), help="VIO streams per GPU")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "16")), help="host thread groups per GPU")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "8")), help="host thread groups per GPU")
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("MSKF_BENCH_HOST_THREADS", "2")), help="host threads per group")
     ap.add_argument("--unique", type=int, default=4, help="distinct rendered sequences per GPU (streams cycle over them)")
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--height", type=int, default=480)
@@ -121,7 +122,7 @@ def main():
     d_frames = torch.from_numpy(frames).cuda(local_rank)      # resident in HBM before the timed region
     frame_bytes = args.width * args.height
     calib = syns[0].calib
-    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank)
+    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads)
     run.keep_trajectory(False)
     imus = [imu_array(s, (total_frames + 3) * 10 + 20) for s in syns]
     base = d_frames.data_ptr()
@@ -129,7 +130,7 @@ def main():
         u = s % args.unique
         cam0 = base + (u * 2 + 0) * n_keys * frame_bytes
         cam1 = base + (u * 2 + 1) * n_keys * frame_bytes
-        run.set_sequence(s, cam0, cam1, True, frame_bytes, 25, args.loop, 1403715273262142976, 50000000, imus[u])
+        run.set_sequence(s, cam0, cam1, 2, frame_bytes, 25, args.loop, 1403715273262142976, 50000000, imus[u])
 
     def barrier():
         torch.cuda.synchronize()
@@ -181,8 +182,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Single MI355X: %dx%d stereo, %d cam clones, grid %s (%d features/frame), 200 Hz IMU; "
-                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups)"
-                                   % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups),
+                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads)"
+                                   % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
                        "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1)},
             "roofline": roof, "kernels": kernels,

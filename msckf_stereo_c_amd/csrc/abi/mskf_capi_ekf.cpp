@@ -393,8 +393,9 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     if (rc != MSKF_OK) return rc;
     int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
-    struct Lay { size_t clones, feats, obs_clone, obs_z, total; size_t o_dx, o_gamma, o_rows, o_status, o_total; int m_total; };
+    struct Lay { size_t clones, feats, obs_clone, obs_z; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
     std::vector<Lay> lay(n);
+    size_t in_bytes = 0, out_bytes = 0;
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         mskf_ekf_update_args &a = args[i];
@@ -421,33 +422,43 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         }
         if (m_total > kMaxRows) { mskf_set_error("stacked Jacobian exceeds the row capacity"); return MSKF_ERR_CAPACITY; }
         L.m_total = m_total;
-        L.clones = 0;
+        L.clones = in_bytes;
         L.feats = align_up(L.clones + sizeof(mskf_clone_state) * (size_t)a.n_clones, 16);
         L.obs_clone = align_up(L.feats + sizeof(EkfFeatDev) * (size_t)a.n_feat, 16);
         L.obs_z = align_up(L.obs_clone + sizeof(int) * (size_t)a.n_obs, 16);
-        L.total = align_up(L.obs_z + sizeof(double) * 4 * (size_t)a.n_obs, 16);
-        L.o_dx = 0;
-        L.o_gamma = align_up(sizeof(double) * (size_t)E.ld, 16);
-        L.o_rows = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
+        in_bytes = align_up(L.obs_z + sizeof(double) * 4 * (size_t)a.n_obs, 64);
+        L.o_dx = out_bytes;
+        L.o_gamma = align_up(L.o_dx + sizeof(double) * (size_t)E.ld, 16);
+        L.o_pos = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
+        L.o_rows = align_up(L.o_pos + sizeof(double) * 3 * (size_t)a.n_feat, 16);
         L.o_status = L.o_rows + 16;
-        L.o_total = align_up(L.o_status + (size_t)a.n_feat, 16);
-        if (L.total > E.arena_bytes || L.o_total > E.out_bytes || m_total > E.max_rows) {
+        out_bytes = align_up(L.o_status + (size_t)a.n_feat, 64);
+        if (m_total > E.max_rows) {
             MSKF_HIPCHK(hipStreamSynchronize(st));
-            if ((rc = arena_ensure(&E.h_arena, &E.d_arena, &E.arena_bytes, L.total)) != MSKF_OK) return rc;
-            if ((rc = arena_ensure(&E.h_out, &E.d_out, &E.out_bytes, L.o_total)) != MSKF_OK) return rc;
-            if (m_total > E.max_rows) {
-                if (E.Hs) (void)hipFree(E.Hs);
-                if (E.rs) (void)hipFree(E.rs);
-                E.Hs = E.rs = nullptr;
-                const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
-                if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld)) != MSKF_OK) return rc;
-                if ((rc = dev_alloc(&E.rs, (size_t)cap)) != MSKF_OK) return rc;
-                E.max_rows = cap;
-            }
+            if (E.Hs) (void)hipFree(E.Hs);
+            if (E.rs) (void)hipFree(E.rs);
+            E.Hs = E.rs = nullptr;
+            const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
+            if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld)) != MSKF_OK) return rc;
+            if ((rc = dev_alloc(&E.rs, (size_t)cap)) != MSKF_OK) return rc;
+            E.max_rows = cap;
         }
-        // pack
-        if (a.n_clones) std::memcpy(E.h_arena + L.clones, a.clones, sizeof(mskf_clone_state) * (size_t)a.n_clones);
-        EkfFeatDev *fd = (EkfFeatDev *)(E.h_arena + L.feats);
+        max_feat = std::max(max_feat, a.n_feat);
+        max_m = std::max(max_m, m_total);
+        max_d = std::max(max_d, E.d);
+    }
+    if (in_bytes > ctx->upd_in.cap || out_bytes > ctx->upd_out.cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        if ((rc = ctx->upd_in.ensure(in_bytes)) != MSKF_OK) return rc;
+        if ((rc = ctx->upd_out.ensure(out_bytes)) != MSKF_OK) return rc;
+    }
+    char *hin = ctx->upd_in.h, *din = ctx->upd_in.d, *hout = ctx->upd_out.h, *dout = ctx->upd_out.d;
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        mskf_ekf_update_args &a = args[i];
+        const Lay &L = lay[i];
+        if (a.n_clones) std::memcpy(hin + L.clones, a.clones, sizeof(mskf_clone_state) * (size_t)a.n_clones);
+        EkfFeatDev *fd = (EkfFeatDev *)(hin + L.feats);
         int row = 0;
         for (int j = 0; j < a.n_feat; ++j) {
             const mskf_ekf_feature &f = a.features[j];
@@ -458,30 +469,27 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             row += 4 * f.n_obs - 3;
         }
         if (a.n_obs) {
-            std::memcpy(E.h_arena + L.obs_clone, a.obs_clone, sizeof(int) * (size_t)a.n_obs);
-            std::memcpy(E.h_arena + L.obs_z, a.obs_z, sizeof(double) * 4 * (size_t)a.n_obs);
+            std::memcpy(hin + L.obs_clone, a.obs_clone, sizeof(int) * (size_t)a.n_obs);
+            std::memcpy(hin + L.obs_z, a.obs_z, sizeof(double) * 4 * (size_t)a.n_obs);
         }
         EkfStreamDev &D = ctx->ekf_desc.h[i];
         base_desc(s, D);
         D.n_clones = a.n_clones; D.n_feat = a.n_feat; D.n_obs = a.n_obs;
         D.dof_offset = a.dof_offset; D.apply_row_cap = a.apply_row_cap;
-        D.m_total = m_total;
+        D.m_total = L.m_total;
         for (int k = 0; k < 3; ++k) D.gravity[k] = a.gravity[k];
-        D.clones = (const mskf_clone_state *)(E.d_arena + L.clones);
-        D.feats = (EkfFeatDev *)(E.d_arena + L.feats);
-        D.obs_clone = (const int *)(E.d_arena + L.obs_clone);
-        D.obs_z = (const double *)(E.d_arena + L.obs_z);
-        D.delta_x = (double *)(E.d_out + L.o_dx);
-        D.gamma = (double *)(E.d_out + L.o_gamma);
-        D.rows_out = (int *)(E.d_out + L.o_rows);
-        D.feat_status = (uint8_t *)(E.d_out + L.o_status);
-        if (L.total) MSKF_HIPCHK(hipMemcpyAsync(E.d_arena, E.h_arena, L.total, hipMemcpyHostToDevice, st));
-        MSKF_HIPCHK(hipMemsetAsync(E.d_out, 0, L.o_total, st));
-        max_feat = std::max(max_feat, a.n_feat);
-        max_m = std::max(max_m, m_total);
-        max_d = std::max(max_d, E.d);
+        D.clones = (const mskf_clone_state *)(din + L.clones);
+        D.feats = (EkfFeatDev *)(din + L.feats);
+        D.obs_clone = (const int *)(din + L.obs_clone);
+        D.obs_z = (const double *)(din + L.obs_z);
+        D.delta_x = (double *)(dout + L.o_dx);
+        D.gamma = (double *)(dout + L.o_gamma);
+        D.pos_out = (double *)(dout + L.o_pos);
+        D.rows_out = (int *)(dout + L.o_rows);
+        D.feat_status = (uint8_t *)(dout + L.o_status);
     }
     if (max_feat > 0) {
+        MSKF_HIPCHK(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
         ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, st);
@@ -520,18 +528,11 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
         mskf_t_end(ctx, ts, (long long)(4.0 * d3));
         (void)max_m;
-        (void)max_d;
         MSKF_HIPCHK(hipGetLastError());
+        MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        mskf_t_collect(ctx);
     }
-    for (int i = 0; i < n; ++i) {
-        EkfStreamState &E = streams[i]->ekf_state;
-        const Lay &L = lay[i];
-        if (!args[i].n_feat) continue;
-        MSKF_HIPCHK(hipMemcpyAsync(E.h_out, E.d_out, L.o_total, hipMemcpyDeviceToHost, st));
-        MSKF_HIPCHK(hipMemcpyAsync(E.h_arena + L.feats, E.d_arena + L.feats, sizeof(EkfFeatDev) * (size_t)args[i].n_feat, hipMemcpyDeviceToHost, st));
-    }
-    MSKF_HIPCHK(hipStreamSynchronize(st));
-    mskf_t_collect(ctx);
     for (int i = 0; i < n; ++i) {
         mskf_ekf_update_args &a = args[i];
         EkfStreamState &E = streams[i]->ekf_state;
@@ -542,13 +543,13 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             if (a.rows_out) *a.rows_out = 0;
             continue;
         }
-        std::memcpy(a.delta_x, E.h_out + L.o_dx, sizeof(double) * (size_t)d);
-        if (a.gamma) std::memcpy(a.gamma, E.h_out + L.o_gamma, sizeof(double) * (size_t)a.n_feat);
-        *a.rows_out = ((const int *)(E.h_out + L.o_rows))[0];
-        std::memcpy(a.feat_status, E.h_out + L.o_status, (size_t)a.n_feat);
-        const EkfFeatDev *fd = (const EkfFeatDev *)(E.h_arena + L.feats);
+        std::memcpy(a.delta_x, hout + L.o_dx, sizeof(double) * (size_t)d);
+        if (a.gamma) std::memcpy(a.gamma, hout + L.o_gamma, sizeof(double) * (size_t)a.n_feat);
+        *a.rows_out = ((const int *)(hout + L.o_rows))[0];
+        std::memcpy(a.feat_status, hout + L.o_status, (size_t)a.n_feat);
+        const double *po = (const double *)(hout + L.o_pos);
         for (int j = 0; j < a.n_feat; ++j)
-            for (int k = 0; k < 3; ++k) a.features[j].position[k] = fd[j].position[k];
+            for (int k = 0; k < 3; ++k) a.features[j].position[k] = po[3 * j + k];
     }
     return MSKF_OK;
 }

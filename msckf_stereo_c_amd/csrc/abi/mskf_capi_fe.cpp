@@ -34,7 +34,7 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     mskf_t_collect(c);
     for (auto &e : c->t_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (int i = 0; i < 3; ++i) c->desc[i].release();
-    c->cell_arena.release(); c->trk_in.release(); c->trk_out.release();
+    c->cell_arena.release(); c->trk_in.release(); c->trk_out.release(); c->upd_in.release(); c->upd_out.release();
     c->jobs.release();
     c->ekf_desc.release();
     c->pred_arena.release();
@@ -107,6 +107,7 @@ void fill_pyr(const mskf_stream *s, int idx, PyrDev &p) {
         p.w[l] = s->lw[l];
         p.h[l] = s->lh[l];
     }
+    if (s->lvl0[idx]) p.lvl[0] = s->lvl0[idx];
 }
 
 extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
@@ -216,9 +217,17 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         if (!s || s->ctx != ctx || !cam0[i] || !cam1[i]) return MSKF_ERR_INVALID;
-        const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr0], cam0[i], (size_t)s->w * s->h, kind, st));
-        MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr1], cam1[i], (size_t)s->w * s->h, kind, st));
+        if (on_device == 2) {
+            // borrowed device images: level 0 is read in place (caller keeps them valid and unchanged until the
+            // second-next push of this stream: the previous frame's cam0 is the LK template of the next frame)
+            s->lvl0[s->i_curr0] = cam0[i];
+            s->lvl0[s->i_curr1] = cam1[i];
+        } else {
+            const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            s->lvl0[s->i_curr0] = nullptr; s->lvl0[s->i_curr1] = nullptr;
+            MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr0], cam0[i], (size_t)s->w * s->h, kind, st));
+            MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr1], cam1[i], (size_t)s->w * s->h, kind, st));
+        }
         s->has_curr = true;
         max_cells = std::max(max_cells, s->fe.det_rows * s->fe.det_cols);
     }
@@ -229,8 +238,10 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
             mskf_stream *s = streams[i];
             for (int c = 0; c < 2; ++c) {
                 PyrJob &j = ctx->jobs.h[(size_t)(l - 1) * 2 * n + 2 * i + c];
-                uint8_t *base = s->pyr[c == 0 ? s->i_curr0 : s->i_curr1];
-                j.src = base + s->lvl_off[l - 1]; j.dst = base + s->lvl_off[l];
+                const int pi = c == 0 ? s->i_curr0 : s->i_curr1;
+                uint8_t *base = s->pyr[pi];
+                j.src = (l == 1 && s->lvl0[pi]) ? s->lvl0[pi] : base + s->lvl_off[l - 1];
+                j.dst = base + s->lvl_off[l];
                 j.sw = s->lw[l - 1]; j.sh = s->lh[l - 1]; j.dw = s->lw[l]; j.dh = s->lh[l];
             }
             max_dw[l] = std::max(max_dw[l], s->lw[l]); max_dh[l] = std::max(max_dh[l], s->lh[l]);
@@ -304,8 +315,7 @@ extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int cap
     if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(s->ctx->device));
     if (s->push_gen != s->ctx->push_gen) { mskf_set_error("cell maxima are stale: another push happened on this context"); return MSKF_ERR_INVALID; }
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    mskf_t_collect(s->ctx);
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));   // no ctx mutation here: callable concurrently for different streams
     std::memcpy(out, s->ctx->cell_arena.h + s->cell_off, sizeof(mskf_corner) * (size_t)n);
     *n_out = n;
     return MSKF_OK;
@@ -402,7 +412,8 @@ extern "C" int mskf_fe_get_level(mskf_stream *s, int role, int level, uint8_t *o
     if ((size_t)capacity < bytes) return MSKF_ERR_CAPACITY;
     MSKF_HIPCHK(hipSetDevice(s->ctx->device));
     MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    MSKF_HIPCHK(hipMemcpy(out, s->pyr[idx] + s->lvl_off[level], bytes, hipMemcpyDeviceToHost));
+    const uint8_t *src = (level == 0 && s->lvl0[idx]) ? s->lvl0[idx] : s->pyr[idx] + s->lvl_off[level];
+    MSKF_HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
     if (w) *w = s->lw[level];
     if (h) *h = s->lh[level];
     return MSKF_OK;

@@ -63,6 +63,7 @@ struct mskf_ctx {
     unsigned long long push_gen = 0;
     PinnedDev<PyrJob> jobs;
     PinnedDev<EkfStreamDev> ekf_desc;
+    PinnedDev<char> upd_in, upd_out;     // inputs / results of every stream of an update batch (one copy each way)
     PinnedDev<char> pred_arena;          // descriptors + IMU steps + J of mskf_ekf_predict_batch
     hipEvent_t pred_done = nullptr;
     bool pred_pending = false;
@@ -80,6 +81,7 @@ struct mskf_stream {
     size_t lvl_off[MSKF_LEVELS];
     size_t pyr_bytes = 0;
     uint8_t *pyr[3] = {nullptr, nullptr, nullptr};
+    const uint8_t *lvl0[3] = {nullptr, nullptr, nullptr};   // level 0 of each pyramid: own buffer or a borrowed device image
     int i_prev0 = 0, i_curr0 = 1, i_curr1 = 2;
     bool has_curr = false;
     int pt_cap = 0;

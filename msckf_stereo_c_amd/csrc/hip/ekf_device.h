@@ -41,6 +41,7 @@ struct EkfStreamDev {
     double *delta_x;          // d
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
+    double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
     int *rows_out;            // [0] stacked rows, [1] rows used by the update (after QR: min(m, d))
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)

@@ -11,6 +11,7 @@
 // All arithmetic is FP64.  The covariance P stays resident in HBM (ld x ld, row-major, exactly
 // symmetric by construction); one workgroup handles one VIO stream (or one feature of one
 // stream), blockIdx.y is the stream of the batch.
+#include <mutex>
 #include "ekf_device.h"
 
 #define WG 256
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
                 sPos[0] = pos[0]; sPos[1] = pos[1]; sPos[2] = pos[2];
                 sValid = valid ? 1 : 0;
                 F.position[0] = pos[0]; F.position[1] = pos[1]; F.position[2] = pos[2];
+                S.pos_out[3 * j] = pos[0]; S.pos_out[3 * j + 1] = pos[1]; S.pos_out[3 * j + 2] = pos[2];
             }
         }
         for (int c = tid; c < MAX_CLONES_DEV; c += WG) sObsOfClone[c] = -1;
@@ -698,12 +700,9 @@ void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
 }
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st) {
     const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GATE_LDS_ROWS * GATE_LDS_ROWS * (int)sizeof(double));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GATE_LDS_ROWS * GATE_LDS_ROWS * (int)sizeof(double)); });
     const int lds_rows = max_rows <= GATE_LDS_ROWS ? max_rows : GATE_LDS_ROWS;
     size_t lds = (size_t)lds_rows * lds_rows * sizeof(double);
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);

@@ -17,6 +17,7 @@
 // H^T r; forming them is one GEMM-shaped pass over the stacked Jacobian (MFMA-friendly, fully parallel
 // over output tiles) instead of d sequential reflector applications.  H^T H is rank deficient (the 21
 // IMU columns of H are zero, the gauge is unobservable): skipped pivots drop exactly those directions.
+#include <mutex>
 #include "ekf_device.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -419,12 +420,9 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
     const int nt = max_d - EKF_IMU_DIM + 1;
     if (nt <= CHOL_LDS_MAX_ROWS) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_LDS_MAX_ROWS * LNB) * sizeof(double)));
-            attr_set = true;
-        }
+        static std::once_flag attr_once;
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_LDS_MAX_ROWS * LNB) * sizeof(double))); });
         const size_t lds = ((size_t)nt * (nt + 1) / 2 + (size_t)nt * LNB) * sizeof(double);
         hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(1024), lds, st, d, which);
         return;
@@ -436,8 +434,8 @@ void ekf_launch_rthin(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchK
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
     const size_t lds = (size_t)(TS_RB * (max_d + 1) + (size_t)max_d * TS_COLS) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     hipLaunchKernelGGL(k_ekf_trsm, dim3(strips, n), dim3(256), lds, st, d);
 }
 void ekf_launch_dx(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_dx, dim3(1, n), dim3(256), 0, st, d); }

@@ -73,11 +73,11 @@ __device__ __forceinline__ long long isqrt64(long long v) {
 }
 
 #define DET_BORDER 8
-#define DET_MAX_CELL 96   // max cell edge staged in LDS per pass
 
-// One workgroup per detector cell.  The cell (+5 px halo) is staged in LDS; each thread scores its
-// pixels with the integer Shi-Tomasi measure and the block reduces to the (max score, first in
-// row-major order) corner.
+// One workgroup per detector cell.  The cell (+5 px halo) is staged in LDS in sub-tiles of <= 32x32 pixels;
+// gradient products are formed once per pixel, the 8x8 box sums are separable (8-wide horizontal pass,
+// then 8-tall vertical pass), and the block reduces to the (max score, first in row-major order) corner.
+#define DT 32
 __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams) {
     const FeStreamDev &S = streams[blockIdx.y];
     const int cell = blockIdx.x;
@@ -87,14 +87,16 @@ __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams
     const int cw = S.cell_w, ch = S.cell_h;
     const int cy = cell / S.det_cols, cx = cell - cy * S.det_cols;
     const int x0 = cx * cw, y0 = cy * ch;
-    __shared__ uint8_t tile[(32 + 10) * (32 + 10)];
+    __shared__ uint8_t tile[(DT + 10) * (DT + 10)];
+    __shared__ int sG[3][(DT + 8) * (DT + 8)];    // dx*dx, dx*dy, dy*dy at tile (r+1, c+1)
+    __shared__ int sH[3][(DT + 8) * DT];          // horizontal 8-sums
     __shared__ unsigned long long s_best[4];
     unsigned long long best = 0ULL;
-    // process the cell in sub-tiles of at most 32x32 so any cell size fits the LDS tile
-    for (int ty = 0; ty < ch; ty += 32)
-        for (int tx = 0; tx < cw; tx += 32) {
-            const int tw = min(32, cw - tx), th = min(32, ch - ty);
+    for (int ty = 0; ty < ch; ty += DT)
+        for (int tx = 0; tx < cw; tx += DT) {
+            const int tw = min(DT, cw - tx), th = min(DT, ch - ty);
             const int lw = tw + 10, lh = th + 10;
+            const int gw = tw + 8, gh = th + 8;
             const int gx0 = x0 + tx - 5, gy0 = y0 + ty - 5;
             __syncthreads();
             for (int i = threadIdx.x; i < lw * lh; i += 256) {
@@ -103,18 +105,30 @@ __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams
                 tile[i] = img[(size_t)gy * W + gx];
             }
             __syncthreads();
+            for (int i = threadIdx.x; i < gw * gh; i += 256) {
+                const int r = i / gw, c = i - r * gw;          // tile position (r+1, c+1)
+                const uint8_t *t = tile + (r + 1) * lw + (c + 1);
+                const int dx = (int)t[1] - (int)t[-1];
+                const int dy = (int)t[lw] - (int)t[-lw];
+                sG[0][i] = dx * dx; sG[1][i] = dx * dy; sG[2][i] = dy * dy;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < gh * tw; i += 256) {
+                const int r = i / tw, c = i - r * tw;
+                const int *g0 = sG[0] + r * gw + c, *g1 = sG[1] + r * gw + c, *g2 = sG[2] + r * gw + c;
+                int a = 0, b = 0, d = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a += g0[u]; b += g1[u]; d += g2[u]; }
+                sH[0][i] = a; sH[1][i] = b; sH[2][i] = d;
+            }
+            __syncthreads();
             for (int i = threadIdx.x; i < tw * th; i += 256) {
                 const int r = i / tw, c = i - r * tw;
                 const int x = x0 + tx + c, y = y0 + ty + r;
                 if (x < DET_BORDER || y < DET_BORDER || x >= W - DET_BORDER || y >= H - DET_BORDER) continue;
                 long long a = 0, b = 0, cc = 0;
-                // box rows y-4..y+3, cols x-4..x+3 ; tile origin is (x-5-c, y-5-r) -> local (c+5, r+5)
-                for (int v = r + 1; v < r + 9; ++v)
-                    for (int u = c + 1; u < c + 9; ++u) {
-                        const int dx = (int)tile[v * lw + u + 1] - (int)tile[v * lw + u - 1];
-                        const int dy = (int)tile[(v + 1) * lw + u] - (int)tile[(v - 1) * lw + u];
-                        a += dx * dx; b += dx * dy; cc += dy * dy;
-                    }
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { a += sH[0][(r + v) * tw + c]; b += sH[1][(r + v) * tw + c]; cc += sH[2][(r + v) * tw + c]; }
                 const long long disc = (a - cc) * (a - cc) + 4 * b * b;
                 const long long score = (a + cc) - isqrt64(disc);
                 if (score > 0) {

@@ -5,7 +5,41 @@
 
 namespace cg {
 
-BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf) {
+ForkJoin::ForkJoin(int n_threads) : nt_(n_threads) {
+    for (int i = 1; i < nt_; ++i) th_.emplace_back([this, i]() { worker(i); });
+}
+ForkJoin::~ForkJoin() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+}
+void ForkJoin::worker(int) {
+    unsigned long long seen = 0;
+    for (;;) {
+        const std::function<void(int)> *fn;
+        int n;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&]() { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            fn = fn_; n = n_;
+        }
+        for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*fn)(i);
+        done_.fetch_add(1);
+    }
+}
+void ForkJoin::run(int n, const std::function<void(int)> &fn) {
+    if (nt_ <= 1 || n <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    next_.store(0); done_.store(0);
+    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; n_ = n; ++gen_; }
+    cv_.notify_all();
+    for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) fn(i);
+    while (done_.load() < nt_ - 1) std::this_thread::yield();
+}
+
+BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads) {
+    if (host_threads > 1) pool_.reset(new ForkJoin(host_threads));
     int rc = mskf_ctx_create(device, &ctx_);
     if (rc != MSKF_OK) { error_ = mskf_last_error(); return; }
     for (int i = 0; i < n; ++i) {
@@ -49,19 +83,21 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
     }
     BR_CHK(mskf_fe_push_stereo_batch(ctx_, n, streams_.data(), cam0, cam1, on_device));
     lap(PH_PUSH);
-    for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phasePrepare1(a1_[i]);
+    if (systems_[0]->imgproc_ptr_->isFirstImage()) BR_CHK(mskf_ctx_sync(ctx_));   // first frame: detections are read right away
+    par(n, [&](int i) { systems_[i]->imgproc_ptr_->phasePrepare1(a1_[i]); });
     lap(PH_PREP1);
     BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a1_.data()));
     lap(PH_TRACK1);
-    for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phaseAfter1(a2_[i]);
+    BR_CHK(mskf_ctx_sync(ctx_));
+    par(n, [&](int i) { systems_[i]->imgproc_ptr_->phaseAfter1(a2_[i]); });
     lap(PH_AFTER1);
     BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a2_.data()));
     lap(PH_TRACK2);
-    for (int i = 0; i < n; ++i) {
+    par(n, [&](int i) {
         systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
         systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
         systems_[i]->msckfvio_ptr()->setZeroTailHint(systems_[i]->imgproc_ptr_->feature_msg_ptr_.get(), systems_[i]->imgproc_ptr_->zeroTailStart());
-    }
+    });
     lap(PH_AFTER2);
     // ---- back-end (System::backend_callback for every stream)
     std::vector<mskf_stream *> sub_s;
@@ -74,7 +110,8 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
         return mskf_ekf_update_batch(ctx_, (int)sub_s.size(), sub_s.data(), sub_a.data());
     };
     bool any = false;
-    for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->phaseA(systems_[i]->feature_msg(), u_[i], true);
+    par(n, [&](int i) { systems_[i]->msckfvio_ptr()->phaseA(systems_[i]->feature_msg(), u_[i], true); });
+    for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->frameActive();
     if (any) {
         std::vector<int32_t> ns(n);
         std::vector<const mskf_imu_step *> sp(n);
@@ -92,19 +129,19 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
     if (!any) return MSKF_OK;
     BR_CHK(run_updates());
     lap(PH_UPD1);
-    for (int i = 0; i < n; ++i) if (systems_[i]->msckfvio_ptr()->frameActive()) systems_[i]->msckfvio_ptr()->phaseB(u_[i]); else std::memset(&u_[i], 0, sizeof(u_[i]));
+    par(n, [&](int i) { if (systems_[i]->msckfvio_ptr()->frameActive()) systems_[i]->msckfvio_ptr()->phaseB(u_[i]); else std::memset(&u_[i], 0, sizeof(u_[i])); });
     lap(PH_EKF_B);
     BR_CHK(run_updates());
     lap(PH_UPD2);
     {
         std::vector<int32_t> rm(2 * (size_t)n, -1);
         bool any_rm = false;
-        for (int i = 0; i < n; ++i) {
+        par(n, [&](int i) {
             MsckfVio &v = *systems_[i]->msckfvio_ptr();
             v.phaseC(true);
             rm[2 * i] = v.pendingRemovals()[0]; rm[2 * i + 1] = v.pendingRemovals()[1];
-            any_rm |= rm[2 * i] >= 0;
-        }
+        });
+        for (int i = 0; i < n; ++i) any_rm |= rm[2 * i] >= 0;
         if (any_rm) BR_CHK(mskf_ekf_remove_clones_batch(ctx_, n, streams_.data(), rm.data()));
     }
     lap(PH_EKF_C);
@@ -149,9 +186,10 @@ int BatchGroup::run(int first, int n_frames) {
     return MSKF_OK;
 }
 
-MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf)
+MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
+                         int host_threads)
     : n_groups_(n_groups), per_group_(per_group) {
-    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf));
+    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads));
 }
 
 bool MultiRunner::ok() const {

@@ -4,7 +4,11 @@
 // A BatchGroup owns one mskf_ctx (one HIP stream); a MultiRunner runs several groups on their own host
 // threads so the host bookkeeping of one group overlaps the kernels of another.
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "system.h"
@@ -22,9 +26,29 @@ struct StreamSequence {   // a looping pre-rendered stereo sequence + IMU sample
     int imu_cursor = 0;
 };
 
+// Fork-join helper: the per-stream host phases of a group are independent, so they are split over a few
+// persistent worker threads (the calling thread takes a share too).
+class ForkJoin {
+  public:
+    explicit ForkJoin(int n_threads);
+    ~ForkJoin();
+    void run(int n, const std::function<void(int)> &fn);   // fn(i) for i in [0, n), returns when all are done
+  private:
+    void worker(int id);
+    int nt_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0;
+    unsigned long long gen_ = 0;
+    std::atomic<int> next_{0}, done_{0};
+    bool stop_ = false;
+};
+
 class BatchGroup {
   public:
-    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf);
+    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1);
     ~BatchGroup();
     bool ok() const { return ok_; }
     int size() const { return (int)systems_.size(); }
@@ -50,11 +74,14 @@ class BatchGroup {
     std::vector<mskf_ekf_update_args> u_;
     std::vector<const uint8_t *> p0_, p1_;
     std::vector<double> t_;
+    std::unique_ptr<ForkJoin> pool_;
+    void par(int n, const std::function<void(int)> &fn) { if (pool_) pool_->run(n, fn); else for (int i = 0; i < n; ++i) fn(i); }
 };
 
 class MultiRunner {
   public:
-    MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf);
+    MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
+                int host_threads = 1);
     bool ok() const;
     int n_streams() const { return n_groups_ * per_group_; }
     int n_groups() const { return n_groups_; }

@@ -7,8 +7,9 @@ using namespace cg;
 
 extern "C" {
 
-void *mskfh_runner_create(int device, int n_groups, int per_group, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf) {
-    MultiRunner *r = new MultiRunner(device, n_groups, per_group, *calib, *fe, *ekf);
+void *mskfh_runner_create(int device, int n_groups, int per_group, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
+                          int host_threads) {
+    MultiRunner *r = new MultiRunner(device, n_groups, per_group, *calib, *fe, *ekf, host_threads);
     if (!r->ok()) {
         std::fprintf(stderr, "mskfh_runner_create: %s\n", r->error().c_str());
         delete r;

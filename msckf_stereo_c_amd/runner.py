@@ -24,7 +24,7 @@ def lib():
             raise MskfError("libmskf_host.so is not built (run python -m msckf_stereo_c_amd.build); there is no CPU fallback")
         L = C.CDLL(p)
         L.mskfh_runner_create.restype = C.c_void_p
-        L.mskfh_runner_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Calib), C.POINTER(FeCfg), C.POINTER(EkfCfg)]
+        L.mskfh_runner_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Calib), C.POINTER(FeCfg), C.POINTER(EkfCfg), C.c_int]
         L.mskfh_runner_destroy.argtypes = [C.c_void_p]
         L.mskfh_runner_error.restype = C.c_char_p
         L.mskfh_runner_error.argtypes = [C.c_void_p]
@@ -61,12 +61,12 @@ def _p(a):
 class Runner:
     """n_groups x per_group independent VIO streams on one GPU."""
 
-    def __init__(self, calib, fe_cfg, ekf_cfg, n_groups=1, per_group=1, device=0):
+    def __init__(self, calib, fe_cfg, ekf_cfg, n_groups=1, per_group=1, device=0, host_threads=1):
         self.L = lib()
         self.calib, self.fe_cfg, self.ekf_cfg = calib, fe_cfg, ekf_cfg
         self.n = n_groups * per_group
         self.n_groups, self.per_group = n_groups, per_group
-        self.h = self.L.mskfh_runner_create(device, n_groups, per_group, C.byref(calib), C.byref(fe_cfg), C.byref(ekf_cfg))
+        self.h = self.L.mskfh_runner_create(device, n_groups, per_group, C.byref(calib), C.byref(fe_cfg), C.byref(ekf_cfg), host_threads)
         if not self.h:
             raise MskfError("could not create the runner (no GPU / HIP library?): see stderr")
         self._keep = []
