@@ -20,7 +20,7 @@ void ekf_launch_dx(const EkfStreamDev *d, int n, hipStream_t st);
 
 namespace {
 constexpr int kMaxClonesDev = 64;   // MAX_CLONES_DEV in ekf_kernels.hip
-constexpr int kMaxRows = 6000;      // LDS-resident Householder vector in k_ekf_qr
+constexpr int kMaxRows = 65536;     // stacked-Jacobian row capacity per stream and update
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -676,6 +676,11 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
         }
         s_cap_from = cap_from; s_stack = stack;
         S.rows_out[0] = stack;
+        // rows beyond the last stacked block are all zero: the Gram pass stops there
+        int m_eff = 0;
+        for (int j = 0; j < cap_from && j < S.n_feat; ++j)
+            if (S.feat_status[j] & 2) m_eff = S.feats[j].row_off + 4 * S.feats[j].n_obs - 3;
+        S.rows_out[1] = m_eff;
     }
     __syncthreads();
     for (int j = s_cap_from; j < S.n_feat; ++j) {

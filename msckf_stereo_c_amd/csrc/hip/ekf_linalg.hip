@@ -40,7 +40,7 @@ __device__ __forceinline__ bool gemm_setup(const EkfStreamDev &S, int mode, Gemm
     g.lda = g.ldb = g.ldc = ld;
     switch (mode) {
         case GM_GRAM:
-            g.A = S.Hs; g.B = S.Hs; g.C = S.S; g.M = g.N = d + 1; g.K = S.m_total; g.transA = 1; g.transB = 0; g.sym = 1;
+            g.A = S.Hs; g.B = S.Hs; g.C = S.S; g.M = g.N = d + 1; g.K = S.rows_out[1]; g.transA = 1; g.transB = 0; g.sym = 1;
             return true;
         case GM_T:
             g.A = S.S; g.B = S.P; g.C = S.T; g.M = d; g.N = d; g.K = d; g.transA = 1; g.transB = 0; g.kmin_i = 1;

@@ -188,3 +188,63 @@ def test_triangulation_matches_oracle(gpu_ctx, oracle):
     assert v.sum() >= 20
     assert np.allclose(got["positions"][v], pos_ref[v], rtol=1e-6, atol=1e-8)
     s.close()
+
+
+# ------------------------------------------------------------------ large-configuration code paths
+def test_detector_large_cells(gpu_ctx, oracle):
+    """Cells larger than the 32x32 LDS sub-tile (4K-like geometry: 2000/47 = 43, 1100/30 = 37 px)."""
+    w, h = 2000, 1100
+    rng = np.random.default_rng(4)
+    base = rng.integers(0, 256, (h // 8 + 1, w // 8 + 1), dtype=np.uint8)
+    img = np.kron(base, np.ones((8, 8), np.uint8))[:h, :w].copy()
+    img = (img.astype(np.int32) + rng.integers(-6, 7, img.shape)).clip(0, 255).astype(np.uint8)
+    s, _ = _stream(gpu_ctx, oracle, w, h)
+    s.push_stereo(img, img)
+    got, ref = s.cell_maxima(), oracle.cell_maxima(img)
+    for k in ("score", "x", "y"):
+        assert np.array_equal(got[k], ref[k]), k
+    for lvl in range(4):
+        assert np.array_equal(s.get_level(1, lvl), oracle.build_pyramid(img)[lvl])
+    s.close()
+
+
+@pytest.mark.parametrize("n_clones,n_feat,seed", [(50, 40, 21), (60, 30, 22)])
+def test_ekf_update_many_clones(gpu_ctx, oracle, n_clones, n_feat, seed):
+    """d = 321 / 381: global-memory Cholesky fallback, gating matrix outside LDS, > 1500 stacked rows (cap)."""
+    s, calib = _stream(gpu_ctx, oracle, 376, 240, max_cam_state_size=n_clones)
+    cfg = default_ekf_cfg(max_cam_state_size=n_clones)
+    pr = ekf_problems.make_problem(calib, seed=seed, n_clones=n_clones, n_feat=n_feat, min_obs=20)
+    ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"],
+                                    pr["obs_clone"], pr["obs_z"], -1)
+    s.ekf_set_cov(pr["P"])
+    got = s.ekf_update(pr["gravity"], pr["clones"], pr["positions"], pr["obs_start"], pr["obs_clone"], pr["obs_z"], -1, True)
+    ev = ref["gamma"] >= 0
+    assert ev.sum() < n_feat          # the 1500-row cap is hit (Q13)
+    assert np.allclose(got["gamma"][ev], ref["gamma"][ev], rtol=1e-7)
+    assert np.array_equal((got["status"] >> 1) & 1, ref["passed"])
+    assert got["rows"] == ref["rows"] > 1500
+    # the oracle getter reconstructs the rotational parts of delta_x from quaternion differences (O(|dtheta|^2) accurate)
+    assert np.allclose(got["delta_x"], ref["delta_x"], rtol=1e-5, atol=2e-8)
+    Pg = s.ekf_get_cov()
+    assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 1e-7
+    s.close()
+
+
+def test_track_capacity_and_errors(gpu_ctx, oracle):
+    """Boundary behaviour of the C-ABI: capacity errors are reported, not crashed on."""
+    s, calib = _stream(gpu_ctx, oracle, 376, 240)
+    with pytest.raises(capi.MskfError):
+        s.track(np.zeros((4, 2), np.float32), do_temporal=False)          # nothing pushed yet
+    img = np.zeros((240, 376), np.uint8)
+    s.push_stereo(img, img)
+    res = s.track(np.zeros((0, 2), np.float32), do_temporal=False)       # empty input is fine
+    assert len(res["status"]) == 0
+    with pytest.raises(capi.MskfError):
+        s.track(np.zeros((100000, 2), np.float32), do_temporal=False)    # exceeds the stream's point capacity
+    with pytest.raises(capi.MskfError):
+        s.push_stereo(np.zeros((100, 100), np.uint8), np.zeros((100, 100), np.uint8))   # wrong image size
+    bad = oracle.euroc_calib(376, 240)
+    bad.cam0_model = 1
+    with pytest.raises(capi.MskfError):
+        capi.Stream(gpu_ctx, bad, default_fe_cfg(), default_ekf_cfg())   # equidistant model: unsupported on device
+    s.close()
