@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "256")), help="VIO streams per GPU")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "8")), help="host thread groups per GPU")
-    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("MSKF_BENCH_HOST_THREADS", "2")), help="host threads per group")
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("MSKF_BENCH_HOST_THREADS", "1")), help="host threads per group")
+    ap.add_argument("--no-pipeline", action="store_true", help="run front-end and filter of a group in lockstep on one thread")
     ap.add_argument("--unique", type=int, default=4, help="distinct rendered sequences per GPU (streams cycle over them)")
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--height", type=int, default=480)
@@ -137,14 +138,15 @@ def main():
         if world > 1:
             dist.barrier()
 
-    run.run(0, args.prime)                       # untimed: gravity/bias init, clone window fills, steady state
-    run.run(args.prime, args.warmup)             # W untimed warmup steps
+    pipe = not args.no_pipeline
+    run.run(0, args.prime, pipelined=pipe)                       # untimed: gravity/bias init, clone window fills, steady state
+    run.run(args.prime, args.warmup, pipelined=pipe)             # W untimed warmup steps
     run.set_timing(True)
     run.get_timing(reset=True)
     run.get_phases(reset=True)
     barrier()
     t0 = time.perf_counter()
-    run.run(args.prime + args.warmup, args.steps)   # EXACTLY K timed steps
+    run.run(args.prime + args.warmup, args.steps, pipelined=pipe)   # EXACTLY K timed steps
     barrier()
     elapsed = time.perf_counter() - t0
     timing = run.get_timing(reset=True)
@@ -182,8 +184,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Single MI355X: %dx%d stereo, %d cam clones, grid %s (%d features/frame), 200 Hz IMU; "
-                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads)"
-                                   % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads),
+                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads%s)"
+                                   % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads,
+                                      ", FE|EKF pipelined" if pipe else ""),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
                        "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1)},
             "roofline": roof, "kernels": kernels,

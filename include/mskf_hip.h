@@ -61,6 +61,10 @@ int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg
                        mskf_stream **out);
 void mskf_stream_destroy(mskf_stream *s);
 mskf_ctx *mskf_stream_ctx(mskf_stream *s);
+/* Run the EKF half of a stream (all mskf_ekf_* calls) on another context of the same GPU, so a front-end
+ * thread and a filter thread can drive one VIO stream concurrently (they share no device buffers). */
+int mskf_stream_set_ekf_ctx(mskf_stream *s, mskf_ctx *ekf_ctx);
+mskf_ctx *mskf_stream_ekf_ctx(mskf_stream *s);
 
 /* ------------------------------------------------------------------ front-end
  * Replaces, inside cg::ImageProcessor::stereoCallback (image_processor.cpp:139-203):

@@ -11,6 +11,7 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
 void ekf_launch_rthin(const EkfStreamDev *d, int n, hipStream_t st);
@@ -123,7 +124,7 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
 static int small_begin(mskf_stream *s, EkfExtra *X, size_t bytes) {
     if (X->small_pending) { MSKF_HIPCHK(hipEventSynchronize(X->small_done)); X->small_pending = false; }
     if (bytes > X->small_cap) {
-        MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+        MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
         int rc = arena_ensure(&X->h_small, &X->d_small, &X->small_cap, bytes);
         if (rc != MSKF_OK) return rc;
     }
@@ -133,8 +134,8 @@ static int small_begin(mskf_stream *s, EkfExtra *X, size_t bytes) {
 extern "C" int mskf_ekf_reset(mskf_stream *s, const double *P0) {
     if (!s || !P0) return MSKF_ERR_INVALID;
     EkfStreamState &E = s->ekf_state;
-    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipSetDevice(s->ctx_ekf->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
     MSKF_HIPCHK(hipMemset(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld));
     MSKF_HIPCHK(hipMemcpy2D(E.P, sizeof(double) * E.ld, P0, sizeof(double) * EKF_IMU_DIM, sizeof(double) * EKF_IMU_DIM, EKF_IMU_DIM,
                             hipMemcpyHostToDevice));
@@ -146,8 +147,8 @@ extern "C" int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d) {
     if (!s || !P) return MSKF_ERR_INVALID;
     EkfStreamState &E = s->ekf_state;
     if (d < EKF_IMU_DIM || (d - EKF_IMU_DIM) % 6 || d > EKF_IMU_DIM + 6 * E.max_clones) return MSKF_ERR_CAPACITY;
-    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipSetDevice(s->ctx_ekf->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
     MSKF_HIPCHK(hipMemset(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld));
     MSKF_HIPCHK(hipMemcpy2D(E.P, sizeof(double) * E.ld, P, sizeof(double) * d, sizeof(double) * d, d, hipMemcpyHostToDevice));
     E.d = d;
@@ -164,8 +165,8 @@ extern "C" int mskf_ekf_get_cov(mskf_stream *s, double *P, int capacity) {
     if (!s || !P) return MSKF_ERR_INVALID;
     EkfStreamState &E = s->ekf_state;
     if (capacity < E.d * E.d) return MSKF_ERR_CAPACITY;
-    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    MSKF_HIPCHK(hipSetDevice(s->ctx_ekf->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
     MSKF_HIPCHK(hipMemcpy2D(P, sizeof(double) * E.d, E.P, sizeof(double) * E.ld, sizeof(double) * E.d, E.d, hipMemcpyDeviceToHost));
     return MSKF_OK;
 }
@@ -174,7 +175,7 @@ extern "C" int mskf_ekf_propagate(mskf_stream *s, int n_steps, const double *Phi
     if (!s || n_steps < 0 || (n_steps && (!Phi || !Q))) return MSKF_ERR_INVALID;
     if (n_steps == 0) return MSKF_OK;
     EkfExtra *X = extra_of(s);
-    mskf_ctx *ctx = s->ctx;
+    mskf_ctx *ctx = s->ctx_ekf;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     const size_t nn = EKF_IMU_DIM * EKF_IMU_DIM;
     const size_t bytes = sizeof(double) * 2 * nn * (size_t)n_steps + sizeof(EkfStreamDev);
@@ -201,7 +202,7 @@ extern "C" int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_im
     if (!s || n_steps < 0 || (n_steps && !steps)) return MSKF_ERR_INVALID;
     if (n_steps == 0) return MSKF_OK;
     EkfExtra *X = extra_of(s);
-    mskf_ctx *ctx = s->ctx;
+    mskf_ctx *ctx = s->ctx_ekf;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     const size_t bytes = sizeof(EkfStreamDev) + sizeof(mskf_imu_step) * (size_t)n_steps;
     int rc = small_begin(s, X, bytes);
@@ -230,7 +231,7 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     hipStream_t st = ctx->stream;
     size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
     for (int i = 0; i < n; ++i) {
-        if (!streams[i] || streams[i]->ctx != ctx || n_steps[i] < 0 || (n_steps[i] && !steps[i])) return MSKF_ERR_INVALID;
+        if (!streams[i] || streams[i]->ctx_ekf != ctx || n_steps[i] < 0 || (n_steps[i] && !steps[i])) return MSKF_ERR_INVALID;
         bytes += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64) + align_up(sizeof(double) * 6 * EKF_IMU_DIM, 64);
     }
     if (!ctx->pred_done) MSKF_HIPCHK(hipEventCreateWithFlags(&ctx->pred_done, hipEventDisableTiming));
@@ -280,23 +281,34 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
 extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out) {
     if (!ctx || n <= 0 || !streams || !out) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
-    for (int i = 0; i < n; ++i) {
-        mskf_stream *s = streams[i];
-        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
-        const EkfStreamState &E = s->ekf_state;
-        // 3 diagonal entries: a strided 2D copy (pitch ld+1 doubles)
-        MSKF_HIPCHK(hipMemcpy2DAsync(out + 3 * i, sizeof(double), E.P + (size_t)12 * E.ld + 12, sizeof(double) * (E.ld + 1),
-                                     sizeof(double), 3, hipMemcpyDeviceToHost, ctx->stream));
+    hipStream_t st = ctx->stream;
+    const size_t desc_bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
+    const size_t bytes = desc_bytes + sizeof(double) * 3 * (size_t)n;
+    if (!ctx->pred_done) MSKF_HIPCHK(hipEventCreateWithFlags(&ctx->pred_done, hipEventDisableTiming));
+    if (ctx->pred_pending) { MSKF_HIPCHK(hipEventSynchronize(ctx->pred_done)); ctx->pred_pending = false; }
+    if (bytes > ctx->pred_arena.cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        int rc = ctx->pred_arena.ensure(bytes);
+        if (rc != MSKF_OK) return rc;
     }
-    MSKF_HIPCHK(hipStreamSynchronize(ctx->stream));
+    EkfStreamDev *D = (EkfStreamDev *)ctx->pred_arena.h;
+    for (int i = 0; i < n; ++i) {
+        if (!streams[i] || streams[i]->ctx_ekf != ctx) return MSKF_ERR_INVALID;
+        base_desc(streams[i], D[i]);
+    }
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.d, ctx->pred_arena.h, desc_bytes, hipMemcpyHostToDevice, st));
+    ekf_launch_posvar((const EkfStreamDev *)ctx->pred_arena.d, n, (double *)(ctx->pred_arena.d + desc_bytes), st);
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.h + desc_bytes, ctx->pred_arena.d + desc_bytes, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+    MSKF_HIPCHK(hipStreamSynchronize(st));
     mskf_t_collect(ctx);
+    std::memcpy(out, ctx->pred_arena.h + desc_bytes, sizeof(double) * 3 * (size_t)n);
     return MSKF_OK;
 }
 
 extern "C" int mskf_ekf_get_pos_var(mskf_stream *s, double out[3]) {
     if (!s || !out) return MSKF_ERR_INVALID;
     mskf_stream *ss[1] = {s};
-    return mskf_ekf_get_pos_var_batch(s->ctx, 1, ss, out);
+    return mskf_ekf_get_pos_var_batch(s->ctx_ekf, 1, ss, out);
 }
 
 extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {
@@ -304,7 +316,7 @@ extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {
     EkfStreamState &E = s->ekf_state;
     if (E.d + 6 > EKF_IMU_DIM + 6 * E.max_clones) { mskf_set_error("clone capacity exceeded"); return MSKF_ERR_CAPACITY; }
     EkfExtra *X = extra_of(s);
-    mskf_ctx *ctx = s->ctx;
+    mskf_ctx *ctx = s->ctx_ekf;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     // the augment descriptor lives after a possible propagate descriptor: use a second region of the small arena
     const size_t off = 0;
@@ -344,7 +356,7 @@ extern "C" int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *c
     bool any = false;
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
-        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
+        if (!s || s->ctx_ekf != ctx) return MSKF_ERR_INVALID;
         EkfStreamState &E = s->ekf_state;
         EkfExtra *X = extra_of(s);
         const int nc = (E.d - EKF_IMU_DIM) / 6;
@@ -382,7 +394,7 @@ extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
     if (clone_index < 0 || clone_index >= nc) return MSKF_ERR_INVALID;
     mskf_stream *ss[1] = {s};
     const int32_t idx[2] = {clone_index, -1};
-    return mskf_ekf_remove_clones_batch(s->ctx, 1, ss, idx);
+    return mskf_ekf_remove_clones_batch(s->ctx_ekf, 1, ss, idx);
 }
 
 extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args) {
@@ -399,7 +411,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         mskf_ekf_update_args &a = args[i];
-        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
+        if (!s || s->ctx_ekf != ctx) return MSKF_ERR_INVALID;
         EkfStreamState &E = s->ekf_state;
         if (a.n_clones * 6 + EKF_IMU_DIM != E.d) { mskf_set_error("n_clones does not match the covariance dimension"); return MSKF_ERR_INVALID; }
         if (a.n_feat < 0 || a.n_obs < 0) return MSKF_ERR_INVALID;
@@ -557,5 +569,5 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
 extern "C" int mskf_ekf_update(mskf_stream *s, mskf_ekf_update_args *args) {
     if (!s || !args) return MSKF_ERR_INVALID;
     mskf_stream *ss[1] = {s};
-    return mskf_ekf_update_batch(s->ctx, 1, ss, args);
+    return mskf_ekf_update_batch(s->ctx_ekf, 1, ss, args);
 }

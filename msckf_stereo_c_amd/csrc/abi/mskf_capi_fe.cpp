@@ -122,6 +122,7 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     mskf_stream *s = new mskf_stream();
     s->ctx = ctx;
+    s->ctx_ekf = ctx;
     s->calib = *calib; s->fe = *fe; s->ekf = *ekf;
     s->w = calib->width; s->h = calib->height;
     size_t off = 0;
@@ -171,11 +172,21 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
 }
 
 extern "C" mskf_ctx *mskf_stream_ctx(mskf_stream *s) { return s ? s->ctx : nullptr; }
+extern "C" mskf_ctx *mskf_stream_ekf_ctx(mskf_stream *s) { return s ? s->ctx_ekf : nullptr; }
+extern "C" int mskf_stream_set_ekf_ctx(mskf_stream *s, mskf_ctx *c) {
+    if (!s || !c || c->device != s->ctx->device) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(c->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
+    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    s->ctx_ekf = c;
+    return MSKF_OK;
+}
 
 extern "C" void mskf_stream_destroy(mskf_stream *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->ctx_ekf && s->ctx_ekf != s->ctx) (void)hipStreamSynchronize(s->ctx_ekf->stream);
     for (int i = 0; i < 3; ++i) if (s->pyr[i]) (void)hipFree(s->pyr[i]);
     mskf_ekf_stream_free(s);
     auto &v = s->ctx->streams;

@@ -72,6 +72,7 @@ struct mskf_ctx {
 
 struct mskf_stream {
     mskf_ctx *ctx = nullptr;
+    mskf_ctx *ctx_ekf = nullptr;      // context the mskf_ekf_* calls run on (== ctx unless re-attached)
     mskf_calib calib;
     mskf_fe_cfg fe;
     mskf_ekf_cfg ekf;

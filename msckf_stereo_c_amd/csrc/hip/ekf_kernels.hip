@@ -238,6 +238,16 @@ __global__ __launch_bounds__(WG) void k_ekf_remove_clone(const EkfStreamDev *str
     }
 }
 
+// ------------------------------------------------------------------------------------ position variances
+// P(12,12), P(13,13), P(14,14) of every stream of the batch (onlineReset, msckf_vio.cpp:1194-1196)
+__global__ void k_ekf_posvar(const EkfStreamDev *streams, int n, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const EkfStreamDev &S = streams[i / 3];
+    const int k = 12 + i % 3;
+    out[i] = S.P[(size_t)k * S.ld + k];
+}
+
 // ------------------------------------------------------------------------------------ feature blocks
 #define MAX_CLONES_DEV 64          // 4*64 = 256 block rows max per feature
 
@@ -712,6 +722,9 @@ void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_row
     size_t lds = (size_t)lds_rows * lds_rows * sizeof(double);
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
     hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
+}
+void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_ekf_posvar, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n, out);
 }
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d); }
 }

@@ -2,6 +2,7 @@
 #include "batch_runner.h"
 #include <chrono>
 #include <cstring>
+#include <deque>
 
 namespace cg {
 
@@ -39,14 +40,17 @@ void ForkJoin::run(int n, const std::function<void(int)> &fn) {
 }
 
 BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads) {
-    if (host_threads > 1) pool_.reset(new ForkJoin(host_threads));
+    if (host_threads > 1) { pool_.reset(new ForkJoin(host_threads)); pool_ekf_.reset(new ForkJoin(host_threads)); }
     int rc = mskf_ctx_create(device, &ctx_);
+    if (rc == MSKF_OK) rc = mskf_ctx_create(device, &ctx_ekf_);
     if (rc != MSKF_OK) { error_ = mskf_last_error(); return; }
     for (int i = 0; i < n; ++i) {
         systems_.emplace_back(new System(calib, fe, ekf, ctx_, device));
         if (!systems_.back()->ok()) { error_ = std::string("stream setup failed: ") + mskf_last_error(); return; }
         systems_.back()->copy_draw_buffers = false;
         streams_.push_back(systems_.back()->stream());
+        // the filter half of every stream runs on its own context (own HIP stream): no device data is shared
+        if (mskf_stream_set_ekf_ctx(streams_.back(), ctx_ekf_) != MSKF_OK) { error_ = mskf_last_error(); return; }
     }
     a1_.resize(n); a2_.resize(n); u_.resize(n); p0_.resize(n); p1_.resize(n); t_.resize(n);
     seq.resize(n);
@@ -55,6 +59,7 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
 
 BatchGroup::~BatchGroup() {
     systems_.clear();
+    if (ctx_ekf_) mskf_ctx_destroy(ctx_ekf_);
     if (ctx_) mskf_ctx_destroy(ctx_);
 }
 
@@ -68,7 +73,7 @@ void BatchGroup::imu(int i, const mskf_imu_sample &s) {
 
 #define BR_CHK(expr) do { int _rc = (expr); if (_rc != MSKF_OK) { error_ = std::string(#expr) + ": " + mskf_last_error(); return _rc; } } while (0)
 
-int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw) {
+int BatchGroup::step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw) {
     const int n = size();
     if (!ok_ || n == 0) return MSKF_ERR_INVALID;
     auto tp = std::chrono::steady_clock::now();
@@ -96,10 +101,25 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
     par(n, [&](int i) {
         systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
         systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
-        systems_[i]->msckfvio_ptr()->setZeroTailHint(systems_[i]->imgproc_ptr_->feature_msg_ptr_.get(), systems_[i]->imgproc_ptr_->zeroTailStart());
     });
     lap(PH_AFTER2);
-    // ---- back-end (System::backend_callback for every stream)
+    return MSKF_OK;
+}
+
+int BatchGroup::step_ekf(const FrameBatch *fb) {
+    const int n = size();
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](int ph) { auto t = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t - tp).count(); tp = t; };
+    mskf_ctx *ctx_ = ctx_ekf_;   // every device call below belongs to the filter context
+    std::vector<std::shared_ptr<CameraMeasurement>> msgs(n);
+    for (int i = 0; i < n; ++i) {
+        MsckfVio &v = *systems_[i]->msckfvio_ptr();
+        if (fb) { msgs[i] = fb->msg[i]; v.setZeroTailHint(msgs[i].get(), fb->tail_start[i], fb->total[i]); }
+        else {
+            msgs[i] = systems_[i]->feature_msg();
+            v.setZeroTailHint(msgs[i].get(), systems_[i]->imgproc_ptr_->zeroTailStart());
+        }
+    }
     std::vector<mskf_stream *> sub_s;
     std::vector<mskf_ekf_update_args> sub_a;
     std::vector<int> sub_i;
@@ -110,7 +130,8 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
         return mskf_ekf_update_batch(ctx_, (int)sub_s.size(), sub_s.data(), sub_a.data());
     };
     bool any = false;
-    par(n, [&](int i) { systems_[i]->msckfvio_ptr()->phaseA(systems_[i]->feature_msg(), u_[i], true); });
+    auto par = [&](int cnt, const std::function<void(int)> &fn) { if (pool_ekf_) pool_ekf_->run(cnt, fn); else for (int i = 0; i < cnt; ++i) fn(i); };
+    par(n, [&](int i) { systems_[i]->msckfvio_ptr()->phaseA(msgs[i], u_[i], true); });
     for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->frameActive();
     if (any) {
         std::vector<int32_t> ns(n);
@@ -152,38 +173,116 @@ int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int
     return MSKF_OK;
 }
 
+int BatchGroup::step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw) {
+    int rc = step_fe(cam0, cam1, on_device, t, is_draw);
+    if (rc != MSKF_OK) return rc;
+    return step_ekf(nullptr);
+}
+
 static double ns_to_sec(long long ns) {   // apps/run_euroc_single_thread.cpp:164-166,192 (Q9)
     const long long sec = ns / 1000000000LL, nsec = ns % 1000000000LL;
     const double stamp_ns = (double)(int)sec * 1e9 + (double)(int)nsec;
     return stamp_ns * 1e-9;
 }
 
-int BatchGroup::run(int first, int n_frames) {
+// do { feed IMU } while (t_imu <= t_img)  (apps/run_euroc_single_thread.cpp:209-238, Q10) for frame k of every stream
+int BatchGroup::feed_imu(int k, bool to_fe, bool to_ekf) {
     const int n = size();
-    for (int k = first; k < first + n_frames; ++k) {
-        auto t_imu0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < n; ++i) {
-            StreamSequence &q = seq[i];
-            if (!q.cam0_base || !q.imu) { error_ = "no sequence attached"; return MSKF_ERR_INVALID; }
-            const double t_img = ns_to_sec(q.t0_ns + (long long)k * q.frame_dt_ns);
-            // do { feed IMU } while (t_imu <= t_img)  (apps/run_euroc_single_thread.cpp:209-238, Q10)
-            double t_imu = 0.0;
-            do {
-                if (q.imu_cursor >= q.n_imu) { error_ = "IMU sequence exhausted"; return MSKF_ERR_CAPACITY; }
-                const mskf_imu_sample &s = q.imu[q.imu_cursor++];
-                imu(i, s);
-                t_imu = s.time_stamp;
-            } while (t_imu <= t_img);
+    for (int i = 0; i < n; ++i) {
+        StreamSequence &q = seq[i];
+        if (!q.cam0_base || !q.imu) { error_ = "no sequence attached"; return MSKF_ERR_INVALID; }
+        const double t_img = ns_to_sec(q.t0_ns + (long long)k * q.frame_dt_ns);
+        int &cur = to_fe ? q.imu_cursor : q.imu_cursor_ekf;
+        double t_imu = 0.0;
+        do {
+            if (cur >= q.n_imu) { error_ = "IMU sequence exhausted"; return MSKF_ERR_CAPACITY; }
+            const mskf_imu_sample &s = q.imu[cur++];
+            std::shared_ptr<Imu> m(new Imu);
+            m->time_stamp = s.time_stamp;
+            m->angular_velocity = Vector3(s.angular_velocity[0], s.angular_velocity[1], s.angular_velocity[2]);
+            m->linear_acceleration = Vector3(s.linear_acceleration[0], s.linear_acceleration[1], s.linear_acceleration[2]);
+            if (to_fe) systems_[i]->imgproc_ptr_->imuCallback(m);      // System::imu_callback, system.cpp:45-48
+            if (to_ekf) systems_[i]->msckfvio_ptr()->imuCallback(m);
+            t_imu = s.time_stamp;
+        } while (t_imu <= t_img);
+        if (to_fe && to_ekf) q.imu_cursor_ekf = q.imu_cursor;
+        if (to_fe) {
             const int key = k < q.n_static ? k : q.n_static + (k - q.n_static) % q.n_loop;
             p0_[i] = q.cam0_base + (size_t)key * q.frame_bytes;
             p1_[i] = q.cam1_base + (size_t)key * q.frame_bytes;
             t_[i] = t_img;
         }
+    }
+    return MSKF_OK;
+}
+
+int BatchGroup::run(int first, int n_frames) {
+    for (int k = first; k < first + n_frames; ++k) {
+        auto t_imu0 = std::chrono::steady_clock::now();
+        int rc = feed_imu(k, true, true);
+        if (rc != MSKF_OK) return rc;
         phase_s[PH_IMU] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_imu0).count();
-        int rc = step(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
+        rc = step(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
         if (rc != MSKF_OK) return rc;
     }
     return MSKF_OK;
+}
+
+int BatchGroup::run_pipelined(int first, int n_frames) {
+    const int n = size();
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<FrameBatch>> queue;
+    bool producer_done = false;
+    std::atomic<int> ekf_rc{MSKF_OK};
+    std::string ekf_err;
+    std::thread consumer([&]() {
+        for (;;) {
+            std::unique_ptr<FrameBatch> fb;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return !queue.empty() || producer_done; });
+                if (queue.empty()) return;
+                fb = std::move(queue.front());
+                queue.pop_front();
+            }
+            cv.notify_all();
+            if (ekf_rc.load() != MSKF_OK) continue;   // drain
+            int rc = feed_imu(fb->frame, false, true);
+            if (rc == MSKF_OK) rc = step_ekf(fb.get());
+            if (rc != MSKF_OK) ekf_rc.store(rc);
+        }
+    });
+    int rc = MSKF_OK;
+    for (int k = first; k < first + n_frames && rc == MSKF_OK && ekf_rc.load() == MSKF_OK; ++k) {
+        rc = feed_imu(k, true, false);
+        if (rc == MSKF_OK) rc = step_fe(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
+        if (rc != MSKF_OK) break;
+        std::unique_ptr<FrameBatch> fb(new FrameBatch);
+        fb->frame = k;
+        fb->msg.resize(n); fb->tail_start.resize(n); fb->total.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const ImageProcessor &ip = *systems_[i]->imgproc_ptr_;
+            const CameraMeasurement &live = *ip.feature_msg_ptr_;
+            const size_t total = live.features.size(), start = ip.zeroTailStart();
+            const size_t keep = std::min(total, start + 1);
+            fb->msg[i].reset(new CameraMeasurement);
+            fb->msg[i]->time_stamp = live.time_stamp;
+            fb->msg[i]->features.assign(live.features.begin(), live.features.begin() + keep);
+            fb->tail_start[i] = start; fb->total[i] = total;
+        }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return queue.size() < 2; });
+            queue.push_back(std::move(fb));
+        }
+        cv.notify_all();
+    }
+    { std::lock_guard<std::mutex> lk(mu); producer_done = true; }
+    cv.notify_all();
+    consumer.join();
+    if (rc == MSKF_OK) rc = ekf_rc.load();
+    return rc;
 }
 
 MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
@@ -210,14 +309,15 @@ int MultiRunner::step(const uint8_t *const *cam0, const uint8_t *const *cam1, in
     return MSKF_OK;
 }
 
-int MultiRunner::run(int first, int n, bool threaded) {
+int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
     std::vector<int> rcs(n_groups_, MSKF_OK);
+    auto one = [&](int g) { return pipelined ? groups_[g]->run_pipelined(first, n) : groups_[g]->run(first, n); };
     if (!threaded || n_groups_ == 1) {
-        for (int g = 0; g < n_groups_; ++g) { rcs[g] = groups_[g]->run(first, n); if (rcs[g] != MSKF_OK) return rcs[g]; }
+        for (int g = 0; g < n_groups_; ++g) { rcs[g] = one(g); if (rcs[g] != MSKF_OK) return rcs[g]; }
         return MSKF_OK;
     }
     std::vector<std::thread> th;
-    for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = groups_[g]->run(first, n); });
+    for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = one(g); });
     for (auto &t : th) t.join();
     for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
     return MSKF_OK;

@@ -23,7 +23,14 @@ struct StreamSequence {   // a looping pre-rendered stereo sequence + IMU sample
     long long t0_ns = 0, frame_dt_ns = 50000000LL;
     const mskf_imu_sample *imu = nullptr;   // sample j, j in [0, n_imu)
     int n_imu = 0;
-    int imu_cursor = 0;
+    int imu_cursor = 0;       // next sample for the front-end (and for the filter in lockstep mode)
+    int imu_cursor_ekf = 0;   // next sample for the filter stage of the pipeline
+};
+
+struct FrameBatch {           // what the front-end stage hands to the filter stage: one frame of every stream
+    int frame = 0;
+    std::vector<std::shared_ptr<CameraMeasurement>> msg;   // snapshot: live + stale entries + first tail record
+    std::vector<size_t> tail_start, total;
 };
 
 // Fork-join helper: the per-stream host phases of a group are independent, so they are split over a few
@@ -58,6 +65,10 @@ class BatchGroup {
     int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw);
     // frames [first, first+n) of the attached sequences, IMU fed in the reference harness order (Q10)
     int run(int first, int n);
+    // same frames as a two-stage pipeline: a front-end thread (context ctx()) and a filter thread (context
+    // ekf_ctx()); the front-end never reads filter state, so the results are identical to run()
+    int run_pipelined(int first, int n);
+    mskf_ctx *ekf_ctx() const { return ctx_ekf_; }
     std::vector<StreamSequence> seq;
     mskf_ctx *ctx() const { return ctx_; }
     const std::string &error() const { return error_; }
@@ -65,7 +76,10 @@ class BatchGroup {
     double phase_s[PH_COUNT] = {0};   // wall seconds per phase of step() (host bookkeeping vs device calls)
 
   private:
-    mskf_ctx *ctx_ = nullptr;
+    int step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw);
+    int step_ekf(const FrameBatch *fb);
+    int feed_imu(int k, bool to_fe, bool to_ekf);
+    mskf_ctx *ctx_ = nullptr, *ctx_ekf_ = nullptr;
     bool ok_ = false;
     std::string error_;
     std::vector<std::unique_ptr<System>> systems_;
@@ -74,7 +88,7 @@ class BatchGroup {
     std::vector<mskf_ekf_update_args> u_;
     std::vector<const uint8_t *> p0_, p1_;
     std::vector<double> t_;
-    std::unique_ptr<ForkJoin> pool_;
+    std::unique_ptr<ForkJoin> pool_, pool_ekf_;
     void par(int n, const std::function<void(int)> &fn) { if (pool_) pool_->run(n, fn); else for (int i = 0; i < n; ++i) fn(i); }
 };
 
@@ -91,7 +105,7 @@ class MultiRunner {
     StreamSequence &sequence(int stream) { int l; BatchGroup &g = group_of(stream, l); return g.seq[l]; }
     void imu(int stream, const mskf_imu_sample &s) { int l; BatchGroup &g = group_of(stream, l); g.imu(l, s); }
     int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t);
-    int run(int first, int n, bool threaded);
+    int run(int first, int n, bool threaded, bool pipelined = false);
     std::string error() const;
 
   private:

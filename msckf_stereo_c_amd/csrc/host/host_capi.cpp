@@ -46,7 +46,8 @@ void mskfh_runner_set_sequence(void *h, int stream, const uint8_t *cam0_base, co
     q.n_static = n_static; q.n_loop = n_loop; q.t0_ns = t0_ns; q.frame_dt_ns = frame_dt_ns; q.imu = imu; q.n_imu = n_imu;
     q.imu_cursor = 0;
 }
-int mskfh_runner_run(void *h, int first, int n, int threaded) { return ((MultiRunner *)h)->run(first, n, threaded != 0); }
+// threaded: one host thread per group; pipelined: front-end and filter of each group run as a two-stage pipeline
+int mskfh_runner_run(void *h, int first, int n, int threaded, int pipelined) { return ((MultiRunner *)h)->run(first, n, threaded != 0, pipelined != 0); }
 void mskfh_runner_keep_trajectory(void *h, int keep) {
     MultiRunner *r = (MultiRunner *)h;
     for (int i = 0; i < r->n_streams(); ++i) r->system(i).msckfvio_ptr()->keepTrajectory = keep != 0;
@@ -54,16 +55,19 @@ void mskfh_runner_keep_trajectory(void *h, int keep) {
 
 void mskfh_runner_set_timing(void *h, int enable) {
     MultiRunner *r = (MultiRunner *)h;
-    for (int g = 0; g < r->n_groups(); ++g) mskf_ctx_set_timing(r->group(g).ctx(), enable);
+    for (int g = 0; g < r->n_groups(); ++g) { mskf_ctx_set_timing(r->group(g).ctx(), enable); mskf_ctx_set_timing(r->group(g).ekf_ctx(), enable); }
 }
 // sums over groups; arrays of MSKF_K_COUNT
 void mskfh_runner_get_timing(void *h, double *ms, long long *launches, long long *units, int reset) {
     MultiRunner *r = (MultiRunner *)h;
     for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] = 0; launches[k] = 0; units[k] = 0; }
     for (int g = 0; g < r->n_groups(); ++g) {
-        double m[MSKF_K_COUNT]; long long l[MSKF_K_COUNT], u[MSKF_K_COUNT];
-        if (mskf_ctx_get_timing(r->group(g).ctx(), m, l, u, reset) != MSKF_OK) continue;
-        for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] += m[k]; launches[k] += l[k]; units[k] += u[k]; }
+        mskf_ctx *cs[2] = {r->group(g).ctx(), r->group(g).ekf_ctx()};
+        for (mskf_ctx *c : cs) {
+            double m[MSKF_K_COUNT]; long long l[MSKF_K_COUNT], u[MSKF_K_COUNT];
+            if (mskf_ctx_get_timing(c, m, l, u, reset) != MSKF_OK) continue;
+            for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] += m[k]; launches[k] += l[k]; units[k] += u[k]; }
+        }
     }
 }
 

@@ -303,7 +303,11 @@ void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
     const int curr_feature_num = (int)map_server.size();
     long long tracked = 0;
     size_t n_full = msg->features.size();
-    if (zero_tail_msg_ == msg.get() && zero_tail_start_ < n_full) n_full = zero_tail_start_ + 1;
+    size_t total = n_full;
+    if (zero_tail_msg_ == msg.get()) {
+        if (zero_tail_total_ > total) total = zero_tail_total_;          // truncated snapshot of a longer message
+        if (zero_tail_start_ < total) n_full = std::min(n_full, zero_tail_start_ + 1);
+    }
     for (size_t k = 0; k < n_full; ++k) {
         const FeatureMeasurement &f = msg->features[k];
         const FeatureIDType fid = (FeatureIDType)f.id;
@@ -317,7 +321,7 @@ void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
             ++tracked;
         }
     }
-    tracked += (long long)(msg->features.size() - n_full);
+    tracked += (long long)(total - n_full);
     tracking_rate = static_cast<double>(tracked) / static_cast<double>(curr_feature_num);   // Q18: 0/0 = NaN on the first frame
 }
 
@@ -539,7 +543,7 @@ void MsckfVio::phaseC(bool defer_device) {
         for (const auto &cid : rm_cam_state_ids_) state_server.cam_states.erase(cid);
         if (!defer_device) {
             mskf_stream *ss[1] = {stream_};
-            int rc = mskf_ekf_remove_clones_batch(mskf_stream_ctx(stream_), 1, ss, pending_rm_);
+            int rc = mskf_ekf_remove_clones_batch(mskf_stream_ekf_ctx(stream_), 1, ss, pending_rm_);
             if (rc != MSKF_OK) fail("mskf_ekf_remove_clones_batch", rc);
             pending_rm_[0] = pending_rm_[1] = -1;
         }

@@ -93,7 +93,10 @@ class MsckfVio {
     void phaseD(const double pos_var[3]);
     bool frameActive() const { return frame_active_; }
     // optional: records [start, size) of `msg` are untouched value-initialised records (Q1 tail)
-    void setZeroTailHint(const CameraMeasurement *msg, size_t start) { zero_tail_msg_ = msg; zero_tail_start_ = start; }
+    // total_size > msg->features.size(): `msg` is a snapshot truncated inside the zero tail of a longer message
+    void setZeroTailHint(const CameraMeasurement *msg, size_t start, size_t total_size = 0) {
+        zero_tail_msg_ = msg; zero_tail_start_ = start; zero_tail_total_ = total_size;
+    }
 
     const std::vector<mskf_pose> &poses() const { return poses_; }
     const IMUState &imuState() const { return state_server.imu_state; }
@@ -170,7 +173,7 @@ class MsckfVio {
     double J_[6 * 21];
     int32_t pending_rm_[2] = {-1, -1};
     const CameraMeasurement *zero_tail_msg_ = nullptr;
-    size_t zero_tail_start_ = 0;
+    size_t zero_tail_start_ = 0, zero_tail_total_ = 0;
     std::ofstream pose_outfile_;
 };
 

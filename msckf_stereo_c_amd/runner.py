@@ -32,7 +32,7 @@ def lib():
         L.mskfh_runner_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mskfh_runner_set_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                                 C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
-        L.mskfh_runner_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mskfh_runner_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mskfh_runner_keep_trajectory.argtypes = [C.c_void_p, C.c_int]
         for name in ("mskfh_num_features", "mskfh_msg_size", "mskfh_num_poses", "mskfh_state_dim", "mskfh_num_updates",
                      "mskfh_num_clones"):
@@ -104,8 +104,10 @@ class Runner:
         self.L.mskfh_runner_set_sequence(self.h, stream, cam0_base_ptr, cam1_base_ptr, int(on_device), frame_bytes, n_static, n_loop,
                                          t0_ns, frame_dt_ns, _p(imu), len(imu))
 
-    def run(self, first, n, threaded=True):
-        self._chk(self.L.mskfh_runner_run(self.h, first, n, int(threaded)))
+    def run(self, first, n, threaded=True, pipelined=False):
+        """Frames [first, first+n) of the attached sequences.  pipelined: front-end and filter of every group run
+        as a two-stage pipeline on two HIP streams (identical results: the front-end never reads filter state)."""
+        self._chk(self.L.mskfh_runner_run(self.h, first, n, int(threaded), int(pipelined)))
 
     def keep_trajectory(self, keep):
         self.L.mskfh_runner_keep_trajectory(self.h, int(keep))

@@ -127,3 +127,52 @@ def test_batched_streams_match_their_oracles(oracle):
         compare_poses(osys[i], run, i)
         assert osys[i].num_updates() == run.num_updates(i) > 0
     run.close()
+
+
+def _attach_sequences(oracle, run, syns, n_frames, keep):
+    from msckf_stereo_c_amd.runner import IMU_SAMPLE
+    for i, syn in enumerate(syns):
+        n_keys = syn.n_static + syn.n_loop
+        frames = np.empty((2, n_keys, syn.h, syn.w), np.uint8)
+        for k in range(min(n_keys, n_frames + 1)):
+            a, b = syn.render(k)
+            frames[0, k], frames[1, k] = a, b
+        imu = np.zeros((n_frames + 3) * 10 + 20, IMU_SAMPLE)
+        for j in range(len(imu)):
+            s = syn.imu(j)
+            imu[j] = (s.time_stamp, tuple(s.angular_velocity), tuple(s.linear_acceleration))
+        keep.append(frames)
+        fb = syn.w * syn.h
+        run.set_sequence(i, frames.ctypes.data, frames.ctypes.data + n_keys * fb, 0, fb, syn.n_static, syn.n_loop,
+                         1403715273262142976, 50000000, imu)
+
+
+def test_pipelined_run_is_identical_to_lockstep(oracle):
+    """BatchGroup::run_pipelined (front-end thread | filter thread, two HIP streams) == lockstep run == oracle."""
+    w, h, n_frames = 376, 240, 70
+    fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
+    syns = [oracle.Synth(seed=0x5EED0020 + i, width=w, height=h) for i in range(2)]
+    keep = []
+    runs = []
+    for pipelined in (False, True):
+        run = R.Runner(syns[0].calib, fe, ekf, 1, 2, host_threads=1)
+        _attach_sequences(oracle, run, syns, n_frames, keep)
+        run.run(0, n_frames, threaded=True, pipelined=pipelined)
+        runs.append(run)
+    a, b = runs
+    for i in range(2):
+        for x, y in zip(a.dump(i)[:4], b.dump(i)[:4]):
+            assert np.array_equal(x, y)
+        pa, pb = a.poses(i), b.poses(i)
+        assert len(pa) == len(pb) > 20
+        assert np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])     # bitwise: same arithmetic, same order
+        assert np.array_equal(a.cov(i), b.cov(i))
+        assert a.num_updates(i) == b.num_updates(i) > 0
+        # and both equal the oracle fed in the reference harness order
+        osys = oracle.OracleSystem(syns[i].calib, fe, ekf)
+        syns[i].feed(osys, n_frames)
+        assert np.array_equal(osys.dump()[0], b.dump(i)[0])
+        op = osys.poses()
+        assert np.abs(op["p"] - pb["p"]).max() < POS_TOL
+    for r in runs:
+        r.close()
