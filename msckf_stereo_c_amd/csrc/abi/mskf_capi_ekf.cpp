@@ -518,9 +518,6 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
         ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
         mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
-        ekf_launch_rthin(ctx->ekf_desc.d, n, st);
-        mskf_t_end(ctx, ts, n);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
         mskf_t_end(ctx, ts, (long long)(2.0 * d3));
@@ -533,9 +530,6 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
         ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
         mskf_t_end(ctx, ts, (long long)(2.0 * d3));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
-        ekf_launch_dx(ctx->ekf_desc.d, n, st);
-        mskf_t_end(ctx, ts, n);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
         mskf_t_end(ctx, ts, (long long)(4.0 * d3));

@@ -623,9 +623,11 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
             }
             __syncthreads();
         }
-        // S = Mm[3:,3:] + sigma^2 I ; in-place Cholesky (lower) on the sub-matrix view, forward solve, gamma
+        // S = Mm[3:,3:] + sigma^2 I ; in-place right-looking Cholesky (lower) on the sub-matrix view.  The residual
+        // r_o rides along as an extra row (sW): after step k it holds y_k = (L^-1 r_o)_k, so gamma = y . y
+        // needs no separate triangular solve.
         double *Sg = Mm + (size_t)3 * rows + 3;    // row stride `rows`
-        for (int i = tid; i < n; i += WG) Sg[(size_t)i * rows + i] += S.sigma2;
+        for (int i = tid; i < n; i += WG) { Sg[(size_t)i * rows + i] += S.sigma2; sW[i] = r0[i]; }
         __syncthreads();
         bool pd_ok = true;
         for (int k = 0; k < n; ++k) {
@@ -634,29 +636,19 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
             const double inv = 1.0 / sqrt(dk);
             __syncthreads();
             for (int i = k + tid; i < n; i += WG) Sg[(size_t)i * rows + k] *= inv;   // column k: l_kk = sqrt(dk), l_ik = a_ik / l_kk
+            if (tid == 0) sW[k] *= inv;                                               // y_k
             __syncthreads();
             const int rem = n - k - 1;
+            const double yk = sW[k];
             for (int idx = tid; idx < rem * rem; idx += WG) {
                 const int a = idx / rem + k + 1, b = idx % rem + k + 1;
                 if (b <= a) Sg[(size_t)a * rows + b] -= Sg[(size_t)a * rows + k] * Sg[(size_t)b * rows + k];
             }
             __syncthreads();
+            for (int i = k + 1 + tid; i < n; i += WG) sW[i] -= Sg[(size_t)i * rows + k] * yk;
         }
         double gamma = 1e300;
         if (pd_ok) {
-            // forward solve L y = r_o (y in sW), one wave; gamma = y . y
-            for (int i = tid; i < n; i += WG) sW[i] = r0[i];
-            __syncthreads();
-            if (tid < 64) {
-                for (int i = 0; i < n; ++i) {
-                    double part = 0;
-                    for (int p = tid; p < i; p += 64) part += Sg[(size_t)i * rows + p] * sW[p];
-                    part = wave_sum(part);
-                    if (tid == 0) sW[i] = (sW[i] - part) / Sg[(size_t)i * rows + i];
-                    __builtin_amdgcn_wave_barrier();
-                    __threadfence_block();
-                }
-            }
             __syncthreads();
             double pg = 0;
             for (int i = tid; i < n; i += WG) pg += sW[i] * sW[i];
@@ -677,25 +669,36 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
 // msckf_vio.cpp:1002-1010: stack passing blocks in feature order, stop once rows > cap
 __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    __shared__ int s_cap_from, s_stack;
-    if (threadIdx.x == 0) {
-        int stack = 0, cap_from = S.n_feat;
-        for (int j = 0; j < S.n_feat; ++j) {
-            if (S.feat_status[j] & 2) stack += 4 * S.feats[j].n_obs - 3;
-            if (S.apply_row_cap && stack > S.max_stack_rows) { cap_from = j + 1; break; }
+    __shared__ int s_cap_from;
+    __shared__ int s_rows[1024];
+    __shared__ unsigned char s_st[1024];
+    const int nf = S.n_feat;
+    if (nf <= 0) return;
+    // the scan is sequential by definition (stack until rows > cap); stage what it reads in LDS first
+    for (int base = 0; base < nf; base += 1024) {
+        const int cnt = min(1024, nf - base);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += WG) { s_st[j] = S.feat_status[base + j]; s_rows[j] = 4 * S.feats[base + j].n_obs - 3; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int stack = base == 0 ? 0 : S.rows_out[0];
+            int cap_from = base == 0 ? nf : s_cap_from;
+            int m_eff = base == 0 ? 0 : S.rows_out[1];
+            if (cap_from == nf) {
+                for (int j = 0; j < cnt; ++j) {
+                    if (s_st[j] & 2) { stack += s_rows[j]; m_eff = S.feats[base + j].row_off + s_rows[j]; }
+                    if (S.apply_row_cap && stack > S.max_stack_rows) { cap_from = base + j + 1; break; }
+                }
+            }
+            s_cap_from = cap_from;
+            S.rows_out[0] = stack;
+            S.rows_out[1] = m_eff;    // rows beyond the last stacked block are all zero: the Gram pass stops there
         }
-        s_cap_from = cap_from; s_stack = stack;
-        S.rows_out[0] = stack;
-        // rows beyond the last stacked block are all zero: the Gram pass stops there
-        int m_eff = 0;
-        for (int j = 0; j < cap_from && j < S.n_feat; ++j)
-            if (S.feat_status[j] & 2) m_eff = S.feats[j].row_off + 4 * S.feats[j].n_obs - 3;
-        S.rows_out[1] = m_eff;
     }
     __syncthreads();
-    for (int j = s_cap_from; j < S.n_feat; ++j) {
+    // zero the blocks of features behind the cap (they passed the gate but are not stacked)
+    for (int j = s_cap_from; j < nf; ++j) {
         if (!(S.feat_status[j] & 2)) continue;
-        __syncthreads();
         const EkfFeatDev &F = S.feats[j];
         const int n = 4 * F.n_obs - 3;
         double *Hrow0 = S.Hs + (size_t)F.row_off * S.ld;

@@ -67,6 +67,16 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams, i
     gemm_setup(S, mode, g);
     const int tiles_n = (g.N + GT - 1) / GT, tiles_m = (g.M + GT - 1) / GT;
     const int tile = blockIdx.x;
+    if (mode == GM_PUPD && tile == tiles_m * tiles_n) {
+        // one extra workgroup: delta_x = Y^T w, w = column d of Y (msckf_vio.cpp:860)
+        const int d = S.d, ld = S.ld;
+        for (int c = threadIdx.x; c < d; c += 256) {
+            double s2 = 0;
+            for (int k = 0; k < d; ++k) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
+            S.delta_x[c] = s2;
+        }
+        return;
+    }
     if (tile >= tiles_m * tiles_n) return;
     const int ti = tile / tiles_n, tj = tile - ti * tiles_n;
     if (g.sym && tj > ti) return;
@@ -217,6 +227,10 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
             A[(size_t)(r0 + a) * lda + r0 + b] -= s;
         }
     }
+    if (which == 0) {
+        __syncthreads();
+        for (int k = tid; k < S.d; k += 256) S.T[(size_t)k * S.ld + S.d] = A[(size_t)S.d * lda + k];
+    }
 }
 
 // ------------------------------------------------------------------------------------ LDS-resident Cholesky
@@ -318,6 +332,10 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
         const int i = e / nt, j = e - i * nt;
         if (j <= i && j < n) A[(size_t)(off + i) * lda + off + j] = sM[(size_t)i * (i + 1) / 2 + j];
     }
+    if (which == 0) {
+        // column d of T <- (Q^T r) = row d of L, so the TRSM carries w = L2^-1 Q^T r along (IMU part is zero)
+        for (int k = tid; k < S.d; k += 1024) S.T[(size_t)k * lda + S.d] = (k < off) ? 0.0 : sM[(size_t)n * (n + 1) / 2 + (k - off)];
+    }
     const double l0 = semidef ? 0.0 : sqrt(S.sigma2);
     const int rows_all = S.d + (which == 0 ? 1 : 0);
     for (int e = tid; e < rows_all * off; e += 1024) {
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(256) void k_ekf_dx(const EkfStreamDev *streams) {
 extern "C" {
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st) {
     const int t = (max_mn + GT - 1) / GT;
-    hipLaunchKernelGGL(k_ekf_gemm, dim3(t * t, n), dim3(256), 0, st, d, mode);
+    hipLaunchKernelGGL(k_ekf_gemm, dim3(t * t + (mode == GM_PUPD ? 1 : 0), n), dim3(256), 0, st, d, mode);
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
     const int nt = max_d - EKF_IMU_DIM + 1;
