@@ -404,22 +404,26 @@ __device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, Tri
 // LDS: static Hf 6K + Hx 12K + r 2K + V 6K + coef 9K ~ 36K; dynamic arena = max(triangulation scratch,
 // lds_rows^2 doubles for the gating matrix M) — M lives in LDS when 4 n_obs <= lds_rows (<= 120 rows = 112.5 KiB),
 // otherwise in the per-slot global scratch gate_S.
+// Mm is symmetric and kept in packed lower form (row i at i(i+1)/2): 120 rows = 56.7 KiB, so with the
+// 32-clone instantiation (19 KiB static) two workgroups share a CU.
 #define GATE_LDS_ROWS 120
+__device__ __forceinline__ size_t pk(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // i >= j
+template <int MAXC>
 __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *streams, int lds_rows) {
     const EkfStreamDev &S = streams[blockIdx.y];
     const int tid = threadIdx.x;
     const int d = S.d, ld = S.ld;
-    __shared__ double sHf[4 * MAX_CLONES_DEV][3];
-    __shared__ double sHx[4 * MAX_CLONES_DEV][6];
-    __shared__ double sr[4 * MAX_CLONES_DEV];
-    __shared__ double sV[3][4 * MAX_CLONES_DEV];
-    __shared__ double sCoef[6 * MAX_CLONES_DEV + 1][3];
+    __shared__ double sHf[4 * MAXC][3];
+    __shared__ double sHx[4 * MAXC][6];
+    __shared__ double sr[4 * MAXC];
+    __shared__ double sV[3][4 * MAXC];
+    __shared__ double sCoef[6 * MAXC + 1][3];
     __shared__ double sBeta[3], sVV[3];  // beta_k ; v2.v1, v3.v1, v3.v2
-    __shared__ int sObsOfClone[MAX_CLONES_DEV];
-    __shared__ int sCloneOfObs[MAX_CLONES_DEV];
+    __shared__ int sObsOfClone[MAX_CLONES_DEV];   // indexed by clone id (any clone of the state)
+    __shared__ int sCloneOfObs[MAXC];
     extern __shared__ double s_arena[];
     TriScratch &sTri = *reinterpret_cast<TriScratch *>(s_arena);
-    __shared__ double sW[4 * MAX_CLONES_DEV];
+    __shared__ double sW[4 * MAXC];
     __shared__ double sPos[3];
     __shared__ int sValid;
     __shared__ double sRed[8];
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
         // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
         // H = A^T H_xj with H_xj block diagonal (4x6 per observation), so H P H^T = A^T Mm A with
         // Mm[a][b] = H_a P_ab H_b^T (4x4 blocks from 6x6 blocks of P), and A^T . A = rows/cols 3.. of Q^T . Q.
-        double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax);
+        double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax);   // packed lower
         const double *P = S.P;
         for (int pr = tid; pr < M * M; pr += WG) {
             const int a = pr / M, b = pr - a * M;
@@ -595,21 +599,22 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
                 HP[i][v] = t;
             }
             for (int i = 0; i < 4; ++i) for (int jj = 0; jj < 4; ++jj) {
+                if (a == b && jj > i) continue;
                 double t = 0;
                 for (int v = 0; v < 6; ++v) t += HP[i][v] * sHx[4 * b + jj][v];
-                Mm[(size_t)(4 * a + i) * rows + 4 * b + jj] = t;
-                Mm[(size_t)(4 * b + jj) * rows + 4 * a + i] = t;
+                Mm[pk(4 * a + i, 4 * b + jj)] = t;
             }
         }
         __syncthreads();
-        // two-sided reflectors: Mm <- Q_k^T Mm Q_k, Q_k = I - beta_k v_k v_k^T  (Mm symmetric)
+        // two-sided reflectors: Mm <- Q_k^T Mm Q_k, Q_k = I - beta_k v_k v_k^T  (Mm symmetric, lower stored)
         for (int k = 0; k < 3; ++k) {
             const double beta = sBeta[k];
             if (beta == 0.0) continue;     // uniform
             for (int i = tid; i < rows; i += WG) {
                 double t = 0;
-                const double *mi = Mm + (size_t)i * rows;
-                for (int c = 0; c < rows; ++c) t += mi[c] * sV[k][c];
+                const double *mi = Mm + pk(i, 0);
+                for (int c = 0; c <= i; ++c) t += mi[c] * sV[k][c];
+                for (int c = i + 1; c < rows; ++c) t += Mm[pk(c, i)] * sV[k][c];
                 sW[i] = t;
             }
             __syncthreads();
@@ -619,34 +624,36 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
             const double b2a = beta * beta * alpha;
             for (int e = tid; e < rows * rows; e += WG) {
                 const int i = e / rows, c = e - i * rows;
-                Mm[e] += -beta * (sV[k][i] * sW[c] + sW[i] * sV[k][c]) + b2a * sV[k][i] * sV[k][c];
+                if (c > i) continue;
+                Mm[pk(i, c)] += -beta * (sV[k][i] * sW[c] + sW[i] * sV[k][c]) + b2a * sV[k][i] * sV[k][c];
             }
             __syncthreads();
         }
         // S = Mm[3:,3:] + sigma^2 I ; in-place right-looking Cholesky (lower) on the sub-matrix view.  The residual
         // r_o rides along as an extra row (sW): after step k it holds y_k = (L^-1 r_o)_k, so gamma = y . y
         // needs no separate triangular solve.
-        double *Sg = Mm + (size_t)3 * rows + 3;    // row stride `rows`
-        for (int i = tid; i < n; i += WG) { Sg[(size_t)i * rows + i] += S.sigma2; sW[i] = r0[i]; }
+#define SG(i, j) Mm[pk((i) + 3, (j) + 3)]
+        for (int i = tid; i < n; i += WG) { SG(i, i) += S.sigma2; sW[i] = r0[i]; }
         __syncthreads();
         bool pd_ok = true;
         for (int k = 0; k < n; ++k) {
-            const double dk = Sg[(size_t)k * rows + k];
+            const double dk = SG(k, k);
             if (!(dk > 0)) { pd_ok = false; break; }
             const double inv = 1.0 / sqrt(dk);
             __syncthreads();
-            for (int i = k + tid; i < n; i += WG) Sg[(size_t)i * rows + k] *= inv;   // column k: l_kk = sqrt(dk), l_ik = a_ik / l_kk
-            if (tid == 0) sW[k] *= inv;                                               // y_k
+            for (int i = k + tid; i < n; i += WG) SG(i, k) *= inv;   // column k: l_kk = sqrt(dk), l_ik = a_ik / l_kk
+            if (tid == 0) sW[k] *= inv;                               // y_k
             __syncthreads();
             const int rem = n - k - 1;
             const double yk = sW[k];
             for (int idx = tid; idx < rem * rem; idx += WG) {
                 const int a = idx / rem + k + 1, b = idx % rem + k + 1;
-                if (b <= a) Sg[(size_t)a * rows + b] -= Sg[(size_t)a * rows + k] * Sg[(size_t)b * rows + k];
+                if (b <= a) SG(a, b) -= SG(a, k) * SG(b, k);
             }
             __syncthreads();
-            for (int i = k + 1 + tid; i < n; i += WG) sW[i] -= Sg[(size_t)i * rows + k] * yk;
+            for (int i = k + 1 + tid; i < n; i += WG) sW[i] -= SG(i, k) * yk;
         }
+#undef SG
         double gamma = 1e300;
         if (pd_ok) {
             __syncthreads();
@@ -718,13 +725,17 @@ void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
 }
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st) {
     const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
+    const int packed_max = GATE_LDS_ROWS * (GATE_LDS_ROWS + 1) / 2 * (int)sizeof(double);
     static std::once_flag attr_once;
-    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GATE_LDS_ROWS * GATE_LDS_ROWS * (int)sizeof(double)); });
+    std::call_once(attr_once, [packed_max]() {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<32>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<MAX_CLONES_DEV>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+    });
     const int lds_rows = max_rows <= GATE_LDS_ROWS ? max_rows : GATE_LDS_ROWS;
-    size_t lds = (size_t)lds_rows * lds_rows * sizeof(double);
+    size_t lds = (size_t)lds_rows * (lds_rows + 1) / 2 * sizeof(double);
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
-    hipLaunchKernelGGL(k_ekf_feature_blocks, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
+    if (max_rows <= 4 * 32) hipLaunchKernelGGL(k_ekf_feature_blocks<32>, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
+    else hipLaunchKernelGGL(k_ekf_feature_blocks<MAX_CLONES_DEV>, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
 }
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_posvar, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n, out);
