@@ -179,6 +179,15 @@ def main():
             achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+        # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+        # separately, profiles/r01_pmc_hbm_traffic.json); only comparable when a launch covers the same 32 streams
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"].get(dom)
+            if pmc and per_group == 32:
+                roof["traffic"] = (pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
+                roof["traffic_note"] = "bytes/launch, raw FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (no gfx950 correction applied)"
+        except Exception:
+            pass
         roof["avg_launch_us"] = avg_s * 1e6
         roof["units_per_launch"] = units / max(launches, 1)
         kernels = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)} for k, v in timing.items()}
