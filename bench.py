@@ -170,7 +170,7 @@ def main():
         dom = max(timing, key=lambda k: timing[k][0])
         ms, launches, units = timing[dom]
         avg_s = max(ms * 1e-3 / max(launches, 1), 1e-12)
-        if dom in ("k_ekf_feature_blocks", "k_ekf_gemm", "k_ekf_chol", "k_ekf_trsm"):
+        if dom in ("k_ekf_feature_blocks", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm"):
             achieved = units / max(launches, 1) / avg_s / 1e12           # units = algorithmic FP64 flops
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}

@@ -78,9 +78,23 @@ def build_host(force=False, verbose=False):
     return target
 
 
+def build_app(force=False, verbose=False):
+    """Headless counterpart of the reference harness apps/run_euroc_single_thread.cpp (zlib PNG reader)."""
+    src = os.path.join(CSRC, "apps", "run_euroc_single_thread.cpp")
+    target = os.path.join(OUT, "run_euroc_single_thread")
+    if not force and not _newer(target, _all_sources()):
+        return target
+    cmd = ["g++"] + COMMON + ["-o", target, src, "-L" + OUT, "-lmskf_host", "-lmskf_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return target
+
+
 def build_all(force=False, verbose=False):
     a = build_hip(force, verbose)
     b = build_host(force, verbose)
+    build_app(force, verbose)
     return a, b
 
 

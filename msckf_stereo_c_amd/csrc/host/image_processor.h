@@ -70,6 +70,7 @@ class ImageProcessor {
     void phaseAfter1(mskf_fe_track_args &args);                     // consume results; prepare new-feature candidates
     void phaseAfter2(bool is_draw);                                 // addNewFeatures tail, prune, publish, rotate
     bool isFirstImage() const { return is_first_img; }
+    void enableFileOutputs() { if (!debug_.is_open()) debug_.open("debug_imageprocessor.txt"); }   // image_processor.cpp:134
     // records [zeroTailStart(), features.size()) of feature_msg_ptr_ were pushed but never written (Q1)
     size_t zeroTailStart() const { return max_published_; }
 

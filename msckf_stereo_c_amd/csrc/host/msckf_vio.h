@@ -92,6 +92,7 @@ class MsckfVio {
     // phase D: online reset decision from the position variances (msckf_vio.cpp:1186-1236)
     void phaseD(const double pos_var[3]);
     bool frameActive() const { return frame_active_; }
+    void enableFileOutputs() { if (!pose_outfile_.is_open()) pose_outfile_.open("pose_out.txt"); }   // msckf_vio.cpp:169
     // optional: records [start, size) of `msg` are untouched value-initialised records (Q1 tail)
     // total_size > msg->features.size(): `msg` is a snapshot truncated inside the zero tail of a longer message
     void setZeroTailHint(const CameraMeasurement *msg, size_t start, size_t total_size = 0) {

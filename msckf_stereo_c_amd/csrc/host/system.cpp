@@ -11,6 +11,7 @@ System::System(std::string file_cam_imu) : feature_msg_ptr_(new CameraMeasuremen
         mskf_fe_cfg fe = fe_cfg_from_yaml(YAML::LoadFile("../config/app_imgproc.yaml"));
         mskf_ekf_cfg ekf = ekf_cfg_from_yaml(YAML::LoadFile("../config/app_msckfvio.yaml"));
         setup(calib, fe, ekf, nullptr, 0);
+        if (ok_) { imgproc_ptr_->enableFileOutputs(); msckfvio_ptr_->enableFileOutputs(); }   // pose_out.txt, debug_imageprocessor.txt
     } catch (const std::exception &e) {   // the reference swallows init errors and only prints (system.cpp:17-33)
         std::cerr << "Cannot initialize System: " << e.what() << std::endl;
     }
