@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--loop", type=int, default=100, help="frames per trajectory period")
     ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("MSKF_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
     return ap.parse_args()
 
 
@@ -104,9 +106,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()      # rehearsal on fewer GPUs than ranks shares devices (gloo only)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from msckf_stereo_c_amd import build, runner as R
     build.build_all()
@@ -123,18 +129,24 @@ def main():
     t_r0 = time.perf_counter()
     syns, frames = render_sequences(oracle_py, args, rank, n_keys)
     render_s = time.perf_counter() - t_r0
-    d_frames = torch.from_numpy(frames).cuda(local_rank)      # resident in HBM before the timed region
     frame_bytes = args.width * args.height
+    if args.host_images:
+        h_frames = torch.from_numpy(frames).pin_memory()
+        base, on_device = h_frames.data_ptr(), 0
+    else:
+        d_frames = torch.from_numpy(frames).cuda(local_rank)  # resident in HBM before the timed region
+        base, on_device = d_frames.data_ptr(), 2              # borrowed in place
     calib = syns[0].calib
     run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads)
     run.keep_trajectory(False)
     imus = [imu_array(s, (total_frames + 3) * 10 + 20) for s in syns]
-    base = d_frames.data_ptr()
     for s in range(n_streams):
         u = s % args.unique
         cam0 = base + (u * 2 + 0) * n_keys * frame_bytes
         cam1 = base + (u * 2 + 1) * n_keys * frame_bytes
-        run.set_sequence(s, cam0, cam1, 2, frame_bytes, 25, args.loop, 1403715273262142976, 50000000, imus[u])
+        run.set_sequence(s, cam0, cam1, on_device, frame_bytes, 25, args.loop, 1403715273262142976, 50000000, imus[u])
+
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,7 +169,7 @@ def main():
     run.set_timing(False)
 
     from msckf_stereo_c_amd.dist_util import aggregate_throughput
-    elapsed, frames_total = aggregate_throughput(elapsed, n_streams * args.steps, world, device="cuda")
+    elapsed, frames_total = aggregate_throughput(elapsed, n_streams * args.steps, world, device=red_dev)
 
     # sanity of the workload actually processed (steady state reached, filter alive)
     n_feat = len(run.dump(0)[0])
@@ -194,7 +206,7 @@ def main():
         out = {
             "metric": "stereo frames/sec/node on EuRoC-shape input", "value": value, "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (host-resident images, PCIe-inclusive)" if args.host_images else ""),
             "config": {"workload": "Single MI355X: %dx%d stereo, %d cam clones, grid %s (%d features/frame), 200 Hz IMU; "
                                    "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads%s)"
                                    % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads,

@@ -176,3 +176,69 @@ def test_pipelined_run_is_identical_to_lockstep(oracle):
         assert np.abs(op["p"] - pb["p"]).max() < POS_TOL
     for r in runs:
         r.close()
+
+
+def _lockstep(oracle, syn, fe, ekf, n_frames, frame_hook=None, check_every=1):
+    """Run oracle and GPU path in lockstep on (possibly modified) frames of `syn`; returns (osys, run)."""
+    osys = oracle.OracleSystem(syn.calib, fe, ekf)
+    run = R.Runner(syn.calib, fe, ekf, 1, 1)
+    view = R.StreamView(run)
+    j = 0
+    for k in range(n_frames):
+        t_img = syn.frame_time(k)
+        while True:
+            s = syn.imu(j)
+            j += 1
+            osys.imu(s)
+            view.imu(s)
+            if not (s.time_stamp <= t_img):
+                break
+        a, b = syn.render(k)
+        if frame_hook:
+            a, b = frame_hook(k, a, b)
+        osys.stereo(a, b, t_img)
+        view.stereo(a, b, t_img)
+        osys.backend()
+        view.backend()
+        if k % check_every == 0:
+            compare_frame(k, osys, run)
+    return osys, run
+
+
+def test_compat_switches_off(oracle):
+    """compat_flags = 0: cleared message (no Q1), true previous timestamp (no Q2), sieve-order responses (no Q4)."""
+    syn = oracle.Synth(seed=0x5EED0030, width=376, height=240)
+    fe, ekf = default_fe_cfg(compat=0), default_ekf_cfg()
+    osys, run = _lockstep(oracle, syn, fe, ekf, 60)
+    compare_msgs(osys, run)
+    assert len(run.msg()) == len(run.dump()[0])          # message holds exactly the live features
+    compare_poses(osys, run)
+    run.close()
+
+
+def test_textureless_stream(oracle):
+    """Empty inputs end to end: flat images give no detections, no tracks, no updates — and no crash."""
+    syn = oracle.Synth(seed=0x5EED0031, width=376, height=240)
+    flat = np.full((240, 376), 90, np.uint8)
+    osys, run = _lockstep(oracle, syn, default_fe_cfg(), default_ekf_cfg(), 40, frame_hook=lambda k, a, b: (flat, flat))
+    assert len(run.dump()[0]) == 0 and len(run.msg()) == 0
+    assert run.num_updates() == osys.num_updates() == 0
+    compare_poses(osys, run)                               # pure IMU dead reckoning, identical host arithmetic
+    run.close()
+
+
+def test_blackout_and_recovery(oracle):
+    """All features lost at once (3 flat frames mid-sequence): one large update (row cap), then re-detection."""
+    syn = oracle.Synth(seed=0x5EED0032, width=376, height=240)
+    flat = np.full((240, 376), 128, np.uint8)
+    fe, ekf = default_fe_cfg(grid_row=6, grid_col=8, grid_min=3, grid_max=4), default_ekf_cfg(max_cam_state_size=12)
+
+    def hook(k, a, b):
+        return (flat, flat) if 45 <= k < 48 else (a, b)
+    osys, run = _lockstep(oracle, syn, fe, ekf, 75, frame_hook=hook)
+    compare_msgs(osys, run)
+    ids = run.dump()[0]
+    assert len(ids) > 80 and ids.min() > 100                # everything alive was born after the blackout
+    assert osys.num_updates() == run.num_updates() > 10
+    compare_poses(osys, run)
+    run.close()
