@@ -204,7 +204,7 @@ static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
     std::memcpy(d.E, s->E, sizeof(d.E));
     d.epi_thresh = s->epi_thresh;
     d.det_rows = s->fe.det_rows; d.det_cols = s->fe.det_cols; d.cell_w = s->det_cw; d.cell_h = s->det_ch;
-    d.cell_max = (mskf_corner *)(s->ctx->cell_arena.d + s->cell_off);
+    d.cell_keys = (unsigned long long *)(s->ctx->cell_arena.d + s->cell_off);
 }
 
 extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
@@ -216,14 +216,14 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
     if (rc != MSKF_OK) return rc;
     rc = ctx->desc[0].ensure(n);
     if (rc != MSKF_OK) return rc;
-    int max_cells = 0;
+    int max_w = 0, max_h = 0;
+    size_t cell_bytes = 0;
     {
-        size_t cell_bytes = 0;
-        for (int i = 0; i < n; ++i) { if (!streams[i] || streams[i]->ctx != ctx) return MSKF_ERR_INVALID; cell_bytes += sizeof(mskf_corner) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
+        for (int i = 0; i < n; ++i) { if (!streams[i] || streams[i]->ctx != ctx) return MSKF_ERR_INVALID; cell_bytes += sizeof(unsigned long long) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
         if (cell_bytes > ctx->cell_arena.cap) { MSKF_HIPCHK(hipStreamSynchronize(st)); rc = ctx->cell_arena.ensure(cell_bytes); if (rc != MSKF_OK) return rc; }
         ++ctx->push_gen;
         size_t off = 0;
-        for (int i = 0; i < n; ++i) { streams[i]->cell_off = off; streams[i]->push_gen = ctx->push_gen; off += sizeof(mskf_corner) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
+        for (int i = 0; i < n; ++i) { streams[i]->cell_off = off; streams[i]->push_gen = ctx->push_gen; off += sizeof(unsigned long long) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
     }
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
@@ -240,7 +240,7 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
             MSKF_HIPCHK(hipMemcpyAsync(s->pyr[s->i_curr1], cam1[i], (size_t)s->w * s->h, kind, st));
         }
         s->has_curr = true;
-        max_cells = std::max(max_cells, s->fe.det_rows * s->fe.det_cols);
+        max_w = std::max(max_w, s->w); max_h = std::max(max_h, s->h);
     }
     // pyramid levels 1..3 of both cameras, one launch per level over all streams
     int max_dw[MSKF_LEVELS] = {0}, max_dh[MSKF_LEVELS] = {0};
@@ -271,13 +271,12 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
     {
         long long px = 0;
         for (int i = 0; i < n; ++i) px += (long long)streams[i]->w * streams[i]->h;
+        MSKF_HIPCHK(hipMemsetAsync(ctx->cell_arena.d, 0, cell_bytes, st));   // keys are merged with atomicMax
         const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
-        fe_launch_detect(ctx->desc[0].d, n, max_cells, st);
+        fe_launch_detect(ctx->desc[0].d, n, max_w, max_h, st);
         mskf_t_end(ctx, ts, px);
     }
     {
-        size_t cell_bytes = 0;
-        for (int i = 0; i < n; ++i) cell_bytes += sizeof(mskf_corner) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols;
         MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
     }
     MSKF_HIPCHK(hipGetLastError());
@@ -327,7 +326,20 @@ extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int cap
     MSKF_HIPCHK(hipSetDevice(s->ctx->device));
     if (s->push_gen != s->ctx->push_gen) { mskf_set_error("cell maxima are stale: another push happened on this context"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));   // no ctx mutation here: callable concurrently for different streams
-    std::memcpy(out, s->ctx->cell_arena.h + s->cell_off, sizeof(mskf_corner) * (size_t)n);
+    // keys -> corners: score << 32 | ~order, order = row-major position inside the cell (0 = no corner)
+    const unsigned long long *keys = (const unsigned long long *)(s->ctx->cell_arena.h + s->cell_off);
+    const int cols = s->fe.det_cols, cw = s->det_cw, ch = s->det_ch;
+    for (int cell = 0; cell < n; ++cell) {
+        mskf_corner &o = out[cell];
+        o.cell = cell;
+        const unsigned long long k = keys[cell];
+        if (k == 0ULL) { o.x = 0.f; o.y = 0.f; o.score = 0; continue; }
+        const unsigned int order = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFULL);
+        const int cy = cell / cols, cx = cell - cy * cols;
+        o.score = (int)(k >> 32);
+        o.y = (float)(cy * ch + (int)(order / (unsigned)cw));
+        o.x = (float)(cx * cw + (int)(order % (unsigned)cw));
+    }
     *n_out = n;
     return MSKF_OK;
 }

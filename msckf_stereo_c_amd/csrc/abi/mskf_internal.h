@@ -12,7 +12,7 @@ struct PyrJob { const uint8_t *src; uint8_t *dst; int sw, sh, dw, dh; };
 
 extern "C" {
 void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t st);
-void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_cells, hipStream_t st);
+void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, hipStream_t st);
 void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st);
 }
 
@@ -58,7 +58,7 @@ struct mskf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
-    PinnedDev<char> cell_arena;       // per-cell maxima of every stream of the last push batch (one D2H copy)
+    PinnedDev<char> cell_arena;       // per-cell maximum keys of every stream of the last push batch (one D2H copy)
     PinnedDev<char> trk_in, trk_out;  // input points / results of every stream of a track batch (one copy each way)
     unsigned long long push_gen = 0;
     PinnedDev<PyrJob> jobs;

@@ -34,5 +34,5 @@ struct FeStreamDev {
     uint8_t *status;              // bit0: temporal track ok (incl. bounds), bit1: stereo inlier
     // detector
     int det_rows, det_cols, cell_w, cell_h;
-    mskf_corner *cell_max;        // det_rows*det_cols per-cell maxima of curr0 level 0
+    unsigned long long *cell_keys; // det_rows*det_cols per-cell maxima of curr0 level 0 as keys score<<32 | ~order (0 = none)
 };

@@ -1,7 +1,7 @@
 // fe_kernels.hip — hand-written gfx950 kernels of the stereo KLT front-end.
 //
 //  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242)
-//  k_detect_cells : cg::CornerDetector      (:132,259,657) — per-cell integer Shi-Tomasi maximum
+//  k_detect_cells : cg::CornerDetector      (:132,259,657) — per-cell integer Shi-Tomasi maximum (32x32 px tiles)
 //  k_lk_points    : cg::optical_flow_multi_level (:410 temporal, :569 stereo) fused with the
 //                   prediction (:321-350), the image-bounds gates (:416-424, :575-583), the stereo
 //                   initial guess (:542-548), undistortion and the epipolar gate (:587-617).
@@ -9,7 +9,7 @@
 // Arithmetic contract: every decision-bearing quantity is integer or a fixed
 // sequence of IEEE-754 double operations; this file must be compiled with -ffp-contract=off.
 // Work shapes: one 64-lane wavefront per tracked point (a 15x15 window = 225 pixels, <= 4 per
-// lane), one workgroup per detector cell, one workgroup per 64x16 pyramid output tile; the
+// lane), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
 #include "fe_device.h"
@@ -65,103 +65,165 @@ extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_d
 }
 
 // ------------------------------------------------------------------------------------------ detector
-__device__ __forceinline__ long long isqrt64(long long v) {
-    long long r = (long long)sqrt((double)v);
-    while (r * r > v) --r;
-    while ((r + 1) * (r + 1) <= v) ++r;
+#define DET_BORDER 8
+#define DTW 32                 // tile of output pixels per workgroup
+#define DTH 32
+#define DSW 48                 // staged bytes per row: image x in [tx0-8, tx0+40)
+#define DSH 42                 // staged rows:          image y in [ty0-5, ty0+37)
+#define DPW 40                 // gradient-product plane: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
+#define DET_SLOTS 64           // per-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
+
+// floor(sqrt(v)) for 0 <= v < 2^48, exact: the hardware estimate is corrected with integer compares.
+__device__ __forceinline__ unsigned int isqrt48(unsigned long long v, double vd) {
+    unsigned int r = (unsigned int)__builtin_amdgcn_sqrt(vd);
+    while ((unsigned long long)r * r > v) --r;
+    while ((unsigned long long)(r + 1) * (r + 1) <= v) ++r;
     return r;
 }
 
-#define DET_BORDER 8
-
-// One workgroup per detector cell.  The cell (+5 px halo) is staged in LDS in sub-tiles of <= 32x32 pixels;
-// gradient products are formed once per pixel, the 8x8 box sums are separable (8-wide horizontal pass,
-// then 8-tall vertical pass), and the block reduces to the (max score, first in row-major order) corner.
-#define DT 32
-__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams) {
+// cg::CornerDetector per-cell maxima.  One workgroup scores a 32x32 pixel tile: the u8 footprint is staged in
+// LDS once (border pixels replicated), the three gradient products dx*dx, dx*dy, dy*dy are formed once per
+// pixel, the 8x8 box sums are separable with sliding windows (horizontal runs of 8, vertical runs of 4), the
+// integer Shi-Tomasi score (a + c) - isqrt((a - c)^2 + 4 b^2) is exact, and per-cell maxima are merged as
+// 64-bit keys  score << 32 | ~order  (order = row-major position inside the cell, so ties go to the first
+// pixel in scan order) through LDS atomics and one global atomicMax per touched cell.  The key array must be
+// zero before the launch; mskf_fe_get_cell_maxima turns keys into mskf_corner records.
+__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams, int tiles_x) {
     const FeStreamDev &S = streams[blockIdx.y];
-    const int cell = blockIdx.x;
-    if (cell >= S.det_rows * S.det_cols) return;
     const int W = S.curr0.w[0], H = S.curr0.h[0];
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int tx0 = txi * DTW, ty0 = tyi * DTH;
+    if (tx0 >= W || ty0 >= H) return;
     const uint8_t *img = S.curr0.lvl[0];
     const int cw = S.cell_w, ch = S.cell_h;
-    const int cy = cell / S.det_cols, cx = cell - cy * S.det_cols;
-    const int x0 = cx * cw, y0 = cy * ch;
-    __shared__ uint8_t tile[(DT + 10) * (DT + 10)];
-    __shared__ int sG[3][(DT + 8) * (DT + 8)];    // dx*dx, dx*dy, dy*dy at tile (r+1, c+1)
-    __shared__ int sH[3][(DT + 8) * DT];          // horizontal 8-sums
-    __shared__ unsigned long long s_best[4];
-    unsigned long long best = 0ULL;
-    for (int ty = 0; ty < ch; ty += DT)
-        for (int tx = 0; tx < cw; tx += DT) {
-            const int tw = min(DT, cw - tx), th = min(DT, ch - ty);
-            const int lw = tw + 10, lh = th + 10;
-            const int gw = tw + 8, gh = th + 8;
-            const int gx0 = x0 + tx - 5, gy0 = y0 + ty - 5;
-            __syncthreads();
-            for (int i = threadIdx.x; i < lw * lh; i += 256) {
-                const int r = i / lw, c = i - r * lw;
-                const int gx = min(max(gx0 + c, 0), W - 1), gy = min(max(gy0 + r, 0), H - 1);
-                tile[i] = img[(size_t)gy * W + gx];
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < gw * gh; i += 256) {
-                const int r = i / gw, c = i - r * gw;          // tile position (r+1, c+1)
-                const uint8_t *t = tile + (r + 1) * lw + (c + 1);
-                const int dx = (int)t[1] - (int)t[-1];
-                const int dy = (int)t[lw] - (int)t[-lw];
-                sG[0][i] = dx * dx; sG[1][i] = dx * dy; sG[2][i] = dy * dy;
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < gh * tw; i += 256) {
-                const int r = i / tw, c = i - r * tw;
-                const int *g0 = sG[0] + r * gw + c, *g1 = sG[1] + r * gw + c, *g2 = sG[2] + r * gw + c;
-                int a = 0, b = 0, d = 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { a += g0[u]; b += g1[u]; d += g2[u]; }
-                sH[0][i] = a; sH[1][i] = b; sH[2][i] = d;
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < tw * th; i += 256) {
-                const int r = i / tw, c = i - r * tw;
-                const int x = x0 + tx + c, y = y0 + ty + r;
-                if (x < DET_BORDER || y < DET_BORDER || x >= W - DET_BORDER || y >= H - DET_BORDER) continue;
-                long long a = 0, b = 0, cc = 0;
-#pragma unroll
-                for (int v = 0; v < 8; ++v) { a += sH[0][(r + v) * tw + c]; b += sH[1][(r + v) * tw + c]; cc += sH[2][(r + v) * tw + c]; }
-                const long long disc = (a - cc) * (a - cc) + 4 * b * b;
-                const long long score = (a + cc) - isqrt64(disc);
-                if (score > 0) {
-                    // row-major scan order inside the cell decides ties: smaller (y, x) wins
-                    const unsigned int order = (unsigned int)((y - y0) * cw + (x - x0));
-                    const unsigned long long key = ((unsigned long long)score << 32) | (0xFFFFFFFFu - order);
-                    best = key > best ? key : best;
-                }
-            }
+    const int tid = threadIdx.x;
+
+    __shared__ uint32_t s_tile[DSW / 4 * DSH];
+    __shared__ int s_P[3][DPW * DPW];
+    __shared__ int s_H[3][DPW * DTW];
+    __shared__ unsigned long long s_key[DET_SLOTS];
+    __shared__ int s_cx[DTW], s_cy[DTH];
+
+    // ---- stage the footprint
+    const int sx0 = tx0 - 8, sy0 = ty0 - 5;
+    const bool fast = sx0 >= 0 && sy0 >= 0 && sx0 + DSW <= W && sy0 + DSH <= H;
+    if (fast) {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        for (int i = tid; i < DSW / 4 * DSH; i += 256) {
+            const int r = i / (DSW / 4), c = i - r * (DSW / 4);
+            s_tile[i] = *(const u32u *)(img + (size_t)(sy0 + r) * W + sx0 + 4 * c);
         }
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off);
-        best = o > best ? o : best;
+    } else {
+        uint8_t *t8 = (uint8_t *)s_tile;
+        for (int i = tid; i < DSW * DSH; i += 256) {
+            const int r = i / DSW, c = i - r * DSW;
+            const int gx = min(max(sx0 + c, 0), W - 1), gy = min(max(sy0 + r, 0), H - 1);
+            t8[i] = img[(size_t)gy * W + gx];
+        }
     }
-    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    if (tid < DTW) s_cx[tid] = (tx0 + tid) / cw;
+    else if (tid < DTW + DTH) s_cy[tid - DTW] = (ty0 + tid - DTW) / ch;
+    if (tid < DET_SLOTS) s_key[tid] = 0ULL;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) best = s_best[i] > best ? s_best[i] : best;
-        mskf_corner out;
-        out.cell = cell;
-        if (best == 0ULL) { out.x = 0.f; out.y = 0.f; out.score = 0; }
-        else {
-            const unsigned int order = 0xFFFFFFFFu - (unsigned int)(best & 0xFFFFFFFFULL);
-            out.score = (int)(best >> 32);
-            out.y = (float)(y0 + (int)(order / (unsigned)cw));
-            out.x = (float)(x0 + (int)(order % (unsigned)cw));
+
+    // ---- gradient products at image (ty0-4+r, tx0-4+c): staged position (r+1, c+4)
+    {
+        const uint8_t *t8 = (const uint8_t *)s_tile;
+        for (int i = tid; i < DPW * DPW; i += 256) {
+            const int r = i / DPW, c = i - r * DPW;
+            const uint8_t *t = t8 + (r + 1) * DSW + (c + 4);
+            const int dx = (int)t[1] - (int)t[-1];
+            const int dy = (int)t[DSW] - (int)t[-DSW];
+            s_P[0][i] = dx * dx; s_P[1][i] = dx * dy; s_P[2][i] = dy * dy;
         }
-        S.cell_max[cell] = out;
+    }
+    __syncthreads();
+
+    // ---- horizontal 8-sums: item = (plane, row, run of 8 outputs)
+    for (int it = tid; it < 3 * DPW * (DTW / 8); it += 256) {
+        const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
+        const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
+        const int *src = s_P[pl] + r * DPW + 8 * q;
+        int v[15];
+#pragma unroll
+        for (int u = 0; u < 15; ++u) v[u] = src[u];
+        int acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        int *dst = s_H[pl] + r * DTW + 8 * q;
+        dst[0] = acc;
+#pragma unroll
+        for (int u = 1; u < 8; ++u) { acc += v[u + 7] - v[u - 1]; dst[u] = acc; }
+    }
+    __syncthreads();
+
+    // ---- vertical 8-sums + score: thread = (column c, run of 4 rows)
+    {
+        const int c = tid & (DTW - 1), q = tid >> 5;          // 32 columns x 8 runs
+        const int x = tx0 + c;
+        int sa[4], sb[4], sc[4];
+        {
+            int v0[11], v1[11], v2[11];
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const int o = (4 * q + u) * DTW + c;
+                v0[u] = s_H[0][o]; v1[u] = s_H[1][o]; v2[u] = s_H[2][o];
+            }
+            int a = 0, b = 0, d = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v0[u]; b += v1[u]; d += v2[u]; }
+            sa[0] = a; sb[0] = b; sc[0] = d;
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                a += v0[u + 7] - v0[u - 1]; b += v1[u + 7] - v1[u - 1]; d += v2[u + 7] - v2[u - 1];
+                sa[u] = a; sb[u] = b; sc[u] = d;
+            }
+        }
+        const int cx = s_cx[c];
+        const int cx_first = s_cx[0], cy_first = s_cy[0];
+        const int ncx = s_cx[DTW - 1] - cx_first + 1, ncy = s_cy[DTH - 1] - cy_first + 1;
+        const bool use_lds = ncx * ncy <= DET_SLOTS;
+        const bool x_ok = x >= DET_BORDER && x < W - DET_BORDER;
+        int cur_cell = -1, cur_slot = 0;
+        unsigned long long cur_key = 0ULL;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int y = ty0 + 4 * q + u;
+            if (!x_ok || y < DET_BORDER || y >= H - DET_BORDER) continue;
+            const int a = sa[u], b = sb[u], d = sc[u];
+            const int df = a - d;
+            const long long disc = (long long)df * df + 4LL * ((long long)b * b);
+            const double discd = (double)df * (double)df + 4.0 * ((double)b * (double)b);   // exact: < 2^48
+            const int score = (a + d) - (int)isqrt48((unsigned long long)disc, discd);
+            if (score <= 0) continue;
+            const int cy = s_cy[4 * q + u];
+            const int cell = cy * S.det_cols + cx;
+            const unsigned int order = (unsigned int)((y - cy * ch) * cw + (x - cx * cw));
+            const unsigned long long key = ((unsigned long long)(unsigned int)score << 32) | (0xFFFFFFFFu - order);
+            if (cell != cur_cell) {
+                if (cur_key) {
+                    if (use_lds) atomicMax(&s_key[cur_slot], cur_key);
+                    else atomicMax(&S.cell_keys[cur_cell], cur_key);
+                }
+                cur_cell = cell; cur_slot = (cy - cy_first) * ncx + (cx - cx_first); cur_key = key;
+            } else if (key > cur_key) cur_key = key;
+        }
+        if (cur_key) {
+            if (use_lds) atomicMax(&s_key[cur_slot], cur_key);
+            else atomicMax(&S.cell_keys[cur_cell], cur_key);
+        }
+        __syncthreads();
+        if (use_lds && tid < ncx * ncy) {
+            const unsigned long long k = s_key[tid];
+            if (k) {
+                const int ly = tid / ncx, lx = tid - ly * ncx;
+                atomicMax(&S.cell_keys[(cy_first + ly) * S.det_cols + (cx_first + lx)], k);
+            }
+        }
     }
 }
 
-extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_cells, hipStream_t st) {
-    hipLaunchKernelGGL(k_detect_cells, dim3(max_cells, n_streams), dim3(256), 0, st, streams_dev);
+extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, hipStream_t st) {
+    const int tiles_x = (max_w + DTW - 1) / DTW, tiles_y = (max_h + DTH - 1) / DTH;
+    hipLaunchKernelGGL(k_detect_cells, dim3(tiles_x * tiles_y, n_streams), dim3(256), 0, st, streams_dev, tiles_x);
 }
 
 // ------------------------------------------------------------------------------------------ point math
@@ -231,15 +293,58 @@ __device__ __forceinline__ int sample5(const uint8_t *img, int w, int h, int x, 
     return (s + 256) >> 9;
 }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// ---- wave-level integer reduction without LDS traffic: four DPP butterflies give every lane the sum of
+// its 16-lane row (int32 is enough for a row, see the bounds below), the four row sums are added as
+// 64-bit scalars.  All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ int dpp_add(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ long long wave_sum_rows(int v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
+           (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
 }
 
-// Pyramidal LK for one point, executed by one full wavefront (all 64 lanes call this with
-// identical arguments; control flow is wave-uniform).  s_P is a per-wave LDS scratch of 17*17 ints.
-__device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, float &bx, float &by, int &status, int *s_P) {
+// Search/template windows are staged in LDS as a byte region of LK_RH rows x LK_RS columns whose left edge
+// is a multiple of 4 pixels; pixels outside the image are replicated from the border (px_clamped), so the
+// iteration loop needs neither clamps nor 64-bit addressing.
+#define LK_RS 36
+#define LK_RH 32
+__device__ __forceinline__ void lk_stage(const uint8_t *img, int w, int h, int x0, int y0, int rows, uint32_t *s_R) {
     const int lane = threadIdx.x & 63;
+    // rows of the odd-width pyramid levels are not dword aligned: the loads are declared align-1 (gfx950 global
+    // memory takes unaligned dword accesses)
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    const bool fast = x0 >= 0 && y0 >= 0 && x0 + LK_RS <= w && y0 + rows <= h;
+    if (fast) {
+        const uint8_t *src = img + (size_t)y0 * w + x0;
+        for (int i = lane; i < (LK_RS / 4) * rows; i += 64) {
+            const int r = i / (LK_RS / 4), c = i - r * (LK_RS / 4);
+            s_R[i] = *(const u32u *)(src + r * w + 4 * c);
+        }
+    } else {
+        uint8_t *dst = (uint8_t *)s_R;
+        for (int i = lane; i < LK_RS * rows; i += 64) {
+            const int r = i / LK_RS, c = i - r * LK_RS;
+            dst[i] = (uint8_t)px_clamped(img, w, h, x0 + c, y0 + r);
+        }
+    }
+}
+
+// Pyramidal LK for one point, executed by one full wavefront (all 64 lanes call this with identical
+// arguments; control flow is wave-uniform).  Lane (j = lane>>2, seg = lane&3) owns the four window pixels
+// (row j, columns 4*seg .. 4*seg+3) — 60 lanes x 4 covers the 15x15 window, column 15 and row 15 are masked.
+// s_P: 17*17 ints (interpolated template), s_R: LK_RS*LK_RH bytes (staged image region).
+// Integer bounds: samples are <= 255*32 = 8160, Scharr gradients <= 4080, so a lane's four products are
+// < 2^27.1 and a 16-lane row sum < 2^31; the cross-row sum is taken in 64 bits.
+__device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, float &bx, float &by, int &status, int *s_P, uint32_t *s_R) {
+    const int lane = threadIdx.x & 63;
+    const int lj = min(lane >> 2, LK_WIN - 1), seg = lane & 3;
+    const bool row_ok = (lane >> 2) < LK_WIN;
+    const uint8_t *s_Rb = (const uint8_t *)s_R;
     const double FLT_SCALE = 1.0 / (double)(1 << 20);
     status = 1;
     float ncx = 0.f, ncy = 0.f;
@@ -258,33 +363,38 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
         }
         int w00, w01, w10, w11;
         bilinear_weights(pwx - (float)ipx, pwy - (float)ipy, w00, w01, w10, w11);
-        // 17x17 interpolated template -> LDS
+        // 18x18 source pixels -> LDS, then the 17x17 interpolated template -> LDS
         __syncthreads();
-        for (int i = lane; i < 17 * 17; i += 64) {
-            const int r = i / 17, c = i - r * 17;
-            s_P[i] = sample5(imA, aw, ah, ipx + c - 1, ipy + r - 1, w00, w01, w10, w11);
+        {
+            const int ax0 = (ipx - 1) & ~3, ay0 = ipy - 1;
+            lk_stage(imA, aw, ah, ax0, ay0, 18, s_R);
+            __syncthreads();
+            const int oxa = ipx - 1 - ax0;
+            for (int i = lane; i < 17 * 17; i += 64) {
+                const int r = i / 17, c = i - r * 17;
+                const uint8_t *q = s_Rb + r * LK_RS + oxa + c;
+                const int sv = (int)q[0] * w00 + (int)q[1] * w01 + (int)q[LK_RS] * w10 + (int)q[LK_RS + 1] * w11;
+                s_P[i] = (sv + 256) >> 9;
+            }
         }
         __syncthreads();
-        // each lane owns pixels lane, lane+64, lane+128, lane+192 (< 225) of the 15x15 window
-        int Pv[4], Ix[4], Iy[4], pj[4], pi[4];
-        long long A11 = 0, A12 = 0, A22 = 0;
+        int Pv[4], Ix[4], Iy[4];
+        int A11 = 0, A12 = 0, A22 = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int idx = lane + 64 * k;
-            Pv[k] = 0; Ix[k] = 0; Iy[k] = 0; pj[k] = 0; pi[k] = 0;
-            if (idx < LK_WIN * LK_WIN) {
-                const int j = idx / LK_WIN, i = idx - j * LK_WIN;
-                pj[k] = j; pi[k] = i;
-                const int *p = s_P + (j + 1) * 17 + (i + 1);
+            const int i = seg * 4 + k;
+            Pv[k] = 0; Ix[k] = 0; Iy[k] = 0;
+            if (row_ok && i < LK_WIN) {
+                const int *p = s_P + (lj + 1) * 17 + (i + 1);
                 const int sx = 3 * (p[-17 + 1] - p[-17 - 1]) + 10 * (p[1] - p[-1]) + 3 * (p[17 + 1] - p[17 - 1]);
                 const int sy = 3 * (p[17 - 1] - p[-17 - 1]) + 10 * (p[17] - p[-17]) + 3 * (p[17 + 1] - p[-17 + 1]);
                 const int gx = (sx + 16) >> 5, gy = (sy + 16) >> 5;
                 Pv[k] = p[0]; Ix[k] = gx; Iy[k] = gy;
-                A11 += (long long)gx * gx; A12 += (long long)gx * gy; A22 += (long long)gy * gy;
+                A11 += gx * gx; A12 += gx * gy; A22 += gy * gy;
             }
         }
-        A11 = wave_sum_i64(A11); A12 = wave_sum_i64(A12); A22 = wave_sum_i64(A22);
-        const double a11 = (double)A11 * FLT_SCALE, a12 = (double)A12 * FLT_SCALE, a22 = (double)A22 * FLT_SCALE;
+        const long long A11s = wave_sum_rows(A11), A12s = wave_sum_rows(A12), A22s = wave_sum_rows(A22);
+        const double a11 = (double)A11s * FLT_SCALE, a12 = (double)A12s * FLT_SCALE, a22 = (double)A22s * FLT_SCALE;
         double D = a11 * a22 - a12 * a12;
         const double dd = a11 - a22;
         const double minEig = (a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12)) / (2.0 * LK_WIN * LK_WIN);
@@ -295,24 +405,40 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
         D = 1.0 / D;
         float wx = ncx - (float)LK_HALF, wy = ncy - (float)LK_HALF;
         float pdx = 0.f, pdy = 0.f;
+        int bx0 = 0, by0 = 0;
+        bool staged = false;
         for (int it = 0; it < LK_ITERS; ++it) {
             const int inx = (int)floorf(wx), iny = (int)floorf(wy);
             if (inx < -LK_WIN || inx >= bw || iny < -LK_WIN || iny >= bh) {
                 if (l == 0) status = 0;
                 break;
             }
+            int ox = inx - bx0, oy = iny - by0;
+            // the lanes read columns ox .. ox+16 and rows oy .. oy+15 of the staged region
+            if (!staged || ox < 0 || ox > LK_RS - 17 || oy < 0 || oy > LK_RH - 16) {
+                bx0 = (inx - 8) & ~3; by0 = iny - 8;
+                __syncthreads();
+                lk_stage(imB, bw, bh, bx0, by0, LK_RH, s_R);
+                __syncthreads();
+                staged = true;
+                ox = inx - bx0; oy = iny - by0;
+            }
             bilinear_weights(wx - (float)inx, wy - (float)iny, w00, w01, w10, w11);
-            long long b1 = 0, b2 = 0;
+            const uint8_t *q = s_Rb + (oy + lj) * LK_RS + ox + seg * 4;
+            int p0[5], p1[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { p0[k] = q[k]; p1[k] = q[LK_RS + k]; }
+            int b1 = 0, b2 = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (lane + 64 * k < LK_WIN * LK_WIN) {
-                    const int diff = sample5(imB, bw, bh, inx + pi[k], iny + pj[k], w00, w01, w10, w11) - Pv[k];
-                    b1 += (long long)(diff * Ix[k]);
-                    b2 += (long long)(diff * Iy[k]);
-                }
+                const int sv = p0[k] * w00 + p0[k + 1] * w01 + p1[k] * w10 + p1[k + 1] * w11;
+                // masked pixels carry Ix = Iy = 0, so they add nothing
+                const int diff = ((sv + 256) >> 9) - Pv[k];
+                b1 += diff * Ix[k];
+                b2 += diff * Iy[k];
             }
-            b1 = wave_sum_i64(b1); b2 = wave_sum_i64(b2);
-            const double db1 = (double)b1 * FLT_SCALE, db2 = (double)b2 * FLT_SCALE;
+            const long long b1s = wave_sum_rows(b1), b2s = wave_sum_rows(b2);
+            const double db1 = (double)b1s * FLT_SCALE, db2 = (double)b2s * FLT_SCALE;
             const float dx = (float)((a12 * db2 - a22 * db1) * D);
             const float dy = (float)((a12 * db1 - a11 * db2) * D);
             wx += dx; wy += dy;
@@ -334,6 +460,7 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams) {
     const int pt = blockIdx.x;
     if (pt >= S.n_pts) return;
     __shared__ int s_P[17 * 17];
+    __shared__ uint32_t s_R[LK_RS * LK_RH / 4];
     const int W = S.curr0.w[0], H = S.curr0.h[0];
     const mskf_point2f pin = S.in_pts[pt];
     int st_bits = 0;
@@ -348,7 +475,7 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams) {
         const double Z = Hm[6] * px + Hm[7] * py + Hm[8] * 1.0;
         float bx = (float)(X / Z), by = (float)(Y / Z);
         int st;
-        lk_point(S.prev0, S.curr0, pin.x, pin.y, bx, by, st, s_P);
+        lk_point(S.prev0, S.curr0, pin.x, pin.y, bx, by, st, s_P, s_R);
         c0x = bx; c0y = by;
         // :416-424
         if (st && (c0y < 0 || c0y > (float)(H - 1) || c0x < 0 || c0x > (float)(W - 1))) st = 0;
@@ -364,7 +491,7 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams) {
         undistort_pt(S.cam0, S.R01, c0x, c0y, rx, ry);
         distort_pt(S.cam1, rx, ry, c1x, c1y);
         int st;
-        lk_point(S.curr0, S.curr1, c0x, c0y, c1x, c1y, st, s_P);
+        lk_point(S.curr0, S.curr1, c0x, c0y, c1x, c1y, st, s_P, s_R);
         // :575-583
         const int W1 = S.curr1.w[0], H1 = S.curr1.h[0];
         if (st && (c1y < 0 || c1y > (float)(H1 - 1) || c1x < 0 || c1x > (float)(W1 - 1))) st = 0;

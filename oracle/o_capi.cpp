@@ -37,6 +37,10 @@ void orc_build_pyramid(const uint8_t *src, int w, int h, uint8_t *dst) {
     for (int l = 1; l < LK_LEVELS; ++l) { std::memcpy(dst + off, pyr[l].d.data(), pyr[l].d.size()); off += pyr[l].d.size(); }
 }
 
+void orc_lk_stats(long long *out3, int reset) {
+    for (int i = 0; i < 3; ++i) { out3[i] = g_lk_stats[i]; if (reset) g_lk_stats[i] = 0; }
+}
+
 void orc_lk_track(const uint8_t *imgA, const uint8_t *imgB, int w, int h, int n, const mskf_point2f *ptsA,
                   mskf_point2f *ptsB, uint8_t *status) {
     std::vector<Img> pa, pb;

@@ -72,12 +72,16 @@ static inline int sample5(const Img &im, int x, int y, int w00, int w01, int w10
     return (s + 256) >> 9;
 }
 
+// work counters for sizing the GPU kernel: [0] points, [1] levels solved, [2] iterations
+long long g_lk_stats[3] = {0, 0, 0};
+
 void lk_track_point(const std::vector<Img> &pyrA, const std::vector<Img> &pyrB,
                     float ax, float ay, float &bx, float &by, uint8_t &status) {
     const double FLT_SCALE = 1.0 / (1 << 20);
     const double MIN_EIG = 1e-4;
     const double EPS2 = 0.01 * 0.01;
     status = 1;
+    ++g_lk_stats[0];
     float ncx = 0.f, ncy = 0.f;  // next point, centre coordinates, current level
     for (int l = LK_LEVELS - 1; l >= 0; --l) {
         const Img &A = pyrA[l];
@@ -124,6 +128,7 @@ void lk_track_point(const std::vector<Img> &pyrA, const std::vector<Img> &pyrB,
             continue;
         }
         D = 1.0 / D;
+        ++g_lk_stats[1];
 
         float wx = ncx - (float)LK_HALF_WIN, wy = ncy - (float)LK_HALF_WIN;
         float pdx = 0.f, pdy = 0.f;
@@ -134,6 +139,7 @@ void lk_track_point(const std::vector<Img> &pyrA, const std::vector<Img> &pyrB,
                 break;
             }
             bilinear_weights(wx - (float)inx, wy - (float)iny, w00, w01, w10, w11);
+            ++g_lk_stats[2];
             int64_t b1 = 0, b2 = 0;
             for (int j = 0; j < 15; ++j)
                 for (int i = 0; i < 15; ++i) {

@@ -67,4 +67,5 @@ void undistort_point(const CamModel &cam, const double R[9], const double Pnew[4
                      float u, float v, float &xo, float &yo);
 void distort_point(const CamModel &cam, float x, float y, float &uo, float &vo);
 
+extern long long g_lk_stats[3];  // [points, levels solved, iterations] since the last reset (test sizing aid)
 }  // namespace orc
