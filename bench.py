@@ -73,7 +73,7 @@ def render_sequences(oracle_py, args, rank, n_keys):
         frames[u, 0, k] = a
         frames[u, 1, k] = b
         syns[u]._cache.clear()
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
+    with ThreadPoolExecutor(max_workers=min(14, os.cpu_count() or 8)) as ex:
         list(ex.map(job, [(u, k) for u in range(args.unique) for k in range(n_keys)]))
     return syns, frames
 
@@ -95,6 +95,20 @@ def cpu_baseline(oracle_py, syn, fe, ekf, prime, frames):
     syn.feed(osys, frames, start=prime)
     dt = time.perf_counter() - t0
     return frames / dt, dt
+
+
+def cgroup_cpu():
+    """(cpu quota in cores or None, throttled microseconds so far or None) of this process's cgroup (v2)."""
+    quota, thr = None, None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                thr = int(line.split()[1])
+    except (OSError, ValueError):
+        pass
+    return quota, thr
 
 
 def main():
@@ -160,10 +174,12 @@ def main():
     run.get_timing(reset=True)
     run.get_phases(reset=True)
     barrier()
+    cpu_quota, thr0 = cgroup_cpu()
     t0 = time.perf_counter()
     run.run(args.prime + args.warmup, args.steps, pipelined=pipe)   # EXACTLY K timed steps
     barrier()
     elapsed = time.perf_counter() - t0
+    _, thr1 = cgroup_cpu()
     timing = run.get_timing(reset=True)
     phases = run.get_phases(reset=True)
     run.set_timing(False)
@@ -212,7 +228,9 @@ def main():
                                    % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads,
                                       ", FE|EKF pipelined" if pipe else ""),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
-                       "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1)},
+                       "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1),
+                       "host_cpu_quota": cpu_quota,
+                       "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "roofline": roof, "kernels": kernels,
             "host_phases_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in phases.items()},
         }

@@ -41,6 +41,10 @@ const char *mskf_last_error(void);
 int mskf_abi_version(void);
 
 int mskf_ctx_create(int device, mskf_ctx **out);
+/* Same, with the context's HIP stream created at the device's most urgent priority when high_priority != 0.
+ * The batch runner puts the filter stage of a pipelined group (the serial dependency chain of the step) on such a
+ * context so that its short kernels are dispatched ahead of the front-end's wide ones. */
+int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **out);
 void mskf_ctx_destroy(mskf_ctx *ctx);
 int mskf_ctx_sync(mskf_ctx *ctx);
 /* the HIP stream of this context as a void* (hipStream_t), for event timing by the caller */

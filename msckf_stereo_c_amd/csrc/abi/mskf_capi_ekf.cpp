@@ -299,7 +299,7 @@ extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *con
     MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.d, ctx->pred_arena.h, desc_bytes, hipMemcpyHostToDevice, st));
     ekf_launch_posvar((const EkfStreamDev *)ctx->pred_arena.d, n, (double *)(ctx->pred_arena.d + desc_bytes), st);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.h + desc_bytes, ctx->pred_arena.d + desc_bytes, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-    MSKF_HIPCHK(hipStreamSynchronize(st));
+    { const int wrc = mskf_wait(ctx); if (wrc != MSKF_OK) return wrc; }
     mskf_t_collect(ctx);
     std::memcpy(out, ctx->pred_arena.h + desc_bytes, sizeof(double) * 3 * (size_t)n);
     return MSKF_OK;
@@ -536,7 +536,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
-        MSKF_HIPCHK(hipStreamSynchronize(st));
+        if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
         mskf_t_collect(ctx);
     }
     for (int i = 0; i < n; ++i) {

@@ -1,5 +1,6 @@
 // mskf_capi_fe.cpp — C-ABI: contexts, streams and the front-end entry points (include/mskf_hip.h).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include "mskf_internal.h"
@@ -10,7 +11,9 @@ void mskf_set_error(const std::string &s) { g_last_error = s; }
 extern "C" const char *mskf_last_error(void) { return g_last_error.c_str(); }
 extern "C" int mskf_abi_version(void) { return 1; }
 
-extern "C" int mskf_ctx_create(int device, mskf_ctx **out) {
+extern "C" int mskf_ctx_create(int device, mskf_ctx **out) { return mskf_ctx_create_prio(device, 0, out); }
+
+extern "C" int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **out) {
     if (!out) return MSKF_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -21,8 +24,16 @@ extern "C" int mskf_ctx_create(int device, mskf_ctx **out) {
     MSKF_HIPCHK(hipSetDevice(device));
     mskf_ctx *c = new mskf_ctx();
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e;
+    if (high_priority) {
+        int lo = 0, hi = 0;   // numerically lower = more urgent
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) { delete c; mskf_set_error(hipGetErrorString(e)); return MSKF_ERR_HIP; }
+    { const char *w = std::getenv("MSKF_WAIT"); c->wait_block = w && std::strcmp(w, "block") == 0; }
     *out = c;
     return MSKF_OK;
 }
@@ -39,13 +50,25 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     c->ekf_desc.release();
     c->pred_arena.release();
     if (c->pred_done) (void)hipEventDestroy(c->pred_done);
+    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
+int mskf_wait(mskf_ctx *c) {
+    if (c->wait_block) {
+        if (!c->wait_ev) MSKF_HIPCHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming | hipEventBlockingSync));
+        MSKF_HIPCHK(hipEventRecord(c->wait_ev, c->stream));
+        MSKF_HIPCHK(hipEventSynchronize(c->wait_ev));
+        return MSKF_OK;
+    }
+    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    return MSKF_OK;
+}
+
 extern "C" int mskf_ctx_sync(mskf_ctx *c) {
     if (!c) return MSKF_ERR_INVALID;
-    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+    { const int rc = mskf_wait(c); if (rc != MSKF_OK) return rc; }
     mskf_t_collect(c);
     return MSKF_OK;
 }
@@ -394,7 +417,7 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     mskf_t_end(ctx, ts_lk, 0);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
     MSKF_HIPCHK(hipGetLastError());
-    MSKF_HIPCHK(hipStreamSynchronize(st));
+    if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
     long long tracks = 0;
     for (int i = 0; i < n; ++i) {
         const mskf_fe_track_args &a = args[i];

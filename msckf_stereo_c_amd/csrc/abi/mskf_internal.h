@@ -12,6 +12,10 @@ struct PyrJob { const uint8_t *src; uint8_t *dst; int sw, sh, dw, dh; };
 
 extern "C" {
 void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t st);
+// Host wait for everything queued on the context's stream.  MSKF_WAIT=block (default when the process runs
+// more waiting host threads than it has cores to spin on) parks the thread on an interrupt-driven event instead of
+// spinning in hipStreamSynchronize, leaving the core to the other groups' host phases.
+int mskf_wait(mskf_ctx *c);
 void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, hipStream_t st);
 void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st);
 }
@@ -58,6 +62,8 @@ struct mskf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
+    hipEvent_t wait_ev = nullptr;     // blocking-sync event of mskf_wait (MSKF_WAIT=block)
+    bool wait_block = false;
     PinnedDev<char> cell_arena;       // per-cell maximum keys of every stream of the last push batch (one D2H copy)
     PinnedDev<char> trk_in, trk_out;  // input points / results of every stream of a track batch (one copy each way)
     unsigned long long push_gen = 0;

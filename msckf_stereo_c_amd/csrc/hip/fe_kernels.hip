@@ -278,9 +278,12 @@ __device__ __forceinline__ int px_clamped(const uint8_t *img, int w, int h, int 
     return img[(size_t)y * w + x];
 }
 
+// The fractional offsets are wave-uniform; readfirstlane moves the fixed-point weight arithmetic to the scalar unit.
 __device__ __forceinline__ void bilinear_weights(float fa, float fb, int &w00, int &w01, int &w10, int &w11) {
-    const int qa = __float2int_rn(fa * 16384.0f);
-    const int qb = __float2int_rn(fb * 16384.0f);
+    int qa = __float2int_rn(fa * 16384.0f), qb = __float2int_rn(fb * 16384.0f);
+    asm volatile("" : "+v"(qa), "+v"(qb));     // keep the conversion ahead of the broadcast (no scalar float->int)
+    qa = __builtin_amdgcn_readfirstlane(qa);
+    qb = __builtin_amdgcn_readfirstlane(qb);
     w00 = ((16384 - qa) * (16384 - qb) + 8192) >> 14;
     w01 = (qa * (16384 - qb) + 8192) >> 14;
     w10 = ((16384 - qa) * qb + 8192) >> 14;
@@ -344,6 +347,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
     const int lane = threadIdx.x & 63;
     const int lj = min(lane >> 2, LK_WIN - 1), seg = lane & 3;
     const bool row_ok = (lane >> 2) < LK_WIN;
+    const int lane_off = lj * LK_RS + seg * 4;
     const uint8_t *s_Rb = (const uint8_t *)s_R;
     const double FLT_SCALE = 1.0 / (double)(1 << 20);
     status = 1;
@@ -356,7 +360,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
         const float pwx = ax * sc - (float)LK_HALF, pwy = ay * sc - (float)LK_HALF;
         if (l == MSKF_LEVELS - 1) { ncx = bx * sc; ncy = by * sc; }
         else { ncx = ncx * 2.0f; ncy = ncy * 2.0f; }
-        const int ipx = (int)floorf(pwx), ipy = (int)floorf(pwy);
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(pwx)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(pwy));   // wave-uniform
         if (ipx < -LK_WIN || ipx >= aw || ipy < -LK_WIN || ipy >= ah) {
             if (l == 0) status = 0;
             continue;
@@ -390,7 +394,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
                 const int sy = 3 * (p[17 - 1] - p[-17 - 1]) + 10 * (p[17] - p[-17]) + 3 * (p[17 + 1] - p[-17 + 1]);
                 const int gx = (sx + 16) >> 5, gy = (sy + 16) >> 5;
                 Pv[k] = p[0]; Ix[k] = gx; Iy[k] = gy;
-                A11 += gx * gx; A12 += gx * gy; A22 += gy * gy;
+                A11 += __mul24(gx, gx); A12 += __mul24(gx, gy); A22 += __mul24(gy, gy);
             }
         }
         const long long A11s = wave_sum_rows(A11), A12s = wave_sum_rows(A12), A22s = wave_sum_rows(A22);
@@ -408,7 +412,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
         int bx0 = 0, by0 = 0;
         bool staged = false;
         for (int it = 0; it < LK_ITERS; ++it) {
-            const int inx = (int)floorf(wx), iny = (int)floorf(wy);
+            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(wx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(wy));
             if (inx < -LK_WIN || inx >= bw || iny < -LK_WIN || iny >= bh) {
                 if (l == 0) status = 0;
                 break;
@@ -424,7 +428,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
                 ox = inx - bx0; oy = iny - by0;
             }
             bilinear_weights(wx - (float)inx, wy - (float)iny, w00, w01, w10, w11);
-            const uint8_t *q = s_Rb + (oy + lj) * LK_RS + ox + seg * 4;
+            const uint8_t *q = s_Rb + lane_off + (oy * LK_RS + ox);
             int p0[5], p1[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) { p0[k] = q[k]; p1[k] = q[LK_RS + k]; }
@@ -434,8 +438,8 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
                 const int sv = p0[k] * w00 + p0[k + 1] * w01 + p1[k] * w10 + p1[k + 1] * w11;
                 // masked pixels carry Ix = Iy = 0, so they add nothing
                 const int diff = ((sv + 256) >> 9) - Pv[k];
-                b1 += diff * Ix[k];
-                b2 += diff * Iy[k];
+                b1 += __mul24(diff, Ix[k]);       // |diff| <= 8160, |I| <= 4080: exact in the 24-bit multiplier
+                b2 += __mul24(diff, Iy[k]);
             }
             const long long b1s = wave_sum_rows(b1), b2s = wave_sum_rows(b2);
             const double db1 = (double)b1s * FLT_SCALE, db2 = (double)b2s * FLT_SCALE;

@@ -1,5 +1,6 @@
 // batch_runner.cpp — see batch_runner.h.
 #include "batch_runner.h"
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <deque>
@@ -42,7 +43,10 @@ void ForkJoin::run(int n, const std::function<void(int)> &fn) {
 BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads) {
     if (host_threads > 1) { pool_.reset(new ForkJoin(host_threads)); pool_ekf_.reset(new ForkJoin(host_threads)); }
     int rc = mskf_ctx_create(device, &ctx_);
-    if (rc == MSKF_OK) rc = mskf_ctx_create(device, &ctx_ekf_);
+    if (rc == MSKF_OK) {
+        const char *pe = std::getenv("MSKF_EKF_PRIORITY");   // default on; MSKF_EKF_PRIORITY=0 disables
+        rc = mskf_ctx_create_prio(device, !(pe && pe[0] == '0'), &ctx_ekf_);
+    }
     if (rc != MSKF_OK) { error_ = mskf_last_error(); return; }
     for (int i = 0; i < n; ++i) {
         systems_.emplace_back(new System(calib, fe, ekf, ctx_, device));
