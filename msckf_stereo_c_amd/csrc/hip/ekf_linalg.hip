@@ -2,21 +2,21 @@
 // one job per VIO stream, blockIdx.y = stream of the batch:
 //
 //  k_ekf_gemm   : 32x32 output tile per workgroup, v_mfma_f64_16x16x4_f64 (one 16x16 sub-tile per wave,
-//                 K staged through LDS 16 at a time).  Modes:
+//                 K staged through LDS 32 at a time, next stage prefetched into registers).  Modes:
 //                   GRAM  G  = [Hs|rs]^T [Hs|rs]          ((d+1)x(d+1), replaces the QR: G = R^T R, last row = (Q^T r)^T R)
 //                   T     T  = R P,  R = L^T upper        (skips the zero half of R)
 //                   S2    S  = T R^T + sigma^2 I          (symmetric, lower computed and mirrored)
 //                   PUPD  P <- P - Y^T Y                  (symmetric)
-//  k_ekf_chol   : blocked (NB = 16) right-looking Cholesky in place, one workgroup per stream; the
-//                 semidefinite variant skips pivots <= tol (zero IMU columns / gauge directions of H^T H)
-//                 and carries extra rows (the Q^T r row) through the panel solves only.
+//  k_ekf_chol   : blocked (NB = 16) right-looking Cholesky in place, one workgroup per stream; the Gram
+//                 variant factors G + lambda I (lambda = 1e-14 d max diag: G is rank deficient and an unpivoted
+//                 factorisation of it is unstable) and carries the extra Q^T r row through the panel solves.
 //  k_ekf_trsm   : Y = L^-1 [T | Q^T r] in place, one workgroup per 32-column strip and stream.
 //  k_ekf_dx     : delta_x = Y^T w (w = column d of Y).
 //
 // Why Gram + Cholesky instead of Householder QR: the update only needs R^T R = H^T H and R^T (Q^T r) =
 // H^T r; forming them is one GEMM-shaped pass over the stacked Jacobian (MFMA-friendly, fully parallel
 // over output tiles) instead of d sequential reflector applications.  H^T H is rank deficient (the 21
-// IMU columns of H are zero, the gauge is unobservable): skipped pivots drop exactly those directions.
+// IMU columns of H are zero, unobserved clones, the gauge): the factorisation is regularised, see k_ekf_chol_lds.
 #include <mutex>
 #include "ekf_device.h"
 
@@ -24,52 +24,37 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
 
-struct GemmArgs {
-    const double *A, *B;
-    double *C;
-    int M, N, K, lda, ldb, ldc;
-    int transA, transB;     // op(A)(i,k) = transA ? A[k*lda+i] : A[i*lda+k] ; op(B)(k,j) = transB ? B[j*ldb+k] : B[k*ldb+j]
-    int sym;                // compute tiles with j0 <= i0 only, mirror
-    int kmin_i, kmin_j;     // op(A)(i,k) == 0 for k < i  /  op(B)(k,j) == 0 for k < j
-    double alpha, beta, diag_add;
-};
-
-__device__ __forceinline__ bool gemm_setup(const EkfStreamDev &S, int mode, GemmArgs &g) {
-    const int d = S.d, ld = S.ld;
-    g.sym = 0; g.kmin_i = 0; g.kmin_j = 0; g.alpha = 1.0; g.beta = 0.0; g.diag_add = 0.0;
-    g.lda = g.ldb = g.ldc = ld;
-    switch (mode) {
-        case GM_GRAM:
-            g.A = S.Hs; g.B = S.Hs; g.C = S.S; g.M = g.N = d + 1; g.K = S.rows_out[1]; g.transA = 1; g.transB = 0; g.sym = 1;
-            return true;
-        case GM_T:
-            g.A = S.S; g.B = S.P; g.C = S.T; g.M = d; g.N = d; g.K = d; g.transA = 1; g.transB = 0; g.kmin_i = 1;
-            return true;
-        case GM_S2:
-            g.A = S.T; g.B = S.S; g.C = S.W; g.M = d; g.N = d; g.K = d; g.transA = 0; g.transB = 0; g.sym = 1; g.kmin_j = 1;
-            g.diag_add = S.sigma2;
-            return true;
-        case GM_PUPD:
-            g.A = S.T; g.B = S.T; g.C = S.P; g.M = d; g.N = d; g.K = d; g.transA = 1; g.transB = 0; g.sym = 1;
-            g.alpha = -1.0; g.beta = 1.0;
-            return true;
-    }
-    return false;
-}
+// Per-mode compile-time shape of op(A) op(B): TA: op(A)(i,k) = A[k*ld+i] (else A[i*ld+k]); B is always B[k*ld+j].
+// KMIN_I: op(A)(i,k) == 0 for k < i (R = L^T is upper triangular); KMIN_J: op(B)(k,j) == 0 for k < j.
+template <int MODE> struct GemmTraits;
+template <> struct GemmTraits<GM_GRAM> { static constexpr bool TA = true,  SYM = true,  KMIN_I = false, KMIN_J = false; };
+template <> struct GemmTraits<GM_T>    { static constexpr bool TA = true,  SYM = false, KMIN_I = true,  KMIN_J = false; };
+template <> struct GemmTraits<GM_S2>   { static constexpr bool TA = false, SYM = true,  KMIN_I = false, KMIN_J = true;  };
+template <> struct GemmTraits<GM_PUPD> { static constexpr bool TA = true,  SYM = true,  KMIN_I = false, KMIN_J = false; };
 
 #define GT 32      // output tile edge
-#define GK 16      // K per LDS stage
+#define GK 32      // K per LDS stage
 
-__global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams, int mode) {
+// One 32x32 output tile per workgroup (one 16x16 MFMA sub-tile per wave).  The K loop is software pipelined:
+// the global loads of stage s+1 are issued into registers before the MFMAs of stage s, so a stage costs an LDS
+// round trip instead of an HBM/L2 round trip.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
+    using TR = GemmTraits<MODE>;
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
-    GemmArgs g;
-    gemm_setup(S, mode, g);
-    const int tiles_n = (g.N + GT - 1) / GT, tiles_m = (g.M + GT - 1) / GT;
+    const int d = S.d, ld = S.ld;
+    const double *__restrict__ A; const double *__restrict__ B; double *C;
+    int M, N, K;
+    double alpha = 1.0, beta = 0.0, diag_add = 0.0;
+    if (MODE == GM_GRAM)      { A = S.Hs; B = S.Hs; C = S.S; M = N = d + 1; K = S.rows_out[1]; }
+    else if (MODE == GM_T)    { A = S.S;  B = S.P;  C = S.T; M = N = d; K = d; }
+    else if (MODE == GM_S2)   { A = S.T;  B = S.S;  C = S.W; M = N = d; K = d; diag_add = S.sigma2; }
+    else                      { A = S.T;  B = S.T;  C = S.P; M = N = d; K = d; alpha = -1.0; beta = 1.0; }
+    const int tiles_n = (N + GT - 1) / GT, tiles_m = (M + GT - 1) / GT;
     const int tile = blockIdx.x;
-    if (mode == GM_PUPD && tile == tiles_m * tiles_n) {
+    if (MODE == GM_PUPD && tile == tiles_m * tiles_n) {
         // one extra workgroup: delta_x = Y^T w, w = column d of Y (msckf_vio.cpp:860)
-        const int d = S.d, ld = S.ld;
         for (int c = threadIdx.x; c < d; c += 256) {
             double s2 = 0;
             for (int k = 0; k < d; ++k) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
@@ -79,38 +64,43 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams, i
     }
     if (tile >= tiles_m * tiles_n) return;
     const int ti = tile / tiles_n, tj = tile - ti * tiles_n;
-    if (g.sym && tj > ti) return;
+    if (TR::SYM && tj > ti) return;
     const int i0 = ti * GT, j0 = tj * GT;
     __shared__ double sA[GK][GT + 1];   // sA[k][i]
     __shared__ double sB[GK][GT + 1];   // sB[k][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    const int lo = tid & 31, hi = tid >> 5;          // hi in [0,8)
     int k_begin = 0;
-    if (g.kmin_i) k_begin = (i0 / GK) * GK;
-    if (g.kmin_j) { const int kb = (j0 / GK) * GK; k_begin = k_begin > kb ? k_begin : kb; }
-    if (g.kmin_i && g.kmin_j) { /* both given: the max above is already right */ }
-    for (int k0 = k_begin; k0 < g.K; k0 += GK) {
-        __syncthreads();
-        // stage op(A)[i0.., k0..] and op(B)[k0.., j0..]
+    if (TR::KMIN_I) k_begin = (i0 / GK) * GK;
+    if (TR::KMIN_J) k_begin = (j0 / GK) * GK;
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int ii, kk;
-            if (g.transA) { ii = tid & 31; kk = (tid >> 5) + 8 * e; }
-            else { kk = tid & 15; ii = (tid >> 4) + 16 * e; }
+        for (int e = 0; e < 4; ++e) {
+            // A: TA -> (i = lo, k = hi + 8e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + 8e) reads A[i*ld + k]
+            const int ii = TR::TA ? lo : hi + 8 * e, kk = TR::TA ? hi + 8 * e : lo;
             const int gi = i0 + ii, gk = k0 + kk;
             double v = 0.0;
-            if (gi < g.M && gk < g.K && !(g.kmin_i && gk < gi)) v = g.transA ? g.A[(size_t)gk * g.lda + gi] : g.A[(size_t)gi * g.lda + gk];
-            sA[kk][ii] = v;
-            int jj, kb;
-            if (g.transB) { kb = tid & 15; jj = (tid >> 4) + 16 * e; }
-            else { jj = tid & 31; kb = (tid >> 5) + 8 * e; }
-            const int gj = j0 + jj, gkb = k0 + kb;
+            if (gi < M && gk < K && !(TR::KMIN_I && gk < gi)) v = TR::TA ? A[(size_t)gk * ld + gi] : A[(size_t)gi * ld + gk];
+            ra[e] = v;
+            const int gj = j0 + lo, gkb = k0 + hi + 8 * e;
             double w = 0.0;
-            if (gj < g.N && gkb < g.K && !(g.kmin_j && gkb < gj)) w = g.transB ? g.B[(size_t)gj * g.ldb + gkb] : g.B[(size_t)gkb * g.ldb + gj];
-            sB[kb][jj] = w;
+            if (gj < N && gkb < K && !(TR::KMIN_J && gkb < gj)) w = B[(size_t)gkb * ld + gj];
+            rb[e] = w;
+        }
+    };
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    if (k_begin < K) fetch(k_begin);
+    for (int k0 = k_begin; k0 < K; k0 += GK) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (TR::TA) sA[hi + 8 * e][lo] = ra[e]; else sA[lo][hi + 8 * e] = ra[e];
+            sB[hi + 8 * e][lo] = rb[e];
         }
         __syncthreads();
+        if (k0 + GK < K) fetch(k0 + GK);
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             const int kk = 4 * s + (lane >> 4);
@@ -124,13 +114,13 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams, i
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + wi + (lane >> 4) + 4 * r;
         const int j = j0 + wj + (lane & 15);
-        if (i >= g.M || j >= g.N) continue;
-        if (g.sym && j > i) continue;             // diagonal tiles: lower part only, mirrored below
-        double v = g.alpha * acc[r];
-        if (g.beta != 0.0) v += g.beta * g.C[(size_t)i * g.ldc + j];
-        if (i == j) v += g.diag_add;
-        g.C[(size_t)i * g.ldc + j] = v;
-        if (g.sym && i != j) g.C[(size_t)j * g.ldc + i] = v;
+        if (i >= M || j >= N) continue;
+        if (TR::SYM && j > i) continue;             // diagonal tiles: lower part only, mirrored below
+        double v = alpha * acc[r];
+        if (MODE == GM_PUPD) v += beta * C[(size_t)i * ld + j];
+        if (i == j) v += diag_add;
+        C[(size_t)i * ld + j] = v;
+        if (TR::SYM && i != j) C[(size_t)j * ld + i] = v;
     }
 }
 
@@ -153,17 +143,20 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
     __shared__ double s_tol;
     const int tid = threadIdx.x;
     if (c.semidef) {
-        // tolerance relative to the largest diagonal entry
+        // regularised factorisation G + lambda I, lambda = 1e-14 d max(diag G) (see k_ekf_chol_lds)
         double mx = 0;
         for (int i = tid; i < n; i += 256) mx = fmax(mx, A[(size_t)i * lda + i]);
         for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
         __shared__ double s_mx[4];
         if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
         __syncthreads();
-        if (tid == 0) s_tol = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3])) * (double)n * 2.220446049250313e-16;
-    } else if (tid == 0) s_tol = 0.0;
-    __syncthreads();
-    const double tol = s_tol;
+        if (tid == 0) s_tol = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3])) * (double)n * 1e-14;
+        __syncthreads();
+        const double lam = s_tol;
+        for (int i = EKF_IMU_DIM + tid; i < n; i += 256) A[(size_t)i * lda + i] += lam;   // clone block only, as the LDS kernel
+        __syncthreads();
+    }
+    const double tol = 0.0;
     for (int kb = 0; kb < n; kb += CNB) {
         const int nb = min(CNB, n - kb);
         // 1. diagonal block
@@ -238,9 +231,38 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
 // Structure used: the 21 IMU columns of every stacked Jacobian are zero (H_x only touches clone columns,
 // msckf_vio.cpp:698,713), so rows/cols [0,21) of G = [H|r]^T[H|r] are exactly zero (pivots skipped, L = 0)
 // and rows/cols [0,21) of S = T R^T + sigma^2 I are sigma^2 I (L = sigma I).  Only the trailing
-// (d-21) x (d-21) block is factorised: <= 180 rows for 30 clones = 127 KiB packed + an 8-wide panel.
-#define LNB 8
+// (d-21) x (d-21) block is factorised: <= 180 rows for 30 clones = 129 KiB packed + a 16-wide panel.
+//
+// Right-looking, 16 columns per panel, one 1024-thread workgroup (16 waves) per stream:
+//   1. wave 0 factors the 16x16 diagonal block in registers: lane r owns row r, the pivot and the column
+//      entries travel through v_readlane (no LDS round trips, no barriers inside the block); 1/sqrt(pivot)
+//      comes from v_rsq_f64 + two Newton steps, so the serial chain has no division;
+//   2. one thread per row below solves x L11^T = a against L11 broadcast from LDS and leaves the panel k-major
+//      (sPanT[c][row]) for the MFMA operands;
+//   3. the trailing update A22 -= X X^T runs on v_mfma_f64_16x16x4_f64, one 16x16 tile of the lower triangle at
+//      a time per wave (4 MFMAs per tile), read-modify-write on the packed matrix.
+#define LNB 16
 #define CHOL_LDS_MAX_ROWS 181     // active rows incl. the extra Q^T r row
+#define CHOL_PAN_RS 192           // row stride of the k-major panel (rows padded to a multiple of 16)
+
+__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// 1/sqrt(x) to double precision without a division: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
 __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
@@ -251,90 +273,139 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
     const bool semidef = which == 0;
     extern __shared__ double s_dyn[];
     double *sM = s_dyn;                            // packed lower, nt rows
-    double *sPan = s_dyn + (size_t)nt * (nt + 1) / 2;   // [nt][LNB]
-    __shared__ double s_tol, s_mx[16];
-    const int tid = threadIdx.x;
-    // load (row-wise, coalesced along j)
-    for (int e = tid; e < nt * nt; e += 1024) {
-        const int i = e / nt, j = e - i * nt;
-        if (j <= i) sM[(size_t)i * (i + 1) / 2 + j] = A[(size_t)(off + i) * lda + off + j];
+    double *sPanT = s_dyn + nt * (nt + 1) / 2;     // [LNB][CHOL_PAN_RS]
+    __shared__ double s_tol, s_mx[16], s_L11[LNB][LNB + 1], s_inv[LNB];   // s_L11[j][c] = L11[c][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // load: one matrix row per wave pass, coalesced along j
+    for (int i = wave; i < nt; i += 16) {
+        const double *src = A + (size_t)(off + i) * lda + off;
+        double *dst = sM + pk(i, 0);
+        for (int j = lane; j <= i; j += 64) dst[j] = src[j];
     }
+    for (int e = tid; e < LNB * CHOL_PAN_RS; e += 1024) sPanT[e] = 0.0;
     __syncthreads();
     if (semidef) {
+        // G = H^T H is rank deficient (unobserved clones, the gauge) and its small pivots are rounding noise:
+        // an unpivoted Cholesky that skips or keeps them by a threshold is unstable (measured: up to 7e-5
+        // relative error in P on few-feature updates, tools/dev/update_truth.py).  Factor G + lambda I instead,
+        // lambda = 1e-14 d max(diag G): every pivot stays above the noise, nothing is skipped, and the only effect
+        // is a prior of weight lambda / sigma^2 on the clone states (bias ~1e-11 relative, same tool).
         double mx = 0;
-        for (int i = tid; i < n; i += 1024) mx = fmax(mx, sM[(size_t)i * (i + 1) / 2 + i]);
+        for (int i = tid; i < n; i += 1024) mx = fmax(mx, sM[pk(i, i)]);
         for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-        if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
+        if (lane == 0) s_mx[wave] = mx;
         __syncthreads();
-        if (tid == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, s_mx[i]); s_tol = m * (double)S.d * 2.220446049250313e-16; }
-    } else if (tid == 0) s_tol = 0.0;
-    __syncthreads();
-    const double tol = s_tol;
+        if (tid == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, s_mx[i]); s_tol = m * (double)S.d * 1e-14; }
+        __syncthreads();
+        const double lam = s_tol;
+        for (int i = tid; i < n; i += 1024) sM[pk(i, i)] += lam;
+        __syncthreads();
+    }
+    const double tol = 0.0;      // a pivot <= 0 (cannot happen for G + lambda I or for S >= sigma^2 I) zeroes its column
     for (int kb = 0; kb < n; kb += LNB) {
         const int nb = min(LNB, n - kb);
-        // 1. diagonal block, in place in sM, by wave 0
-        if (tid < 64) {
-            for (int j = 0; j < nb; ++j) {
-                const double piv = sM[(size_t)(kb + j) * (kb + j + 1) / 2 + kb + j];
-                const bool skip = !(piv > tol);
-                const double l = skip ? 0.0 : sqrt(piv);
-                const double inv = skip ? 0.0 : 1.0 / l;
-                __builtin_amdgcn_wave_barrier();
-                if (tid >= j && tid < nb) {
-                    double *p = &sM[(size_t)(kb + tid) * (kb + tid + 1) / 2 + kb + j];
-                    *p = (tid == j) ? l : (*p) * inv;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // (i, c) with j < c <= i < nb
-                if (tid < LNB * LNB) {
-                    const int i = tid / LNB, cc = tid % LNB;
-                    if (cc > j && cc <= i && i < nb) {
-                        const size_t ri = (size_t)(kb + i) * (kb + i + 1) / 2 + kb, rc = (size_t)(kb + cc) * (kb + cc + 1) / 2 + kb;
-                        sM[ri + cc] -= sM[ri + j] * sM[rc + j];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+        // ---- 1. diagonal block in the registers of wave 0 (rows >= nb are padded with the identity)
+        if (wave == 0) {
+            int r = lane & 15;
+            asm volatile("" : "+v"(r));      // per-panel value: keeps 16 x 16 lane predicates from being hoisted and spilled
+            // Entries right of the diagonal (and rows past nb in the last panel) are whatever follows in LDS: they
+            // only ever feed other upper-triangle / padded entries, never the factor, and are masked on the way out.
+            double a[LNB];
+            {
+                const double *src = sM + pk(kb + r, kb);
+#pragma unroll
+                for (int c = 0; c < LNB; ++c) a[c] = src[c];
             }
-        }
-        __syncthreads();
-        // 2. panel rows below: x L11^T = a
-        const int r0 = kb + nb;
-        for (int i = r0 + tid; i < nt; i += 1024) {
-            double *row = &sM[(size_t)i * (i + 1) / 2 + kb];
-            double x[LNB];
+            double invd = 0.0;     // lane r keeps 1/L[r][r]
 #pragma unroll
             for (int j = 0; j < LNB; ++j) {
-                double s2 = (j < nb) ? row[j] : 0.0;
-                const size_t rj = (size_t)(kb + j) * (kb + j + 1) / 2 + kb;
+                const double piv = readlane_f64(a[j], j);
+                const bool skip = !(piv > tol);
+                const double y = skip ? 0.0 : rsqrt_nr(piv);
+                double l = piv * y;
+                l = skip ? 0.0 : fma(0.5 * y, fma(-l, l, piv), l);
+                if (r == j) { a[j] = l; invd = y; } else a[j] *= y;
 #pragma unroll
-                for (int cc = 0; cc < j; ++cc) s2 -= x[cc] * ((j < nb) ? sM[rj + cc] : 0.0);
-                const double ljj = (j < nb) ? sM[rj + j] : 0.0;
-                x[j] = (j < nb && ljj != 0.0) ? s2 / ljj : 0.0;
+                for (int c = j + 1; c < LNB; ++c) {
+                    const double lcj = readlane_f64(a[j], c);
+                    a[c] = fma(-a[j], lcj, a[c]);      // rows r < c carry unused upper-triangle values
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the unrolled columns in order (register pressure)
             }
+            if (lane < LNB) {
 #pragma unroll
-            for (int j = 0; j < LNB; ++j) { if (j < nb) row[j] = x[j]; sPan[(size_t)j * nt + (i - r0)] = x[j]; }
+                for (int c = 0; c < LNB; ++c) {
+                    const bool in = c <= r && r < nb;
+                    if (in) sM[pk(kb + r, kb + c)] = a[c];
+                    s_L11[c][r] = in ? a[c] : 0.0;
+                }
+                s_inv[r] = r < nb ? invd : 0.0;
+            }
         }
         __syncthreads();
-        // 3. trailing update (lower part; the extra row only against columns < n)
-        const int rem = nt - r0, remc = n - r0;
-        for (int e = tid; e < rem * remc; e += 1024) {
-            const int a = e / remc, b = e - a * remc;
-            if (b > a) continue;
-            double s2 = 0;
+        // ---- 2. panel rows below: x L11^T = a, one thread per row
+        const int r0 = kb + nb;
+        const int rem = nt - r0;
+        if (wave * 64 < rem) {           // wave-uniform: all 64 lanes take part in the broadcasts
+            // lanes 0..15 hold row (lane) of L11 and 1/diag; every lane owns one matrix row x
+            const int rr = lane & 15;
+            double Lr[LNB];
 #pragma unroll
-            for (int cc = 0; cc < LNB; ++cc) s2 += sPan[(size_t)cc * nt + a] * sPan[(size_t)cc * nt + b];
-            sM[(size_t)(r0 + a) * (r0 + a + 1) / 2 + r0 + b] -= s2;
+            for (int c = 0; c < LNB; ++c) Lr[c] = s_L11[c][rr];
+            const double invr = s_inv[rr];
+            const bool has_row = tid < rem;
+            const int i = r0 + (has_row ? tid : 0);
+            double *row = sM + pk(i, kb);
+            double x[LNB];
+#pragma unroll
+            for (int c = 0; c < LNB; ++c) x[c] = row[c];        // columns >= nb: finite filler, multiplied by 0 below
+#pragma unroll
+            for (int j = 0; j < LNB; ++j) {
+                x[j] *= readlane_f64(invr, j);
+#pragma unroll
+                for (int c = j + 1; c < LNB; ++c) x[c] = fma(-x[j], readlane_f64(Lr[j], c), x[c]);
+            }
+            if (has_row) {
+#pragma unroll
+                for (int c = 0; c < LNB; ++c) {
+                    if (c < nb) row[c] = x[c];
+                    sPanT[c * CHOL_PAN_RS + tid] = x[c];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. trailing update on the matrix cores: 16x16 tiles (ta, tb <= ta) of rows/cols r0 + ...
+        const int ntr = (rem + 15) >> 4;
+        const int n_tiles = ntr * (ntr + 1) / 2;
+        for (int t = wave; t < n_tiles; t += 16) {
+            int ta = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (ta * (ta + 1) / 2 > t) --ta;
+            while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
+            const int tb = t - ta * (ta + 1) / 2;
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < LNB / 4; ++s4) {
+                const double *pp = sPanT + (4 * s4 + (lane >> 4)) * CHOL_PAN_RS + (lane & 15);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[16 * ta], pp[16 * tb], acc, 0, 0, 0);
+            }
+            const int j = r0 + 16 * tb + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = r0 + 16 * ta + (lane >> 4) + 4 * q;
+                if (i < nt && j <= i) sM[pk(i, j)] -= acc[q];
+            }
         }
         __syncthreads();
     }
     // store back; the trivial IMU block: L = 0 (Gram) or sigma I (S)
-    for (int e = tid; e < nt * nt; e += 1024) {
-        const int i = e / nt, j = e - i * nt;
-        if (j <= i && j < n) A[(size_t)(off + i) * lda + off + j] = sM[(size_t)i * (i + 1) / 2 + j];
+    for (int i = wave; i < nt; i += 16) {
+        double *dst = A + (size_t)(off + i) * lda + off;
+        const double *src = sM + pk(i, 0);
+        for (int j = lane; j <= i && j < n; j += 64) dst[j] = src[j];
     }
     if (which == 0) {
         // column d of T <- (Q^T r) = row d of L, so the TRSM carries w = L2^-1 Q^T r along (IMU part is zero)
-        for (int k = tid; k < S.d; k += 1024) S.T[(size_t)k * lda + S.d] = (k < off) ? 0.0 : sM[(size_t)n * (n + 1) / 2 + (k - off)];
+        for (int k = tid; k < S.d; k += 1024) S.T[(size_t)k * lda + S.d] = (k < off) ? 0.0 : sM[pk(n, k - off)];
     }
     const double l0 = semidef ? 0.0 : sqrt(S.sigma2);
     const int rows_all = S.d + (which == 0 ? 1 : 0);
@@ -433,15 +504,21 @@ __global__ __launch_bounds__(256) void k_ekf_dx(const EkfStreamDev *streams) {
 extern "C" {
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st) {
     const int t = (max_mn + GT - 1) / GT;
-    hipLaunchKernelGGL(k_ekf_gemm, dim3(t * t + (mode == GM_PUPD ? 1 : 0), n), dim3(256), 0, st, d, mode);
+    const dim3 grid(t * t + (mode == GM_PUPD ? 1 : 0), n);
+    switch (mode) {
+        case GM_GRAM: hipLaunchKernelGGL(k_ekf_gemm<GM_GRAM>, grid, dim3(256), 0, st, d); break;
+        case GM_T:    hipLaunchKernelGGL(k_ekf_gemm<GM_T>, grid, dim3(256), 0, st, d); break;
+        case GM_S2:   hipLaunchKernelGGL(k_ekf_gemm<GM_S2>, grid, dim3(256), 0, st, d); break;
+        default:      hipLaunchKernelGGL(k_ekf_gemm<GM_PUPD>, grid, dim3(256), 0, st, d); break;
+    }
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
     const int nt = max_d - EKF_IMU_DIM + 1;
     if (nt <= CHOL_LDS_MAX_ROWS) {
         static std::once_flag attr_once;
     std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_LDS_MAX_ROWS * LNB) * sizeof(double))); });
-        const size_t lds = ((size_t)nt * (nt + 1) / 2 + (size_t)nt * LNB) * sizeof(double);
+                                      (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_PAN_RS * LNB) * sizeof(double))); });
+        const size_t lds = ((size_t)nt * (nt + 1) / 2 + (size_t)CHOL_PAN_RS * LNB) * sizeof(double);
         hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(1024), lds, st, d, which);
         return;
     }

@@ -153,6 +153,17 @@ int orc_system_map_size(void *h) { return (int)((OSystem *)h)->vio.map_server.si
 //   features: position[3] per feature, obs_start[n_feat+1], obs_clone[n_obs], obs_z[n_obs*4]
 //   dof_offset: gating dof = n_obs_j + dof_offset (-1 lost features, 0 pruning; Q12)
 // Outputs: gamma[n_feat], pass[n_feat], delta_x[d], P updated in place; returns stacked row count.
+// last stacked system handed to measurementUpdate by orc_ekf_update_problem (row-major H: rows x d, then r)
+static std::vector<double> g_last_H, g_last_r;
+static int g_last_rows = 0, g_last_d = 0;
+int orc_ekf_last_system(double *H, double *r, int capacity_rows) {
+    if (H && r && capacity_rows >= g_last_rows) {
+        std::memcpy(H, g_last_H.data(), sizeof(double) * g_last_H.size());
+        std::memcpy(r, g_last_r.data(), sizeof(double) * g_last_r.size());
+    }
+    return g_last_rows;
+}
+
 int orc_ekf_update_problem(const mskf_calib *calib, const mskf_ekf_cfg *cfg, const double gravity[3], int n_clones,
                            const double *clones, double *P, int n_feat, const double *positions, const int *obs_start,
                            const int *obs_clone, const double *obs_z, int dof_offset, double *gamma_out,
@@ -222,6 +233,10 @@ int orc_ekf_update_problem(const mskf_calib *calib, const mskf_ekf_cfg *cfg, con
     IMUState before = vio.state_server.imu_state;
     std::vector<V3> cam_p_before;
     for (auto &kv : vio.state_server.cam_states) cam_p_before.push_back(kv.second.position);
+    g_last_rows = stack; g_last_d = d;
+    g_last_H.assign((size_t)stack * d, 0.0);
+    for (int i = 0; i < stack; ++i) for (int j = 0; j < d; ++j) g_last_H[(size_t)i * d + j] = H_x(i, j);
+    g_last_r = r;
     vio.measurementUpdate(H_x, r);
     for (int i = 0; i < d; ++i) delta_x[i] = 0;
     if (stack > 0) {

@@ -170,7 +170,7 @@ def test_ekf_update_matches_oracle(gpu_ctx, oracle, n_clones, n_feat, seed, dof_
     scale = np.abs(ref["delta_x"]).max()
     assert np.allclose(got["delta_x"], ref["delta_x"], rtol=1e-6, atol=1e-9 * max(scale, 1e-3))
     Pg = s.ekf_get_cov()
-    assert np.allclose(Pg, ref["P"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(Pg, ref["P"], rtol=1e-7, atol=1e-8 * np.abs(ref["P"]).max())   # incl. the lambda-prior bias (~1e-10)
     assert np.array_equal(Pg, Pg.T)
     s.close()
 
@@ -205,6 +205,25 @@ def test_detector_large_cells(gpu_ctx, oracle):
         assert np.array_equal(got[k], ref[k]), k
     for lvl in range(4):
         assert np.array_equal(s.get_level(1, lvl), oracle.build_pyramid(img)[lvl])
+    s.close()
+
+
+@pytest.mark.parametrize("n_clones,n_feat", [(29, 4), (13, 4), (24, 4), (30, 4), (10, 2), (19, 3)])
+def test_ekf_update_ill_conditioned(gpu_ctx, oracle, n_clones, n_feat):
+    """Few features over many clones: the stacked Jacobian is rank deficient beyond the gauge and cond(H) ~ 1e6-1e7.
+    An unpivoted semidefinite Cholesky of H^T H loses up to 7e-5 here (tools/dev/update_truth.py); the regularised
+    factorisation has to stay at the 1e-9 level against the oracle's Householder path."""
+    s, calib = _stream(gpu_ctx, oracle, 376, 240, max_cam_state_size=max(n_clones, 4))
+    cfg = default_ekf_cfg(max_cam_state_size=max(n_clones, 4))
+    pr = ekf_problems.make_problem(calib, seed=100 + n_clones, n_clones=n_clones, n_feat=n_feat, min_obs=3)
+    ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"],
+                                    pr["obs_clone"], pr["obs_z"], -1)
+    s.ekf_set_cov(pr["P"])
+    got = s.ekf_update(pr["gravity"], pr["clones"], pr["positions"], pr["obs_start"], pr["obs_clone"], pr["obs_z"], -1, True)
+    assert got["rows"] == ref["rows"] > 0
+    Pg = s.ekf_get_cov()
+    assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 2e-9
+    assert np.abs(got["delta_x"] - ref["delta_x"]).max() / np.abs(ref["delta_x"]).max() < 2e-8
     s.close()
 
 
