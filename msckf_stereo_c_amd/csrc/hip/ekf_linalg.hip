@@ -233,25 +233,27 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
 // and rows/cols [0,21) of S = T R^T + sigma^2 I are sigma^2 I (L = sigma I).  Only the trailing
 // (d-21) x (d-21) block is factorised: <= 180 rows for 30 clones = 129 KiB packed + a 16-wide panel.
 //
-// Right-looking, 16 columns per panel, one 1024-thread workgroup (16 waves) per stream:
+// Right-looking, 16 columns per panel, one 512-thread workgroup (8 waves) per stream:
 //   1. wave 0 factors the 16x16 diagonal block in registers: lane r owns row r, the pivot and the column
-//      entries travel through v_readlane (no LDS round trips, no barriers inside the block); 1/sqrt(pivot)
+//      entries travel through v_mov_b64_dpp row_newbcast (no LDS round trips, no barriers inside the block); 1/sqrt(pivot)
 //      comes from v_rsq_f64 + two Newton steps, so the serial chain has no division;
-//   2. one thread per row below solves x L11^T = a against L11 broadcast from LDS and leaves the panel k-major
+//   2. one thread per row below solves x L11^T = a against L11 broadcast the same way and leaves the panel k-major
 //      (sPanT[c][row]) for the MFMA operands;
 //   3. the trailing update A22 -= X X^T runs on v_mfma_f64_16x16x4_f64, one 16x16 tile of the lower triangle at
 //      a time per wave (4 MFMAs per tile), read-modify-write on the packed matrix.
 #define LNB 16
 #define CHOL_LDS_MAX_ROWS 181     // active rows incl. the extra Q^T r row
+#define CHOL_THREADS 512          // 8 waves: 256 VGPRs per lane, the unrolled 16-column eliminations stay in registers
+#define CHOL_WAVES (CHOL_THREADS / 64)
 #define CHOL_PAN_RS 192           // row stride of the k-major panel (rows padded to a multiple of 16)
 
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+// value of lane C of each 16-lane row, in every lane of that row: one v_mov_b64_dpp row_newbcast
+template <int C> __device__ __forceinline__ double row_bcast_f64(double v) {
+    long long b = __double_as_longlong(v);
+    b = __builtin_amdgcn_update_dpp(b, b, 0x150 + C, 0xf, 0xf, false);
+    return __longlong_as_double(b);
 }
 
 // 1/sqrt(x) to double precision without a division: hardware estimate + two Newton steps
@@ -263,7 +265,46 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-__global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
+// Column-by-column elimination with the matrix rows spread over the lanes of a 16-lane row (lane r = row r, a[c]
+// = entry (r, c)); unrolled by template recursion because the DPP lane selectors are immediates.
+template <int J, int C> __device__ __forceinline__ void chol_rank1(double (&a)[LNB]) {
+    if constexpr (C < LNB) {
+        a[C] = fma(-a[J], row_bcast_f64<C>(a[J]), a[C]);      // rows r < C carry unused upper-triangle values
+        chol_rank1<J, C + 1>(a);
+    }
+}
+template <int J> __device__ __forceinline__ void chol_diag_cols(double (&a)[LNB], int r, double tol, double &invd) {
+    if constexpr (J < LNB) {
+        const double piv = row_bcast_f64<J>(a[J]);
+        const bool skip = !(piv > tol);
+        const double y = skip ? 0.0 : rsqrt_nr(piv);
+        double l = piv * y;
+        l = skip ? 0.0 : fma(0.5 * y, fma(-l, l, piv), l);
+        if (r == J) { a[J] = l; invd = y; } else a[J] *= y;
+        chol_rank1<J, J + 1>(a);
+        chol_diag_cols<J + 1>(a, r, tol, invd);
+    }
+}
+// x L11^T = a for one matrix row per lane; lane c of every 16-lane row holds row c of L11 (Lr) and 1/L11[c][c]
+template <int J, int C> __device__ __forceinline__ void panel_elim(double (&x)[LNB], double lj) {
+    if constexpr (C < LNB) {
+        x[C] = fma(-x[J], row_bcast_f64<C>(lj), x[C]);
+        panel_elim<J, C + 1>(x, lj);
+    }
+}
+template <int J> __device__ __forceinline__ void panel_cols(double (&x)[LNB], const double (&Lr)[LNB], double invr) {
+    if constexpr (J < LNB) {
+        x[J] *= row_bcast_f64<J>(invr);
+        // L11 does not depend on x, so the optimiser would materialise all 120 broadcasts up front (240 VGPRs, spills):
+        // tie column J's source to x[J] so its broadcasts are formed when they are consumed
+        double lj = Lr[J];
+        asm volatile("" : "+v"(lj) : "v"(x[J]));
+        panel_elim<J, J + 1>(x, lj);
+        panel_cols<J + 1>(x, Lr, invr);
+    }
+}
+
+__global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
     double *A = which == 0 ? S.S : S.W;
@@ -274,15 +315,32 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
     extern __shared__ double s_dyn[];
     double *sM = s_dyn;                            // packed lower, nt rows
     double *sPanT = s_dyn + nt * (nt + 1) / 2;     // [LNB][CHOL_PAN_RS]
-    __shared__ double s_tol, s_mx[16], s_L11[LNB][LNB + 1], s_inv[LNB];   // s_L11[j][c] = L11[c][j]
+    __shared__ double s_tol, s_mx[CHOL_WAVES], s_L11[LNB][LNB + 1], s_inv[LNB];   // s_L11[j][c] = L11[c][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CHOL_PROF
+    long long tp0 = clock64(), tp_load = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp_store = 0, tq;
+#endif
     // load: one matrix row per wave pass, coalesced along j
-    for (int i = wave; i < nt; i += 16) {
-        const double *src = A + (size_t)(off + i) * lda + off;
-        double *dst = sM + pk(i, 0);
-        for (int j = lane; j <= i; j += 64) dst[j] = src[j];
+    // (8 rows x 3 column chunks = up to 24 loads in flight per lane: the copy is latency bound otherwise)
+    for (int i0 = wave * 8; i0 < nt; i0 += CHOL_WAVES * 8) {
+        double v[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u;
+            const double *src = A + (size_t)(off + i) * lda + off;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const int j = lane + 64 * k; v[u][k] = (i < nt && j <= i) ? src[j] : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u;
+            if (i >= nt) continue;
+            double *dst = sM + pk(i, 0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const int j = lane + 64 * k; if (j <= i) dst[j] = v[u][k]; }
+        }
     }
-    for (int e = tid; e < LNB * CHOL_PAN_RS; e += 1024) sPanT[e] = 0.0;
+    for (int e = tid; e < LNB * CHOL_PAN_RS; e += CHOL_THREADS) sPanT[e] = 0.0;
     __syncthreads();
     if (semidef) {
         // G = H^T H is rank deficient (unobserved clones, the gauge) and its small pivots are rounding noise:
@@ -291,16 +349,19 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
         // lambda = 1e-14 d max(diag G): every pivot stays above the noise, nothing is skipped, and the only effect
         // is a prior of weight lambda / sigma^2 on the clone states (bias ~1e-11 relative, same tool).
         double mx = 0;
-        for (int i = tid; i < n; i += 1024) mx = fmax(mx, sM[pk(i, i)]);
+        for (int i = tid; i < n; i += CHOL_THREADS) mx = fmax(mx, sM[pk(i, i)]);
         for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
         if (lane == 0) s_mx[wave] = mx;
         __syncthreads();
-        if (tid == 0) { double m = 0; for (int i = 0; i < 16; ++i) m = fmax(m, s_mx[i]); s_tol = m * (double)S.d * 1e-14; }
+        if (tid == 0) { double m = 0; for (int i = 0; i < CHOL_WAVES; ++i) m = fmax(m, s_mx[i]); s_tol = m * (double)S.d * 1e-14; }
         __syncthreads();
         const double lam = s_tol;
-        for (int i = tid; i < n; i += 1024) sM[pk(i, i)] += lam;
+        for (int i = tid; i < n; i += CHOL_THREADS) sM[pk(i, i)] += lam;
         __syncthreads();
     }
+#ifdef CHOL_PROF
+    tq = clock64(); tp_load = tq - tp0; tp0 = tq;
+#endif
     const double tol = 0.0;      // a pivot <= 0 (cannot happen for G + lambda I or for S >= sigma^2 I) zeroes its column
     for (int kb = 0; kb < n; kb += LNB) {
         const int nb = min(LNB, n - kb);
@@ -317,21 +378,7 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
                 for (int c = 0; c < LNB; ++c) a[c] = src[c];
             }
             double invd = 0.0;     // lane r keeps 1/L[r][r]
-#pragma unroll
-            for (int j = 0; j < LNB; ++j) {
-                const double piv = readlane_f64(a[j], j);
-                const bool skip = !(piv > tol);
-                const double y = skip ? 0.0 : rsqrt_nr(piv);
-                double l = piv * y;
-                l = skip ? 0.0 : fma(0.5 * y, fma(-l, l, piv), l);
-                if (r == j) { a[j] = l; invd = y; } else a[j] *= y;
-#pragma unroll
-                for (int c = j + 1; c < LNB; ++c) {
-                    const double lcj = readlane_f64(a[j], c);
-                    a[c] = fma(-a[j], lcj, a[c]);      // rows r < c carry unused upper-triangle values
-                }
-                __builtin_amdgcn_sched_barrier(0);     // keep the unrolled columns in order (register pressure)
-            }
+            chol_diag_cols<0>(a, r, tol, invd);
             if (lane < LNB) {
 #pragma unroll
                 for (int c = 0; c < LNB; ++c) {
@@ -343,6 +390,9 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
             }
         }
         __syncthreads();
+#ifdef CHOL_PROF
+        tq = clock64(); tp1 += tq - tp0; tp0 = tq;
+#endif
         // ---- 2. panel rows below: x L11^T = a, one thread per row
         const int r0 = kb + nb;
         const int rem = nt - r0;
@@ -359,12 +409,7 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
             double x[LNB];
 #pragma unroll
             for (int c = 0; c < LNB; ++c) x[c] = row[c];        // columns >= nb: finite filler, multiplied by 0 below
-#pragma unroll
-            for (int j = 0; j < LNB; ++j) {
-                x[j] *= readlane_f64(invr, j);
-#pragma unroll
-                for (int c = j + 1; c < LNB; ++c) x[c] = fma(-x[j], readlane_f64(Lr[j], c), x[c]);
-            }
+            panel_cols<0>(x, Lr, invr);
             if (has_row) {
 #pragma unroll
                 for (int c = 0; c < LNB; ++c) {
@@ -374,45 +419,60 @@ __global__ __launch_bounds__(1024) void k_ekf_chol_lds(const EkfStreamDev *strea
             }
         }
         __syncthreads();
+#ifdef CHOL_PROF
+        tq = clock64(); tp2 += tq - tp0; tp0 = tq;
+#endif
         // ---- 3. trailing update on the matrix cores: 16x16 tiles (ta, tb <= ta) of rows/cols r0 + ...
         const int ntr = (rem + 15) >> 4;
         const int n_tiles = ntr * (ntr + 1) / 2;
-        for (int t = wave; t < n_tiles; t += 16) {
-            int ta = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while (ta * (ta + 1) / 2 > t) --ta;
-            while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
-            const int tb = t - ta * (ta + 1) / 2;
-            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        {
+            // tiles are numbered row-major over the lower triangle; a wave takes tiles wave, wave + 8, ...
+            int ta = 0, tb = wave;
+            while (tb > ta) { tb -= ta + 1; ++ta; }
+            for (int t = wave; t < n_tiles; t += CHOL_WAVES) {
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s4 = 0; s4 < LNB / 4; ++s4) {
-                const double *pp = sPanT + (4 * s4 + (lane >> 4)) * CHOL_PAN_RS + (lane & 15);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[16 * ta], pp[16 * tb], acc, 0, 0, 0);
-            }
-            const int j = r0 + 16 * tb + (lane & 15);
+                for (int s4 = 0; s4 < LNB / 4; ++s4) {
+                    const double *pp = sPanT + (4 * s4 + (lane >> 4)) * CHOL_PAN_RS + (lane & 15);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[16 * ta], pp[16 * tb], acc, 0, 0, 0);
+                }
+                const int j = r0 + 16 * tb + (lane & 15);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = r0 + 16 * ta + (lane >> 4) + 4 * q;
-                if (i < nt && j <= i) sM[pk(i, j)] -= acc[q];
+                for (int q = 0; q < 4; ++q) {
+                    const int i = r0 + 16 * ta + (lane >> 4) + 4 * q;
+                    if (i < nt && j <= i) sM[pk(i, j)] -= acc[q];
+                }
+                tb += CHOL_WAVES;
+                while (tb > ta) { tb -= ta + 1; ++ta; }
             }
         }
         __syncthreads();
+#ifdef CHOL_PROF
+        tq = clock64(); tp3 += tq - tp0; tp0 = tq;
+#endif
     }
     // store back; the trivial IMU block: L = 0 (Gram) or sigma I (S)
-    for (int i = wave; i < nt; i += 16) {
+    for (int i = wave; i < nt; i += CHOL_WAVES) {
         double *dst = A + (size_t)(off + i) * lda + off;
         const double *src = sM + pk(i, 0);
-        for (int j = lane; j <= i && j < n; j += 64) dst[j] = src[j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int j = lane + 64 * k; if (j <= i && j < n) dst[j] = src[j]; }
     }
     if (which == 0) {
         // column d of T <- (Q^T r) = row d of L, so the TRSM carries w = L2^-1 Q^T r along (IMU part is zero)
-        for (int k = tid; k < S.d; k += 1024) S.T[(size_t)k * lda + S.d] = (k < off) ? 0.0 : sM[pk(n, k - off)];
+        for (int k = tid; k < S.d; k += CHOL_THREADS) S.T[(size_t)k * lda + S.d] = (k < off) ? 0.0 : sM[pk(n, k - off)];
     }
     const double l0 = semidef ? 0.0 : sqrt(S.sigma2);
     const int rows_all = S.d + (which == 0 ? 1 : 0);
-    for (int e = tid; e < rows_all * off; e += 1024) {
+    for (int e = tid; e < rows_all * off; e += CHOL_THREADS) {
         const int i = e / off, j = e - i * off;
         if (j <= i) A[(size_t)i * lda + j] = (i == j) ? l0 : 0.0;
     }
+#ifdef CHOL_PROF
+    __syncthreads();
+    tq = clock64(); tp_store = tq - tp0;
+    if (tid == 0 && blockIdx.y == 0) printf("CHOLPROF which %d n %d load %lld diag %lld panel %lld trail %lld store %lld\n", which, n, tp_load, tp1, tp2, tp3, tp_store);
+#endif
 }
 
 // ------------------------------------------------------------------------------------ r_thin column
@@ -519,7 +579,7 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
     std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_PAN_RS * LNB) * sizeof(double))); });
         const size_t lds = ((size_t)nt * (nt + 1) / 2 + (size_t)CHOL_PAN_RS * LNB) * sizeof(double);
-        hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(1024), lds, st, d, which);
+        hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(CHOL_THREADS), lds, st, d, which);
         return;
     }
     const size_t lds = (size_t)(CNB * (CNB + 1) + (size_t)(max_d + 2) * CNB) * sizeof(double);
