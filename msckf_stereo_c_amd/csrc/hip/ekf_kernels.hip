@@ -13,6 +13,7 @@
 // stream), blockIdx.y is the stream of the batch.
 #include <mutex>
 #include "ekf_device.h"
+#include "chol_block.h"
 
 #define WG 256
 
@@ -407,59 +408,83 @@ __device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, Tri
 // Mm is symmetric and kept in packed lower form (row i at i(i+1)/2): 120 rows = 56.7 KiB, so with the
 // 32-clone instantiation (19 KiB static) two workgroups share a CU.
 #define GATE_LDS_ROWS 120
+#define GATE_PAN_RS 128          // k-major Cholesky panel stride (>= GATE_LDS_ROWS - 2 rows, multiple of 16)
 __device__ __forceinline__ size_t pk(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // i >= j
-template <int MAXC>
-__global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *streams, int lds_rows) {
+// Work group of a feature: the whole 256-thread workgroup (WAVE = false), or one wavefront (WAVE = true: four
+// features per workgroup side by side, wave-level barriers only) for launches whose features all have <= MAXC = 4
+// observations in the Jacobian — the pruning update hands over hundreds of 2-observation features per stream, for
+// which the workgroup-wide barriers were the whole cost (~140 us per feature, measured).
+template <int MAXC, bool WAVE>
+__global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev *streams, int lds_rows, int arena_doubles) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    const int tid = threadIdx.x;
+    constexpr int GS = WAVE ? 64 : WG;          // threads per feature
+    constexpr int NSUB = WG / GS;               // features side by side in a workgroup
+    const int gt = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int sub = WAVE ? (int)(threadIdx.x >> 6) : 0;
     const int d = S.d, ld = S.ld;
-    __shared__ double sHf[4 * MAXC][3];
-    __shared__ double sHx[4 * MAXC][6];
-    __shared__ double sr[4 * MAXC];
-    __shared__ double sV[3][4 * MAXC];
-    __shared__ double sCoef[6 * MAXC + 1][3];
-    __shared__ double sBeta[3], sVV[3];  // beta_k ; v2.v1, v3.v1, v3.v2
-    __shared__ int sObsOfClone[MAX_CLONES_DEV];   // indexed by clone id (any clone of the state)
-    __shared__ int sCloneOfObs[MAXC];
-    extern __shared__ double s_arena[];
+    // Jacobian / reflector scratch, one block per feature in flight: it is dead once the gate matrix is reflected,
+    // and the 16-wide Cholesky panel (LNB x GATE_PAN_RS doubles) of the workgroup variant reuses it
+    constexpr int BLK_DOUBLES = (12 + 24 + 4 + 12) * MAXC + 3 * (6 * MAXC + 1);
+    static_assert(MAXC != 32 || BLK_DOUBLES >= LNB * GATE_PAN_RS, "panel does not fit the dead scratch");
+    __shared__ double s_blk_all[NSUB][BLK_DOUBLES];
+    double *s_blk = s_blk_all[sub];
+    double (*sHf)[3] = reinterpret_cast<double (*)[3]>(s_blk);
+    double (*sHx)[6] = reinterpret_cast<double (*)[6]>(s_blk + 12 * MAXC);
+    double *sr = s_blk + 36 * MAXC;
+    double (*sV)[4 * MAXC] = reinterpret_cast<double (*)[4 * MAXC]>(s_blk + 40 * MAXC);
+    double (*sCoef)[3] = reinterpret_cast<double (*)[3]>(s_blk + 52 * MAXC);
+    __shared__ CholBlockShared s_cb;
+    __shared__ double sBeta_all[NSUB][3], sVV_all[NSUB][3];  // beta_k ; v2.v1, v3.v1, v3.v2
+    __shared__ int sObsOfClone_all[NSUB][MAX_CLONES_DEV];   // indexed by clone id (any clone of the state)
+    __shared__ int sCloneOfObs_all[NSUB][MAXC];
+    extern __shared__ double s_arena_all[];
+    double *s_arena = s_arena_all + (size_t)sub * arena_doubles;
     TriScratch &sTri = *reinterpret_cast<TriScratch *>(s_arena);
-    __shared__ double sW[4 * MAXC];
-    __shared__ double sPos[3];
-    __shared__ int sValid;
+    __shared__ double sW_all[NSUB][4 * MAXC];
+    __shared__ double sPos_all[NSUB][3];
+    __shared__ int sValid_all[NSUB];
     __shared__ double sRed[8];
+    double *sBeta = sBeta_all[sub], *sVV = sVV_all[sub], *sW = sW_all[sub], *sPos = sPos_all[sub];
+    int *sObsOfClone = sObsOfClone_all[sub], *sCloneOfObs = sCloneOfObs_all[sub];
+    int &sValid = sValid_all[sub];
+    auto GSYNC = [&]() {
+        if (WAVE) { __builtin_amdgcn_wave_barrier(); __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    auto gsum = [&](double v) { return WAVE ? wave_sum(v) : block_sum(v, sRed); };
 
-    for (int j = blockIdx.x; j < S.n_feat; j += gridDim.x) {
-        __syncthreads();
+    for (int j = blockIdx.x * NSUB + sub; j < S.n_feat; j += gridDim.x * NSUB) {
+        GSYNC();
         EkfFeatDev &F = S.feats[j];
         const int M = F.n_obs, rows = 4 * M, n = rows - 3;
         double *Hrow0 = S.Hs + (size_t)F.row_off * ld;
         double *r0 = S.rs + F.row_off;
         // ---- 1. position
-        if (tid < 64) {
+        if (gt < 64) {
             bool valid = true;
             double pos[3] = {F.position[0], F.position[1], F.position[2]};
             if (F.needs_init) valid = triangulate_wave(S, F, sTri, pos);
-            if (tid == 0) {
+            if (gt == 0) {
                 sPos[0] = pos[0]; sPos[1] = pos[1]; sPos[2] = pos[2];
                 sValid = valid ? 1 : 0;
                 F.position[0] = pos[0]; F.position[1] = pos[1]; F.position[2] = pos[2];
                 S.pos_out[3 * j] = pos[0]; S.pos_out[3 * j + 1] = pos[1]; S.pos_out[3 * j + 2] = pos[2];
             }
         }
-        for (int c = tid; c < MAX_CLONES_DEV; c += WG) sObsOfClone[c] = -1;
-        __syncthreads();
+        for (int c = gt; c < MAX_CLONES_DEV; c += GS) sObsOfClone[c] = -1;
+        GSYNC();
         if (!sValid || M < 2) {
-            if (tid == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; }
-            for (int i = tid; i < n * ld; i += WG) Hrow0[i] = 0.0;
-            for (int i = tid; i < n; i += WG) r0[i] = 0.0;
+            if (gt == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; }
+            for (int i = gt; i < n * ld; i += GS) Hrow0[i] = 0.0;
+            for (int i = gt; i < n; i += GS) r0[i] = 0.0;
             continue;
         }
         // ---- 2. per-observation Jacobians (msckf_vio.cpp:610-677)
-        if (tid < M) {
-            const int o = F.obs_start + tid;
+        if (gt < M) {
+            const int o = F.obs_start + gt;
             const int ci = S.obs_clone[o];
-            sObsOfClone[ci] = tid;
-            sCloneOfObs[tid] = ci;
+            sObsOfClone[ci] = gt;
+            sCloneOfObs[gt] = ci;
             const mskf_clone_state &cam = S.clones[ci];
             double R_w_c0[9], R_w_c1[9], tmp[3];
             quat_to_rot(cam.q, R_w_c0);
@@ -500,50 +525,50 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
             for (int rr = 0; rr < 4; ++rr) {
                 double Au = 0;
                 for (int k = 0; k < 6; ++k) Au += Hx[rr][k] * u[k];
-                for (int c = 0; c < 6; ++c) sHx[4 * tid + rr][c] = Hx[rr][c] - Au * (1.0 / uu) * u[c];
+                for (int c = 0; c < 6; ++c) sHx[4 * gt + rr][c] = Hx[rr][c] - Au * (1.0 / uu) * u[c];
             }
-            for (int rr = 0; rr < 4; ++rr) for (int c = 0; c < 3; ++c) sHf[4 * tid + rr][c] = -sHx[4 * tid + rr][3 + c];
+            for (int rr = 0; rr < 4; ++rr) for (int c = 0; c < 3; ++c) sHf[4 * gt + rr][c] = -sHx[4 * gt + rr][3 + c];
             const double *z = S.obs_z + 4 * o;
-            sr[4 * tid + 0] = z[0] - p_c0[0] / p_c0[2];
-            sr[4 * tid + 1] = z[1] - p_c0[1] / p_c0[2];
-            sr[4 * tid + 2] = z[2] - p_c1[0] / p_c1[2];
-            sr[4 * tid + 3] = z[3] - p_c1[1] / p_c1[2];
+            sr[4 * gt + 0] = z[0] - p_c0[0] / p_c0[2];
+            sr[4 * gt + 1] = z[1] - p_c0[1] / p_c0[2];
+            sr[4 * gt + 2] = z[2] - p_c1[0] / p_c1[2];
+            sr[4 * gt + 3] = z[3] - p_c1[1] / p_c1[2];
         }
-        __syncthreads();
+        GSYNC();
         // ---- 3. three Householder reflectors of H_f (left null space, msckf_vio.cpp:757-766)
         for (int k = 0; k < 3; ++k) {
             double part = 0;
-            for (int i = k + tid; i < rows; i += WG) part += sHf[i][k] * sHf[i][k];
-            const double nrm2 = block_sum(part, sRed);
+            for (int i = k + gt; i < rows; i += GS) part += sHf[i][k] * sHf[i][k];
+            const double nrm2 = gsum(part);
             const double nrm = sqrt(nrm2);
             const double x0 = sHf[k][k];
             const double alpha = x0 > 0 ? -nrm : nrm;
-            __syncthreads();
-            for (int i = tid; i < rows; i += WG) sV[k][i] = (i < k) ? 0.0 : (i == k ? x0 - alpha : sHf[i][k]);
-            __syncthreads();
+            GSYNC();
+            for (int i = gt; i < rows; i += GS) sV[k][i] = (i < k) ? 0.0 : (i == k ? x0 - alpha : sHf[i][k]);
+            GSYNC();
             double pv = 0;
-            for (int i = k + tid; i < rows; i += WG) pv += sV[k][i] * sV[k][i];
-            const double vn = block_sum(pv, sRed);
+            for (int i = k + gt; i < rows; i += GS) pv += sV[k][i] * sV[k][i];
+            const double vn = gsum(pv);
             const double beta = (nrm == 0.0 || vn == 0.0) ? 0.0 : 2.0 / vn;
-            if (tid == 0) sBeta[k] = beta;
+            if (gt == 0) sBeta[k] = beta;
             // apply to the remaining columns of H_f
             for (int c = k + 1; c < 3; ++c) {
                 double pd = 0;
-                for (int i = k + tid; i < rows; i += WG) pd += sV[k][i] * sHf[i][c];
-                const double sdot = block_sum(pd, sRed) * beta;
-                for (int i = k + tid; i < rows; i += WG) sHf[i][c] -= sdot * sV[k][i];
-                __syncthreads();
+                for (int i = k + gt; i < rows; i += GS) pd += sV[k][i] * sHf[i][c];
+                const double sdot = gsum(pd) * beta;
+                for (int i = k + gt; i < rows; i += GS) sHf[i][c] -= sdot * sV[k][i];
+                GSYNC();
             }
         }
         {
             double p21 = 0, p31 = 0, p32 = 0;
-            for (int i = tid; i < rows; i += WG) { p21 += sV[1][i] * sV[0][i]; p31 += sV[2][i] * sV[0][i]; p32 += sV[2][i] * sV[1][i]; }
-            const double a = block_sum(p21, sRed), b = block_sum(p31, sRed), c = block_sum(p32, sRed);
-            if (tid == 0) { sVV[0] = a; sVV[1] = b; sVV[2] = c; }
+            for (int i = gt; i < rows; i += GS) { p21 += sV[1][i] * sV[0][i]; p31 += sV[2][i] * sV[0][i]; p32 += sV[2][i] * sV[1][i]; }
+            const double a = gsum(p21), b = gsum(p31), c = gsum(p32);
+            if (gt == 0) { sVV[0] = a; sVV[1] = b; sVV[2] = c; }
         }
-        __syncthreads();
+        GSYNC();
         // ---- 4. coefficients c_k of every compact column (6M Jacobian columns + the residual)
-        for (int cc = tid; cc <= 6 * M; cc += WG) {
+        for (int cc = gt; cc <= 6 * M; cc += GS) {
             double s1 = 0, s2 = 0, s3 = 0;
             if (cc < 6 * M) {
                 const int blk = cc / 6, c6 = cc - 6 * blk;
@@ -559,34 +584,38 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
             const double c3 = sBeta[2] * (s3 - c1 * sVV[1] - c2 * sVV[2]);
             sCoef[cc][0] = c1; sCoef[cc][1] = c2; sCoef[cc][2] = c3;
         }
-        __syncthreads();
+        GSYNC();
         // ---- 5. write the projected block: rows 3..4M-1 of Q^T [H_xj | r_j]
-        for (int idx = tid; idx < n * d; idx += WG) {
-            const int i = idx / d + 3, c = idx - (i - 3) * d;
-            double v = 0.0;
-            if (c >= EKF_IMU_DIM) {
-                const int cl = (c - EKF_IMU_DIM) / 6, c6 = (c - EKF_IMU_DIM) - 6 * cl;
-                const int ob = sObsOfClone[cl];
-                if (ob >= 0) {
-                    const int cc = 6 * ob + c6;
-                    const double base = ((i >> 2) == ob) ? sHx[i][c6] : 0.0;
-                    v = base - sCoef[cc][0] * sV[0][i] - sCoef[cc][1] * sV[1][i] - sCoef[cc][2] * sV[2][i];
+        for (int i = 3 + (gt >> 6); i < rows; i += GS / 64) {       // one output row per wave pass, columns across lanes
+            const double v0 = sV[0][i], v1 = sV[1][i], v2 = sV[2][i];
+            double *out = Hrow0 + (size_t)(i - 3) * ld;
+            const int ob_i = i >> 2;
+            for (int c = gt & 63; c < d; c += 64) {
+                double v = 0.0;
+                if (c >= EKF_IMU_DIM) {
+                    const int cl = (c - EKF_IMU_DIM) / 6, c6 = (c - EKF_IMU_DIM) - 6 * cl;
+                    const int ob = sObsOfClone[cl];
+                    if (ob >= 0) {
+                        const int cc = 6 * ob + c6;
+                        const double base = (ob_i == ob) ? sHx[i][c6] : 0.0;
+                        v = base - sCoef[cc][0] * v0 - sCoef[cc][1] * v1 - sCoef[cc][2] * v2;
+                    }
                 }
+                out[c] = v;
             }
-            Hrow0[(size_t)(i - 3) * ld + c] = v;
         }
-        for (int i = 3 + tid; i < rows; i += WG) {
+        for (int i = 3 + gt; i < rows; i += GS) {
             const double rv = sr[i] - sCoef[6 * M][0] * sV[0][i] - sCoef[6 * M][1] * sV[1][i] - sCoef[6 * M][2] * sV[2][i];
             r0[i - 3] = rv;
             Hrow0[(size_t)(i - 3) * ld + d] = rv;   // column d of the stacked matrix carries the residual ([H | r])
         }
-        __syncthreads();
+        GSYNC();
         // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
         // H = A^T H_xj with H_xj block diagonal (4x6 per observation), so H P H^T = A^T Mm A with
         // Mm[a][b] = H_a P_ab H_b^T (4x4 blocks from 6x6 blocks of P), and A^T . A = rows/cols 3.. of Q^T . Q.
         double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax);   // packed lower
         const double *P = S.P;
-        for (int pr = tid; pr < M * M; pr += WG) {
+        for (int pr = gt; pr < M * M; pr += GS) {
             const int a = pr / M, b = pr - a * M;
             if (b > a) continue;
             const int ca = EKF_IMU_DIM + 6 * sCloneOfObs[a], cb = EKF_IMU_DIM + 6 * sCloneOfObs[b];
@@ -605,69 +634,135 @@ __global__ __launch_bounds__(WG) void k_ekf_feature_blocks(const EkfStreamDev *s
                 Mm[pk(4 * a + i, 4 * b + jj)] = t;
             }
         }
-        __syncthreads();
-        // two-sided reflectors: Mm <- Q_k^T Mm Q_k, Q_k = I - beta_k v_k v_k^T  (Mm symmetric, lower stored)
+        GSYNC();
+        // two-sided reflectors in one pass: Q = Q_1 Q_2 Q_3 = I - V T V^T (compact WY, T 3x3 upper triangular), so
+        //   Q^T Mm Q = Mm - Z V^T - V Z^T,   Z = W T - 1/2 V (T^T G T),   W = Mm V,   G = V^T W
+        // (Mm symmetric, lower stored).  The LDS case keeps W and Z in the dead H_f / coefficient scratch.
+        if (rows <= lds_rows) {
+            double (*sWm)[3] = sHf;                 // rows x 3, H_f is dead after step 4
+            double (*sZ)[3] = sCoef;                // rows x 3 (<= 4 MAXC), the coefficients are dead after step 5
+            if (gt < rows) {
+                const int i = gt;
+                double w0 = 0, w1 = 0, w2 = 0;
+                const double *mi = Mm + pk(i, 0);
+                for (int c = 0; c <= i; ++c) { const double m = mi[c]; w0 += m * sV[0][c]; w1 += m * sV[1][c]; w2 += m * sV[2][c]; }
+                size_t o = pk(i + 1, i);
+                for (int c = i + 1; c < rows; ++c) { const double m = Mm[o]; w0 += m * sV[0][c]; w1 += m * sV[1][c]; w2 += m * sV[2][c]; o += c + 1; }
+                sWm[i][0] = w0; sWm[i][1] = w1; sWm[i][2] = w2;
+            }
+            GSYNC();
+            double g[6] = {0, 0, 0, 0, 0, 0};       // G: 00 01 02 11 12 22
+            for (int i = gt; i < rows; i += GS) {
+                const double a0 = sV[0][i], a1 = sV[1][i], a2 = sV[2][i];
+                g[0] += a0 * sWm[i][0]; g[1] += a0 * sWm[i][1]; g[2] += a0 * sWm[i][2];
+                g[3] += a1 * sWm[i][1]; g[4] += a1 * sWm[i][2]; g[5] += a2 * sWm[i][2];
+            }
+            for (int q = 0; q < 6; ++q) g[q] = gsum(g[q]);
+            // T (upper): T00 = b1, T11 = b2, T22 = b3, T01 = -b2 T00 (v1.v2), [T02; T12] = -b3 T[0:2,0:2] [v1.v3; v2.v3]
+            const double b1 = sBeta[0], b2 = sBeta[1], b3 = sBeta[2];
+            const double T01 = -b2 * b1 * sVV[0];
+            const double T02 = -b3 * (b1 * sVV[1] + T01 * sVV[2]);
+            const double T12 = -b3 * (b2 * sVV[2]);
+            // U = T^T G T (symmetric 3x3): first X = G T, then U = T^T X
+            const double G00 = g[0], G01 = g[1], G02 = g[2], G11 = g[3], G12 = g[4], G22 = g[5];
+            const double X00 = G00 * b1, X01 = G00 * T01 + G01 * b2, X02 = G00 * T02 + G01 * T12 + G02 * b3;
+            const double X10 = G01 * b1, X11 = G01 * T01 + G11 * b2, X12 = G01 * T02 + G11 * T12 + G12 * b3;
+            const double X20 = G02 * b1, X21 = G02 * T01 + G12 * b2, X22 = G02 * T02 + G12 * T12 + G22 * b3;
+            const double U00 = b1 * X00, U01 = b1 * X01, U02 = b1 * X02;
+            const double U11 = T01 * X01 + b2 * X11, U12 = T01 * X02 + b2 * X12;
+            const double U22 = T02 * X02 + T12 * X12 + b3 * X22;
+            (void)X10; (void)X20; (void)X21;
+            for (int i = gt; i < rows; i += GS) {
+                const double a0 = sV[0][i], a1 = sV[1][i], a2 = sV[2][i];
+                const double w0 = sWm[i][0], w1 = sWm[i][1], w2 = sWm[i][2];
+                sZ[i][0] = w0 * b1 - 0.5 * (a0 * U00 + a1 * U01 + a2 * U02);
+                sZ[i][1] = w0 * T01 + w1 * b2 - 0.5 * (a0 * U01 + a1 * U11 + a2 * U12);
+                sZ[i][2] = w0 * T02 + w1 * T12 + w2 * b3 - 0.5 * (a0 * U02 + a1 * U12 + a2 * U22);
+            }
+            GSYNC();
+            for (int i = gt >> 6; i < rows; i += GS / 64) {
+                const double z0 = sZ[i][0], z1 = sZ[i][1], z2 = sZ[i][2];
+                const double a0 = sV[0][i], a1 = sV[1][i], a2 = sV[2][i];
+                double *mi = Mm + pk(i, 0);
+                for (int c = gt & 63; c <= i; c += 64)
+                    mi[c] -= z0 * sV[0][c] + z1 * sV[1][c] + z2 * sV[2][c] + a0 * sZ[c][0] + a1 * sZ[c][1] + a2 * sZ[c][2];
+            }
+            GSYNC();
+        } else
         for (int k = 0; k < 3; ++k) {
             const double beta = sBeta[k];
             if (beta == 0.0) continue;     // uniform
-            for (int i = tid; i < rows; i += WG) {
+            for (int i = gt; i < rows; i += GS) {
                 double t = 0;
                 const double *mi = Mm + pk(i, 0);
                 for (int c = 0; c <= i; ++c) t += mi[c] * sV[k][c];
                 for (int c = i + 1; c < rows; ++c) t += Mm[pk(c, i)] * sV[k][c];
                 sW[i] = t;
             }
-            __syncthreads();
+            GSYNC();
             double pa = 0;
-            for (int i = tid; i < rows; i += WG) pa += sV[k][i] * sW[i];
-            const double alpha = block_sum(pa, sRed);
+            for (int i = gt; i < rows; i += GS) pa += sV[k][i] * sW[i];
+            const double alpha = gsum(pa);
             const double b2a = beta * beta * alpha;
-            for (int e = tid; e < rows * rows; e += WG) {
+            for (int e = gt; e < rows * rows; e += GS) {
                 const int i = e / rows, c = e - i * rows;
                 if (c > i) continue;
                 Mm[pk(i, c)] += -beta * (sV[k][i] * sW[c] + sW[i] * sV[k][c]) + b2a * sV[k][i] * sV[k][c];
             }
-            __syncthreads();
+            GSYNC();
         }
         // S = Mm[3:,3:] + sigma^2 I ; in-place right-looking Cholesky (lower) on the sub-matrix view.  The residual
         // r_o rides along as an extra row (sW): after step k it holds y_k = (L^-1 r_o)_k, so gamma = y . y
         // needs no separate triangular solve.
 #define SG(i, j) Mm[pk((i) + 3, (j) + 3)]
-        for (int i = tid; i < n; i += WG) { SG(i, i) += S.sigma2; sW[i] = r0[i]; }
-        __syncthreads();
         bool pd_ok = true;
-        for (int k = 0; k < n; ++k) {
-            const double dk = SG(k, k);
-            if (!(dk > 0)) { pd_ok = false; break; }
-            const double inv = 1.0 / sqrt(dk);
-            __syncthreads();
-            for (int i = k + tid; i < n; i += WG) SG(i, k) *= inv;   // column k: l_kk = sqrt(dk), l_ik = a_ik / l_kk
-            if (tid == 0) sW[k] *= inv;                               // y_k
-            __syncthreads();
-            const int rem = n - k - 1;
-            const double yk = sW[k];
-            for (int idx = tid; idx < rem * rem; idx += WG) {
-                const int a = idx / rem + k + 1, b = idx % rem + k + 1;
-                if (b <= a) SG(a, b) -= SG(a, k) * SG(b, k);
+        const bool blocked = !WAVE && (rows <= lds_rows) && (MAXC == 32);
+        if (blocked) {
+            // packed row `rows` (columns 3 ..) carries r_o: the blocked factorisation leaves L^-1 r_o there
+            for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; SG(n, i) = r0[i]; }
+            for (int i = gt; i < LNB * GATE_PAN_RS; i += GS) s_blk[i] = 0.0;       // panel buffer (scratch is dead)
+            if (gt < 16) Mm[pk(rows, 3 + n) + gt] = 0.0;                          // readable slack behind the last row
+            GSYNC();
+            chol_blocked_lds<WG / 64>(Mm, [](int i, int j) { return (int)pk(i + 3, j + 3); }, n, n + 1, 0.0, s_blk, GATE_PAN_RS, s_cb);
+            int bad = 0;
+            for (int i = gt; i < n; i += GS) { bad |= !(SG(i, i) > 0.0); sW[i] = SG(n, i); }
+            pd_ok = !__syncthreads_or(bad);
+        } else {
+            for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; sW[i] = r0[i]; }
+            GSYNC();
+            for (int k = 0; k < n; ++k) {
+                const double dk = SG(k, k);
+                if (!(dk > 0)) { pd_ok = false; break; }
+                const double inv = 1.0 / sqrt(dk);
+                GSYNC();
+                for (int i = k + gt; i < n; i += GS) SG(i, k) *= inv;   // column k: l_kk = sqrt(dk), l_ik = a_ik / l_kk
+                if (gt == 0) sW[k] *= inv;                               // y_k
+                GSYNC();
+                const int rem = n - k - 1;
+                const double yk = sW[k];
+                for (int idx = gt; idx < rem * rem; idx += GS) {
+                    const int a = idx / rem + k + 1, b = idx % rem + k + 1;
+                    if (b <= a) SG(a, b) -= SG(a, k) * SG(b, k);
+                }
+                GSYNC();
+                for (int i = k + 1 + gt; i < n; i += GS) sW[i] -= SG(i, k) * yk;
             }
-            __syncthreads();
-            for (int i = k + 1 + tid; i < n; i += WG) sW[i] -= SG(i, k) * yk;
         }
 #undef SG
         double gamma = 1e300;
         if (pd_ok) {
-            __syncthreads();
+            GSYNC();
             double pg = 0;
-            for (int i = tid; i < n; i += WG) pg += sW[i] * sW[i];
-            gamma = block_sum(pg, sRed);
+            for (int i = gt; i < n; i += GS) pg += sW[i] * sW[i];
+            gamma = gsum(pg);
         }
         const int dof = M + S.dof_offset;
         const bool pass = pd_ok && dof >= 1 && dof < 100 && gamma < S.chi2[dof];
-        if (tid == 0) { S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma; }
+        if (gt == 0) { S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma; }
         if (!pass) {
-            __syncthreads();
-            for (int i = tid; i < n * ld; i += WG) Hrow0[i] = 0.0;
-            for (int i = tid; i < n; i += WG) r0[i] = 0.0;
+            GSYNC();
+            for (int i = gt; i < n * ld; i += GS) Hrow0[i] = 0.0;
+            for (int i = gt; i < n; i += GS) r0[i] = 0.0;
         }
     }
 }
@@ -724,18 +819,27 @@ void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);
 }
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st) {
-    const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
-    const int packed_max = GATE_LDS_ROWS * (GATE_LDS_ROWS + 1) / 2 * (int)sizeof(double);
+    const int packed_max = ((GATE_LDS_ROWS + 1) * (GATE_LDS_ROWS + 2) / 2 + 16) * (int)sizeof(double);   // + the r_o row + slack
+    const int tri_doubles = (int)((sizeof(TriScratch) + 7) / 8);
     static std::once_flag attr_once;
-    std::call_once(attr_once, [packed_max]() {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<32>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<MAX_CLONES_DEV>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+    std::call_once(attr_once, [=]() {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<MAX_CLONES_DEV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * tri_doubles * 8);
     });
+    if (max_rows <= 16) {
+        // every feature has <= 4 Jacobian observations: one wavefront per feature, four per workgroup
+        const int groups = (max_feat + 3) / 4;
+        const int slots = groups < EKF_SLOTS ? (groups > 0 ? groups : 1) : EKF_SLOTS;
+        hipLaunchKernelGGL((k_ekf_feature_blocks<4, true>), dim3(slots, n), dim3(WG), (size_t)4 * tri_doubles * 8, st, d, 16, tri_doubles);
+        return;
+    }
+    const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
     const int lds_rows = max_rows <= GATE_LDS_ROWS ? max_rows : GATE_LDS_ROWS;
-    size_t lds = (size_t)lds_rows * (lds_rows + 1) / 2 * sizeof(double);
+    size_t lds = ((size_t)(lds_rows + 1) * (lds_rows + 2) / 2 + 16) * sizeof(double);
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
-    if (max_rows <= 4 * 32) hipLaunchKernelGGL(k_ekf_feature_blocks<32>, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
-    else hipLaunchKernelGGL(k_ekf_feature_blocks<MAX_CLONES_DEV>, dim3(slots, n), dim3(WG), lds, st, d, lds_rows);
+    if (max_rows <= 4 * 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false>), dim3(slots, n), dim3(WG), lds, st, d, lds_rows, 0);
+    else hipLaunchKernelGGL((k_ekf_feature_blocks<MAX_CLONES_DEV, false>), dim3(slots, n), dim3(WG), lds, st, d, lds_rows, 0);
 }
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_posvar, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n, out);

@@ -19,6 +19,7 @@
 // IMU columns of H are zero, unobserved clones, the gauge): the factorisation is regularised, see k_ekf_chol_lds.
 #include <mutex>
 #include "ekf_device.h"
+#include "chol_block.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -241,68 +242,12 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
 //      (sPanT[c][row]) for the MFMA operands;
 //   3. the trailing update A22 -= X X^T runs on v_mfma_f64_16x16x4_f64, one 16x16 tile of the lower triangle at
 //      a time per wave (4 MFMAs per tile), read-modify-write on the packed matrix.
-#define LNB 16
 #define CHOL_LDS_MAX_ROWS 181     // active rows incl. the extra Q^T r row
 #define CHOL_THREADS 512          // 8 waves: 256 VGPRs per lane, the unrolled 16-column eliminations stay in registers
 #define CHOL_WAVES (CHOL_THREADS / 64)
 #define CHOL_PAN_RS 192           // row stride of the k-major panel (rows padded to a multiple of 16)
 
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
-
-// value of lane C of each 16-lane row, in every lane of that row: one v_mov_b64_dpp row_newbcast
-template <int C> __device__ __forceinline__ double row_bcast_f64(double v) {
-    long long b = __double_as_longlong(v);
-    b = __builtin_amdgcn_update_dpp(b, b, 0x150 + C, 0xf, 0xf, false);
-    return __longlong_as_double(b);
-}
-
-// 1/sqrt(x) to double precision without a division: hardware estimate + two Newton steps
-__device__ __forceinline__ double rsqrt_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
-
-// Column-by-column elimination with the matrix rows spread over the lanes of a 16-lane row (lane r = row r, a[c]
-// = entry (r, c)); unrolled by template recursion because the DPP lane selectors are immediates.
-template <int J, int C> __device__ __forceinline__ void chol_rank1(double (&a)[LNB]) {
-    if constexpr (C < LNB) {
-        a[C] = fma(-a[J], row_bcast_f64<C>(a[J]), a[C]);      // rows r < C carry unused upper-triangle values
-        chol_rank1<J, C + 1>(a);
-    }
-}
-template <int J> __device__ __forceinline__ void chol_diag_cols(double (&a)[LNB], int r, double tol, double &invd) {
-    if constexpr (J < LNB) {
-        const double piv = row_bcast_f64<J>(a[J]);
-        const bool skip = !(piv > tol);
-        const double y = skip ? 0.0 : rsqrt_nr(piv);
-        double l = piv * y;
-        l = skip ? 0.0 : fma(0.5 * y, fma(-l, l, piv), l);
-        if (r == J) { a[J] = l; invd = y; } else a[J] *= y;
-        chol_rank1<J, J + 1>(a);
-        chol_diag_cols<J + 1>(a, r, tol, invd);
-    }
-}
-// x L11^T = a for one matrix row per lane; lane c of every 16-lane row holds row c of L11 (Lr) and 1/L11[c][c]
-template <int J, int C> __device__ __forceinline__ void panel_elim(double (&x)[LNB], double lj) {
-    if constexpr (C < LNB) {
-        x[C] = fma(-x[J], row_bcast_f64<C>(lj), x[C]);
-        panel_elim<J, C + 1>(x, lj);
-    }
-}
-template <int J> __device__ __forceinline__ void panel_cols(double (&x)[LNB], const double (&Lr)[LNB], double invr) {
-    if constexpr (J < LNB) {
-        x[J] *= row_bcast_f64<J>(invr);
-        // L11 does not depend on x, so the optimiser would materialise all 120 broadcasts up front (240 VGPRs, spills):
-        // tie column J's source to x[J] so its broadcasts are formed when they are consumed
-        double lj = Lr[J];
-        asm volatile("" : "+v"(lj) : "v"(x[J]));
-        panel_elim<J, J + 1>(x, lj);
-        panel_cols<J + 1>(x, Lr, invr);
-    }
-}
 
 __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
     const EkfStreamDev &S = streams[blockIdx.y];
@@ -315,11 +260,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     extern __shared__ double s_dyn[];
     double *sM = s_dyn;                            // packed lower, nt rows
     double *sPanT = s_dyn + nt * (nt + 1) / 2;     // [LNB][CHOL_PAN_RS]
-    __shared__ double s_tol, s_mx[CHOL_WAVES], s_L11[LNB][LNB + 1], s_inv[LNB];   // s_L11[j][c] = L11[c][j]
+    __shared__ double s_tol, s_mx[CHOL_WAVES];
+    __shared__ CholBlockShared s_cb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef CHOL_PROF
-    long long tp0 = clock64(), tp_load = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp_store = 0, tq;
-#endif
     // load: one matrix row per wave pass, coalesced along j
     // (8 rows x 3 column chunks = up to 24 loads in flight per lane: the copy is latency bound otherwise)
     for (int i0 = wave * 8; i0 < nt; i0 += CHOL_WAVES * 8) {
@@ -359,98 +302,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
         for (int i = tid; i < n; i += CHOL_THREADS) sM[pk(i, i)] += lam;
         __syncthreads();
     }
-#ifdef CHOL_PROF
-    tq = clock64(); tp_load = tq - tp0; tp0 = tq;
-#endif
     const double tol = 0.0;      // a pivot <= 0 (cannot happen for G + lambda I or for S >= sigma^2 I) zeroes its column
-    for (int kb = 0; kb < n; kb += LNB) {
-        const int nb = min(LNB, n - kb);
-        // ---- 1. diagonal block in the registers of wave 0 (rows >= nb are padded with the identity)
-        if (wave == 0) {
-            int r = lane & 15;
-            asm volatile("" : "+v"(r));      // per-panel value: keeps 16 x 16 lane predicates from being hoisted and spilled
-            // Entries right of the diagonal (and rows past nb in the last panel) are whatever follows in LDS: they
-            // only ever feed other upper-triangle / padded entries, never the factor, and are masked on the way out.
-            double a[LNB];
-            {
-                const double *src = sM + pk(kb + r, kb);
-#pragma unroll
-                for (int c = 0; c < LNB; ++c) a[c] = src[c];
-            }
-            double invd = 0.0;     // lane r keeps 1/L[r][r]
-            chol_diag_cols<0>(a, r, tol, invd);
-            if (lane < LNB) {
-#pragma unroll
-                for (int c = 0; c < LNB; ++c) {
-                    const bool in = c <= r && r < nb;
-                    if (in) sM[pk(kb + r, kb + c)] = a[c];
-                    s_L11[c][r] = in ? a[c] : 0.0;
-                }
-                s_inv[r] = r < nb ? invd : 0.0;
-            }
-        }
-        __syncthreads();
-#ifdef CHOL_PROF
-        tq = clock64(); tp1 += tq - tp0; tp0 = tq;
-#endif
-        // ---- 2. panel rows below: x L11^T = a, one thread per row
-        const int r0 = kb + nb;
-        const int rem = nt - r0;
-        if (wave * 64 < rem) {           // wave-uniform: all 64 lanes take part in the broadcasts
-            // lanes 0..15 hold row (lane) of L11 and 1/diag; every lane owns one matrix row x
-            const int rr = lane & 15;
-            double Lr[LNB];
-#pragma unroll
-            for (int c = 0; c < LNB; ++c) Lr[c] = s_L11[c][rr];
-            const double invr = s_inv[rr];
-            const bool has_row = tid < rem;
-            const int i = r0 + (has_row ? tid : 0);
-            double *row = sM + pk(i, kb);
-            double x[LNB];
-#pragma unroll
-            for (int c = 0; c < LNB; ++c) x[c] = row[c];        // columns >= nb: finite filler, multiplied by 0 below
-            panel_cols<0>(x, Lr, invr);
-            if (has_row) {
-#pragma unroll
-                for (int c = 0; c < LNB; ++c) {
-                    if (c < nb) row[c] = x[c];
-                    sPanT[c * CHOL_PAN_RS + tid] = x[c];
-                }
-            }
-        }
-        __syncthreads();
-#ifdef CHOL_PROF
-        tq = clock64(); tp2 += tq - tp0; tp0 = tq;
-#endif
-        // ---- 3. trailing update on the matrix cores: 16x16 tiles (ta, tb <= ta) of rows/cols r0 + ...
-        const int ntr = (rem + 15) >> 4;
-        const int n_tiles = ntr * (ntr + 1) / 2;
-        {
-            // tiles are numbered row-major over the lower triangle; a wave takes tiles wave, wave + 8, ...
-            int ta = 0, tb = wave;
-            while (tb > ta) { tb -= ta + 1; ++ta; }
-            for (int t = wave; t < n_tiles; t += CHOL_WAVES) {
-                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s4 = 0; s4 < LNB / 4; ++s4) {
-                    const double *pp = sPanT + (4 * s4 + (lane >> 4)) * CHOL_PAN_RS + (lane & 15);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[16 * ta], pp[16 * tb], acc, 0, 0, 0);
-                }
-                const int j = r0 + 16 * tb + (lane & 15);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = r0 + 16 * ta + (lane >> 4) + 4 * q;
-                    if (i < nt && j <= i) sM[pk(i, j)] -= acc[q];
-                }
-                tb += CHOL_WAVES;
-                while (tb > ta) { tb -= ta + 1; ++ta; }
-            }
-        }
-        __syncthreads();
-#ifdef CHOL_PROF
-        tq = clock64(); tp3 += tq - tp0; tp0 = tq;
-#endif
-    }
+    chol_blocked_lds<CHOL_WAVES>(sM, [](int i, int j) { return pk(i, j); }, n, nt, tol, sPanT, CHOL_PAN_RS, s_cb);
     // store back; the trivial IMU block: L = 0 (Gram) or sigma I (S)
     for (int i = wave; i < nt; i += CHOL_WAVES) {
         double *dst = A + (size_t)(off + i) * lda + off;
@@ -468,11 +321,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
         const int i = e / off, j = e - i * off;
         if (j <= i) A[(size_t)i * lda + j] = (i == j) ? l0 : 0.0;
     }
-#ifdef CHOL_PROF
-    __syncthreads();
-    tq = clock64(); tp_store = tq - tp0;
-    if (tid == 0 && blockIdx.y == 0) printf("CHOLPROF which %d n %d load %lld diag %lld panel %lld trail %lld store %lld\n", which, n, tp_load, tp1, tp2, tp3, tp_store);
-#endif
 }
 
 // ------------------------------------------------------------------------------------ r_thin column
