@@ -176,9 +176,11 @@ def main():
     barrier()
     cpu_quota, thr0 = cgroup_cpu()
     t0 = time.perf_counter()
+    run.get_hostprof(reset=True)
     run.run(args.prime + args.warmup, args.steps, pipelined=pipe)   # EXACTLY K timed steps
     barrier()
     elapsed = time.perf_counter() - t0
+    hostprof = run.get_hostprof()
     _, thr1 = cgroup_cpu()
     timing = run.get_timing(reset=True)
     phases = run.get_phases(reset=True)
@@ -232,6 +234,7 @@ def main():
                        "host_cpu_quota": cpu_quota,
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "roofline": roof, "kernels": kernels,
+            "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
             "host_phases_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in phases.items()},
         }
         if not args.no_cpu and world == 1 and args.cpu_frames > 0:

@@ -93,6 +93,11 @@ int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams,
 
 /* All det_rows*det_cols per-cell maxima of the last pushed cam0 image (score 0 = no corner). Synchronises. */
 int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out);
+/* Same, restricted to the cells whose maximum score exceeds min_score (the detector threshold of
+ * image_processor.cpp:132, in 1/256 units), in cell order; out[k].cell identifies the cell.  This is what
+ * detect_features() needs — converting and copying the ~1400 sub-threshold cells of a 752x480 frame was a
+ * measurable share of the host time per frame. */
+int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_corner *out, int capacity, int *n_out);
 
 typedef struct mskf_fe_track_args {
     int32_t n;                    /* number of points */

@@ -341,29 +341,52 @@ extern "C" int mskf_fe_push_stereo_device(mskf_stream *s, const uint8_t *d_cam0,
     return mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 1);
 }
 
-extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out) {
-    if (!s || !out || !n_out) return MSKF_ERR_INVALID;
-    const int n = s->fe.det_rows * s->fe.det_cols;
-    if (capacity < n) return MSKF_ERR_CAPACITY;
+// keys -> corners: score << 32 | ~order, order = row-major position inside the cell (0 = no corner)
+static inline void corner_of_key(const mskf_stream *s, int cell, unsigned long long k, mskf_corner &o) {
+    o.cell = cell;
+    if (k == 0ULL) { o.x = 0.f; o.y = 0.f; o.score = 0; return; }
+    const int cols = s->fe.det_cols, cw = s->det_cw, ch = s->det_ch;
+    const unsigned int order = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFULL);
+    const int cy = cell / cols, cx = cell - cy * cols;
+    o.score = (int)(k >> 32);
+    o.y = (float)(cy * ch + (int)(order / (unsigned)cw));
+    o.x = (float)(cx * cw + (int)(order % (unsigned)cw));
+}
+
+static int cell_keys_ready(mskf_stream *s) {
     if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(s->ctx->device));
     if (s->push_gen != s->ctx->push_gen) { mskf_set_error("cell maxima are stale: another push happened on this context"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));   // no ctx mutation here: callable concurrently for different streams
-    // keys -> corners: score << 32 | ~order, order = row-major position inside the cell (0 = no corner)
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out) {
+    if (!s || !out || !n_out) return MSKF_ERR_INVALID;
+    const int n = s->fe.det_rows * s->fe.det_cols;
+    if (capacity < n) return MSKF_ERR_CAPACITY;
+    const int rc = cell_keys_ready(s);
+    if (rc != MSKF_OK) return rc;
     const unsigned long long *keys = (const unsigned long long *)(s->ctx->cell_arena.h + s->cell_off);
-    const int cols = s->fe.det_cols, cw = s->det_cw, ch = s->det_ch;
-    for (int cell = 0; cell < n; ++cell) {
-        mskf_corner &o = out[cell];
-        o.cell = cell;
-        const unsigned long long k = keys[cell];
-        if (k == 0ULL) { o.x = 0.f; o.y = 0.f; o.score = 0; continue; }
-        const unsigned int order = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFULL);
-        const int cy = cell / cols, cx = cell - cy * cols;
-        o.score = (int)(k >> 32);
-        o.y = (float)(cy * ch + (int)(order / (unsigned)cw));
-        o.x = (float)(cx * cw + (int)(order % (unsigned)cw));
-    }
+    for (int cell = 0; cell < n; ++cell) corner_of_key(s, cell, keys[cell], out[cell]);
     *n_out = n;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_corner *out, int capacity, int *n_out) {
+    if (!s || !out || !n_out) return MSKF_ERR_INVALID;
+    const int n = s->fe.det_rows * s->fe.det_cols;
+    const int rc = cell_keys_ready(s);
+    if (rc != MSKF_OK) return rc;
+    const unsigned long long *keys = (const unsigned long long *)(s->ctx->cell_arena.h + s->cell_off);
+    int m = 0;
+    for (int cell = 0; cell < n; ++cell) {
+        const unsigned long long k = keys[cell];
+        if ((long long)(k >> 32) <= (long long)min_score) continue;       // also skips empty cells (key 0)
+        if (m >= capacity) return MSKF_ERR_CAPACITY;
+        corner_of_key(s, cell, k, out[m++]);
+    }
+    *n_out = m;
     return MSKF_OK;
 }
 

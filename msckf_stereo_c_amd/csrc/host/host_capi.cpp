@@ -2,6 +2,7 @@
 // tests and bench.py.  This is host glue above the C-ABI of include/mskf_hip.h, not part of it.
 #include <cstring>
 #include "batch_runner.h"
+#include "host_prof.h"
 
 using namespace cg;
 
@@ -78,6 +79,16 @@ void mskfh_runner_get_phases(void *h, double *out, int reset) {
     for (int g = 0; g < r->n_groups(); ++g)
         for (int k = 0; k < BatchGroup::PH_COUNT; ++k) { out[k] += r->group(g).phase_s[k]; if (reset) r->group(g).phase_s[k] = 0; }
 }
+
+// host bookkeeping accounting (host_prof.h): seconds per slot summed over all streams/threads; returns the slot count
+int mskfh_get_hostprof(double *out, int capacity, int reset) {
+    for (int k = 0; k < cg::hostprof::N_SLOTS && k < capacity; ++k) {
+        out[k] = (double)cg::hostprof::counters()[k].load() * 1e-9;
+        if (reset) cg::hostprof::counters()[k].store(0);
+    }
+    return cg::hostprof::N_SLOTS;
+}
+const char *mskfh_hostprof_name(int slot) { return cg::hostprof::name(slot); }
 
 // ---- per-stream inspection
 int mskfh_num_features(void *h, int stream) {

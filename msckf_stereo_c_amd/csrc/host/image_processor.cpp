@@ -1,6 +1,7 @@
 // image_processor.cpp — host mirror of cg::ImageProcessor; see image_processor.h.
 // Reference: msckf_core/src/image_processor.cpp (line numbers cited per function).
 #include "image_processor.h"
+#include "host_prof.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -179,11 +180,12 @@ void ImageProcessor::detectFeatures(std::vector<Point2f> &pts, std::vector<doubl
     const int cells = cfg_.det_rows * cfg_.det_cols;
     cell_max_.resize(cells);
     int n = 0;
-    int rc = mskf_fe_get_cell_maxima(stream_, cell_max_.data(), cells, &n);
+    // only the cells whose maximum beats the detector threshold come back (in cell order)
+    int rc = mskf_fe_get_cell_candidates(stream_, cfg_.fast_threshold * 256, cell_max_.data(), cells, &n);
     pts.clear(); responses.clear();
-    if (rc != MSKF_OK) { fail("mskf_fe_get_cell_maxima", rc); return; }
+    if (rc != MSKF_OK) { fail("mskf_fe_get_cell_candidates", rc); return; }
     for (int i = 0; i < n; ++i) {
-        if (cell_max_[i].score > cfg_.fast_threshold * 256 && !occupancy_[i]) {
+        if (!occupancy_[cell_max_[i].cell]) {
             pts.push_back(Point2f(cell_max_[i].x, cell_max_[i].y));
             responses.push_back((double)cell_max_[i].score / 256.0);
         }
@@ -252,6 +254,7 @@ void ImageProcessor::phasePrepare1(mskf_fe_track_args &args) {
         return;
     }
     // trackFeatures head (:352-410)
+    hostprof::Scope hp(hostprof::FE_PREPARE);
     hm::Mat3 cam0_R_p_c, cam1_R_p_c;
     integrateImuData(cam0_R_p_c, cam1_R_p_c);
     t_ids_.clear(); t_lifetime_.clear(); in_pts_.clear();
@@ -268,10 +271,25 @@ void ImageProcessor::phasePrepare1(mskf_fe_track_args &args) {
 
 static bool cmpResponse(const float &a, const float &b) { return a > b; }
 
+// std::stable_sort allocates a merge buffer on every call; the per-cell lists it is used on hold a handful of
+// entries, for which a stable insertion sort gives the same order without touching the allocator
+template <class It, class Cmp>
+static void small_stable_sort(It b, It e, Cmp cmp) {
+    if (e - b > 32) { std::stable_sort(b, e, cmp); return; }
+    for (It i = b; i != e; ++i)
+        for (It j = i; j != b && cmp(*j, *(j - 1)); --j) std::iter_swap(j, j - 1);
+}
+
+// empty every cell list but keep the storage (and the keys) of the map
+void ImageProcessor::resetGrid(GridFeatures &g) const {
+    for (auto &kv : g) kv.second.clear();
+    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) g[code];
+}
+
 // :270-316
 void ImageProcessor::initializeFirstFrameTail() {
-    GridFeatures grid_new_features;
-    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) grid_new_features[code] = std::vector<FeatureMetaData>(0);
+    GridFeatures &grid_new_features = grid_new_features_;
+    resetGrid(grid_new_features);
     for (size_t i = 0; i < status_.size(); ++i) {
         if (!(status_[i] & 2)) continue;
         FeatureMetaData nf;
@@ -286,8 +304,8 @@ void ImageProcessor::initializeFirstFrameTail() {
         grid_new_features[row * cfg_.grid_col + col].push_back(nf);
     }
     for (auto &item : grid_new_features)   // Q19: stable sort is the defined behaviour
-        std::stable_sort(item.second.begin(), item.second.end(),
-                         [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
+        small_stable_sort(item.second.begin(), item.second.end(),
+                          [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
     for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) {
         std::vector<FeatureMetaData> &features_this_grid = (*curr_features_ptr)[code];
         std::vector<FeatureMetaData> &new_features_this_grid = grid_new_features[code];
@@ -329,15 +347,21 @@ void ImageProcessor::trackFeaturesTail() {
 
 // :622-688
 void ImageProcessor::addNewFeaturesHead() {
-    for (const auto &features : *curr_features_ptr)
-        for (const auto &feature : features.second) {
-            const int y = static_cast<int>(feature.cam0_point.y);
-            const int x = static_cast<int>(feature.cam0_point.x);
-            setGridPosition((float)x, (float)y);
-        }
+    {
+        hostprof::Scope hp(hostprof::FE_OCCUPANCY);
+        for (const auto &features : *curr_features_ptr)
+            for (const auto &feature : features.second) {
+                const int y = static_cast<int>(feature.cam0_point.y);
+                const int x = static_cast<int>(feature.cam0_point.x);
+                setGridPosition((float)x, (float)y);
+            }
+    }
     std::vector<Point2f> new_features;
-    detectFeatures(new_features, cand_responses_det_);
-    std::vector<std::vector<std::pair<Point2f, double>>> sieve((size_t)cfg_.grid_row * cfg_.grid_col);
+    { hostprof::Scope hp(hostprof::FE_DETECT); detectFeatures(new_features, cand_responses_det_); }
+    hostprof::Scope hp_sieve(hostprof::FE_SIEVE);
+    std::vector<std::vector<std::pair<Point2f, double>>> &sieve = sieve_;
+    sieve.resize((size_t)cfg_.grid_row * cfg_.grid_col);
+    for (auto &cell : sieve) cell.clear();
     for (size_t i = 0; i < new_features.size(); ++i) {
         int row = static_cast<int>(new_features[i].y / grid_height);
         int col = static_cast<int>(new_features[i].x / grid_width);
@@ -348,8 +372,8 @@ void ImageProcessor::addNewFeaturesHead() {
     in_pts_.clear(); cand_responses_sieved_.clear();
     for (auto &item : sieve) {
         if ((int)item.size() > cfg_.grid_max_feature_num) {
-            std::stable_sort(item.begin(), item.end(),
-                             [](const std::pair<Point2f, double> &a, const std::pair<Point2f, double> &b) { return a.second > b.second; });
+            small_stable_sort(item.begin(), item.end(),
+                              [](const std::pair<Point2f, double> &a, const std::pair<Point2f, double> &b) { return a.second > b.second; });
             item.erase(item.begin() + cfg_.grid_max_feature_num, item.end());
         }
         for (const auto &p : item) { in_pts_.push_back(mskf_point2f{p.first.x, p.first.y}); cand_responses_sieved_.push_back(p.second); }
@@ -359,8 +383,8 @@ void ImageProcessor::addNewFeaturesHead() {
 // :690-750
 void ImageProcessor::addNewFeaturesTail() {
     const bool q4 = (cfg_.compat_flags & MSKF_COMPAT_Q4_RESPONSE_INDEX) != 0;
-    GridFeatures grid_new_features;
-    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) grid_new_features[code] = std::vector<FeatureMetaData>(0);
+    GridFeatures &grid_new_features = grid_new_features_;
+    resetGrid(grid_new_features);
     for (size_t i = 0; i < status_.size(); ++i) {
         if (!(status_[i] & 2)) continue;
         FeatureMetaData nf;
@@ -375,8 +399,8 @@ void ImageProcessor::addNewFeaturesTail() {
         grid_new_features[row * cfg_.grid_col + col].push_back(nf);
     }
     for (auto &item : grid_new_features)
-        std::stable_sort(item.second.begin(), item.second.end(),
-                         [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
+        small_stable_sort(item.second.begin(), item.second.end(),
+                          [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
     for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) {
         std::vector<FeatureMetaData> &features_this_grid = (*curr_features_ptr)[code];
         std::vector<FeatureMetaData> &new_features_this_grid = grid_new_features[code];
@@ -395,8 +419,8 @@ void ImageProcessor::pruneGridFeatures() {
     for (auto &item : *curr_features_ptr) {
         auto &grid_features = item.second;
         if ((int)grid_features.size() <= cfg_.grid_max_feature_num) continue;
-        std::stable_sort(grid_features.begin(), grid_features.end(),
-                         [](const FeatureMetaData &a, const FeatureMetaData &b) { return a.lifetime > b.lifetime; });
+        small_stable_sort(grid_features.begin(), grid_features.end(),
+                          [](const FeatureMetaData &a, const FeatureMetaData &b) { return a.lifetime > b.lifetime; });
         grid_features.erase(grid_features.begin() + cfg_.grid_max_feature_num, grid_features.end());
     }
 }
@@ -409,7 +433,7 @@ void ImageProcessor::phaseAfter1(mskf_fe_track_args &args2) {
         stage_ = 0;
         return;
     }
-    trackFeaturesTail();
+    { hostprof::Scope hp(hostprof::FE_TRACK_TAIL); trackFeaturesTail(); }
     addNewFeaturesHead();
     fill_args(args2, (int)in_pts_.size(), 0, in_pts_, out0_, out1_, und0_, und1_, status_);
     stage_ = 3;
@@ -417,8 +441,8 @@ void ImageProcessor::phaseAfter1(mskf_fe_track_args &args2) {
 
 void ImageProcessor::phaseAfter2(bool is_draw) {
     if (stage_ == 3) {
-        addNewFeaturesTail();
-        pruneGridFeatures();
+        { hostprof::Scope hp(hostprof::FE_NEW_TAIL); addNewFeaturesTail(); }
+        { hostprof::Scope hp(hostprof::FE_PRUNE); pruneGridFeatures(); }
         stage_ = 0;
     }
     if (is_draw) {   // :163-184
@@ -428,13 +452,13 @@ void ImageProcessor::phaseAfter2(bool is_draw) {
         for (const auto &g : *prev_features_ptr) for (const auto &f : g.second) { prev_cam0_points_[f.id] = f.cam0_point; prev_cam1_points_[f.id] = f.cam1_point; }
         for (const auto &g : *curr_features_ptr) for (const auto &f : g.second) { curr_cam0_points_[f.id] = f.cam0_point; curr_cam1_points_[f.id] = f.cam1_point; }
     }
+    hostprof::Scope hp_pub(hostprof::FE_PUBLISH);
     publish();
     // :192-200
     if (!(cfg_.compat_flags & MSKF_COMPAT_Q2_PREV_ALIAS)) cam0_prev_time = cam0_curr_time;
-    prev_features_ptr = curr_features_ptr;
+    std::swap(prev_features_ptr, curr_features_ptr);     // prev <- the grid just published; the old prev is recycled
     mskf_fe_swap(stream_);
-    curr_features_ptr.reset(new GridFeatures());
-    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) (*curr_features_ptr)[code] = std::vector<FeatureMetaData>(0);
+    resetGrid(*curr_features_ptr);
 }
 
 // :1137-1182

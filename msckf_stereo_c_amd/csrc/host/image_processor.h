@@ -101,6 +101,7 @@ class ImageProcessor {
     void addNewFeaturesHead();
     void addNewFeaturesTail();
     void pruneGridFeatures();
+    void resetGrid(GridFeatures &g) const;
     void publish();
     void fail(const char *what, int rc);
 
@@ -134,6 +135,8 @@ class ImageProcessor {
     std::vector<double> cand_responses_det_;     // responses in detection order (Q4)
     std::vector<double> cand_responses_sieved_;  // responses in sieve order
     std::vector<mskf_corner> cell_max_;
+    GridFeatures grid_new_features_;                                     // per-frame scratch, storage reused
+    std::vector<std::vector<std::pair<Point2f, double>>> sieve_;         // per-frame scratch, storage reused
     size_t max_published_ = 0;
     int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
     std::ofstream debug_;

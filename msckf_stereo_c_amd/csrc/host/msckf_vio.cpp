@@ -1,6 +1,7 @@
 // msckf_vio.cpp — host mirror of cg::MsckfVio; see msckf_vio.h.
 // Reference: msckf_core/src/msckf_vio.cpp and msckf_core/include/feature.hpp (lines cited per function).
 #include "msckf_vio.h"
+#include "host_prof.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -168,10 +169,10 @@ bool MsckfVio::phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args
     if (is_first_img) { is_first_img = false; state_server.imu_state.time = msg->time_stamp; }
     frame_active_ = true;
     frame_time_ = msg->time_stamp;
-    batchImuProcessing(msg->time_stamp);
-    stateAugmentation(msg->time_stamp);
-    addFeatureObservations(msg);
-    buildLostFeatureUpdate(upd);
+    { hostprof::Scope hp(hostprof::EKF_IMU); batchImuProcessing(msg->time_stamp); }
+    { hostprof::Scope hp(hostprof::EKF_AUGMENT); stateAugmentation(msg->time_stamp); }
+    { hostprof::Scope hp(hostprof::EKF_ADD_OBS); addFeatureObservations(msg); }
+    { hostprof::Scope hp(hostprof::EKF_BUILD_LOST); buildLostFeatureUpdate(upd); }
     return true;
 }
 
@@ -404,7 +405,7 @@ void MsckfVio::buildLostFeatureUpdate(mskf_ekf_update_args &upd) {
         feats_.push_back(f);
         feat_ids_.push_back(feature.id);
     }
-    for (const auto &id : invalid_ids) map_server.erase(id);
+    map_server.erase_many(invalid_ids);
     packClones();
     finishArgs(upd, -1, 1);   // Q12 dof = #obs - 1, Q13 row cap
 }
@@ -438,9 +439,11 @@ void MsckfVio::applyCorrection(const std::vector<double> &dx) {
 void MsckfVio::phaseB(mskf_ekf_update_args &upd) {
     // tail of removeLostFeatures (:1016-1021)
     if (!feats_.empty()) {
-        if (rows_out_ > 0) applyCorrection(delta_x_);
-        for (const auto &fid : feat_ids_) map_server.erase(fid);
+        if (rows_out_ > 0) { hostprof::Scope hp(hostprof::EKF_APPLY1); applyCorrection(delta_x_); }
+        hostprof::Scope hp(hostprof::EKF_ERASE_LOST);
+        map_server.erase_many(feat_ids_);
     }
+    hostprof::Scope hp(hostprof::EKF_BUILD_PRUNE);
     buildPruneUpdate(upd);
 }
 
@@ -525,6 +528,7 @@ void MsckfVio::phaseC(bool defer_device) {
     pending_rm_[0] = pending_rm_[1] = -1;
     if (!frame_active_) return;
     if (prune_pending_) {
+        hostprof::Scope hp(hostprof::EKF_TAIL_PRUNE);
         // tail of pruneCamStateBuffer (:1100-1181)
         for (size_t j = 0; j < feats_.size(); ++j) {
             Feature &feature = map_server[feat_ids_[j]];
@@ -549,6 +553,7 @@ void MsckfVio::phaseC(bool defer_device) {
         }
         prune_pending_ = false;
     }
+    hostprof::Scope hp_pub(hostprof::EKF_PUBLISH);
     publish(frame_time_);
 }
 

@@ -16,6 +16,7 @@
 #include <vector>
 #include "../../../include/mskf_hip.h"
 #include "cg_types.h"
+#include "flat_map.h"
 #include "yaml_lite.h"
 
 namespace cg {
@@ -50,11 +51,11 @@ typedef std::map<StateIDType, CAMState> CamStateServer;
 
 struct Feature {   // feature.hpp:31-163 (triangulation itself runs on the device)
     FeatureIDType id = 0;
-    std::map<StateIDType, std::array<double, 4>> observations;
+    FlatMap<StateIDType, std::array<double, 4>> observations;   // feature.hpp:139 keeps a std::map; see flat_map.h
     Vector3 position;
     bool is_initialized = false;
 };
-typedef std::map<FeatureIDType, Feature> MapServer;
+typedef FlatMap<FeatureIDType, Feature> MapServer;
 
 class MsckfVio {
   public:

@@ -136,6 +136,14 @@ class Runner:
         self.L.mskfh_runner_get_phases(self.h, _p(out), int(reset))
         return {n: float(out[i]) for i, n in enumerate(self.PHASES)}
 
+    def get_hostprof(self, reset=True):
+        """Seconds of host bookkeeping per slot of csrc/host/host_prof.h, summed over all streams and threads."""
+        out = np.zeros(64)
+        self.L.mskfh_get_hostprof.restype = C.c_int
+        self.L.mskfh_hostprof_name.restype = C.c_char_p
+        n = self.L.mskfh_get_hostprof(_p(out), 64, int(reset))
+        return {self.L.mskfh_hostprof_name(i).decode(): float(out[i]) for i in range(n)}
+
     def hip_stream(self, stream=0):
         return self.L.mskfh_group_hip_stream(self.h, stream)
 
