@@ -77,6 +77,12 @@ def test_lk_temporal_and_stereo_bit_exact(gpu_ctx, oracle, w, h, seed):
     rng = np.random.default_rng(seed)
     extra = np.stack([rng.uniform(-20, w + 20, 64), rng.uniform(-20, h + 20, 64)], 1).astype(np.float32)
     pts = np.concatenate([pts, extra, np.array([[0, 0], [w - 1, h - 1], [3.5, 2.25], [w - 2.5, 7.75]], np.float32)])
+    # sub-pixel offsets whose 14-bit fractions multiply to 8192: the fourth bilinear weight is -1 there
+    # (16384 - w00 - w01 - w10 with all three rounded up), which the packed 16-bit dot products must reproduce
+    det = pts[:40].copy()
+    for k, (fa, fb) in enumerate([(64, 128), (2, 4096), (8192, 1), (128, 64), (1024, 8), (16, 512)]):
+        det[k::6] = np.floor(det[k::6]) + np.array([fa / 16384.0, fb / 16384.0], np.float32)
+    pts = np.concatenate([pts, det]).astype(np.float32)
     s.swap()
     s.push_stereo(a1, b1)
     # --- temporal + stereo (trackFeatures path)
