@@ -54,12 +54,24 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     else                      { A = S.T;  B = S.T;  C = S.P; M = N = d; K = d; alpha = -1.0; beta = 1.0; }
     const int tiles_n = (N + GT - 1) / GT, tiles_m = (M + GT - 1) / GT;
     const int tile = blockIdx.x;
-    if (MODE == GM_PUPD && tile == tiles_m * tiles_n) {
-        // one extra workgroup: delta_x = Y^T w, w = column d of Y (msckf_vio.cpp:860)
-        for (int c = threadIdx.x; c < d; c += 256) {
-            double s2 = 0;
-            for (int k = 0; k < d; ++k) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
-            S.delta_x[c] = s2;
+    if (MODE == GM_PUPD && tile >= tiles_m * tiles_n) {
+        // tiles_n extra workgroups: delta_x = Y^T w, w = column d of Y (msckf_vio.cpp:860); 32 columns each,
+        // the K range split over the 8 thread rows and reduced through LDS
+        const int c0 = (tile - tiles_m * tiles_n) * GT;
+        if (c0 >= d) return;
+        __shared__ double s_part[8][GT + 1];
+        const int cl = threadIdx.x & 31, ks = threadIdx.x >> 5;
+        const int c = c0 + cl;
+        double s2 = 0;
+        if (c < d)
+            for (int k = ks; k < d; k += 8) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
+        s_part[ks][cl] = s2;
+        __syncthreads();
+        if (ks == 0 && c < d) {
+            double t = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += s_part[q][cl];
+            S.delta_x[c] = t;
         }
         return;
     }
@@ -352,12 +364,35 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
         const int i = e >> 5, cc = e & 31;
         sY[e] = (c0 + cc < ncols) ? B[(size_t)i * ld + c0 + cc] : 0.0;
     }
+    // L row blocks are prefetched one block ahead into registers: 16 threads per row, columns lr, lr + 16, ...
+    constexpr int LPF = 14;                       // ceil((max d + 16) / 16) for d <= 208
+    const int lrow = tid >> 4, lr = tid & 15;
+    double lpf[LPF];
+    auto fetch_L = [&](int ib) {
+        const int nb = min(TS_RB, n - ib), wcols = ib + nb;
+#pragma unroll
+        for (int q = 0; q < LPF; ++q) {
+            const int p = lr + 16 * q;
+            lpf[q] = (lrow < nb && p < wcols) ? L[(size_t)(ib + lrow) * ld + p] : 0.0;
+        }
+    };
+    const bool l_fits = n + TS_RB <= 16 * LPF;    // else fall back to direct staging
+    if (l_fits) fetch_L(0);
     for (int ib = 0; ib < n; ib += TS_RB) {
         const int nb = min(TS_RB, n - ib);
         __syncthreads();
-        for (int e = tid; e < nb * (ib + nb); e += 256) {
-            const int i = e / (ib + nb), p = e - i * (ib + nb);
-            sL[(size_t)i * (n + 1) + p] = L[(size_t)(ib + i) * ld + p];
+        if (l_fits) {
+#pragma unroll
+            for (int q = 0; q < LPF; ++q) {
+                const int p = lr + 16 * q;
+                if (lrow < nb && p < ib + nb) sL[(size_t)lrow * (n + 1) + p] = lpf[q];
+            }
+            if (ib + TS_RB < n) fetch_L(ib + TS_RB);
+        } else {
+            for (int e = tid; e < nb * (ib + nb); e += 256) {
+                const int i = e / (ib + nb), p = e - i * (ib + nb);
+                sL[(size_t)i * (n + 1) + p] = L[(size_t)(ib + i) * ld + p];
+            }
         }
         __syncthreads();
         // GEMM part: rows r8 and r8 + 8 of the block against all previous rows of the strip
@@ -412,7 +447,7 @@ __global__ __launch_bounds__(256) void k_ekf_dx(const EkfStreamDev *streams) {
 extern "C" {
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st) {
     const int t = (max_mn + GT - 1) / GT;
-    const dim3 grid(t * t + (mode == GM_PUPD ? 1 : 0), n);
+    const dim3 grid(t * t + (mode == GM_PUPD ? t : 0), n);
     switch (mode) {
         case GM_GRAM: hipLaunchKernelGGL(k_ekf_gemm<GM_GRAM>, grid, dim3(256), 0, st, d); break;
         case GM_T:    hipLaunchKernelGGL(k_ekf_gemm<GM_T>, grid, dim3(256), 0, st, d); break;
