@@ -242,3 +242,27 @@ def test_blackout_and_recovery(oracle):
     assert osys.num_updates() == run.num_updates() > 10
     compare_poses(osys, run)
     run.close()
+
+
+def test_trajectory_error_against_ground_truth(oracle):
+    """SURVEY §8(d) metric 2: ATE RMSE (Horn alignment, tools/ate_rmse.py) of the GPU trajectory against the synthetic
+    ground truth is the oracle's (centimetres), and against the oracle's trajectory it is ~0."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("ate_rmse", os.path.join(os.path.dirname(__file__), "..", "tools", "ate_rmse.py"))
+    ate = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ate)
+    syn = oracle.Synth(width=376, height=240)
+    n = 110
+    osys, run = _lockstep(oracle, syn, default_fe_cfg(), default_ekf_cfg(), n, check_every=10)
+    gp, op = run.poses(0), osys.poses()
+    assert len(gp) == len(op) > 80
+    k0 = n - len(gp)
+    gt_t = np.array([syn.frame_time(k) for k in range(k0, n)])
+    gt_p = np.array([syn.gt_pose(k)["p"] for k in range(k0, n)])
+    r_gt = ate.ate_rmse(gp["t"], gp["p"], gt_t, gt_p, max_dt=1e-3)
+    r_or = ate.ate_rmse(op["t"], op["p"], gt_t, gt_p, max_dt=1e-3)
+    r_x = ate.ate_rmse(gp["t"], gp["p"], op["t"], op["p"], max_dt=1e-6)
+    assert r_gt["pairs"] == len(gp)
+    assert r_gt["rmse"] < 0.03 and abs(r_gt["rmse"] - r_or["rmse"]) < 1e-6
+    assert r_x["rmse"] < 1e-6
+    run.close()
