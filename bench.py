@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "256")), help="VIO streams per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "512")), help="VIO streams per GPU")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "8")), help="host thread groups per GPU")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("MSKF_BENCH_HOST_THREADS", "1")), help="host threads per group")
     ap.add_argument("--no-pipeline", action="store_true", help="run front-end and filter of a group in lockstep on one thread")
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--grid", type=str, default="8x10x4x5", help="rows x cols x min x max features per cell")
     ap.add_argument("--prime", type=int, default=75, help="untimed frames before warmup: gravity init + clone window fill")
     ap.add_argument("--loop", type=int, default=100, help="frames per trajectory period")
-    ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=150, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("MSKF_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
@@ -213,7 +213,7 @@ def main():
         # separately, profiles/r01_pmc_hbm_traffic.json); only comparable when a launch covers the same 32 streams
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"].get(dom)
-            if pmc and per_group == 32:
+            if pmc and per_group == 64:
                 roof["traffic"] = (pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
                 roof["traffic_note"] = "bytes/launch, raw FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (no gfx950 correction applied)"
         except Exception:

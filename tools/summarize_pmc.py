@@ -30,7 +30,7 @@ def main():
     ft, fc = agg(fetch, "FETCH_SIZE")
     wt, wc = agg(write, "WRITE_SIZE")
     res = {"command": cmd,
-           "note": "KB per launch, RAW FETCH_SIZE / WRITE_SIZE (separate passes); default workload = 32 streams per launch; "
+           "note": "KB per launch, RAW FETCH_SIZE / WRITE_SIZE (separate passes); default workload = 64 streams per launch; "
                    "gfx950 FETCH_SIZE halves wide 16 B/lane streams, narrower widths are uncalibrated: no factor applied",
            "kernels": {k: {"launches": fc[k], "fetch_kb_per_launch": round(ft[k] / fc[k], 1),
                            "write_kb_per_launch": round(wt.get(k, 0) / max(wc.get(k, 1), 1), 1)} for k in sorted(ft)}}
