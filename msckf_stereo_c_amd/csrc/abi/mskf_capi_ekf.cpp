@@ -9,7 +9,7 @@ extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
-void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st);
+void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, int max_clones, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
@@ -504,7 +504,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         MSKF_HIPCHK(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
-        ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, st);
+        ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, (max_d - 21) / 6, st);
         mskf_t_end(ctx, ts, (long long)fl_feat);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);

@@ -12,6 +12,7 @@
 // symmetric by construction); one workgroup handles one VIO stream (or one feature of one
 // stream), blockIdx.y is the stream of the batch.
 #include <mutex>
+#include <type_traits>
 #include "ekf_device.h"
 #include "chol_block.h"
 
@@ -252,15 +253,19 @@ __global__ void k_ekf_posvar(const EkfStreamDev *streams, int n, double *out) {
 // ------------------------------------------------------------------------------------ feature blocks
 #define MAX_CLONES_DEV 64          // 4*64 = 256 block rows max per feature
 
-struct TriScratch {
-    double R[2 * MAX_CLONES_DEV][9];
-    double t[2 * MAX_CLONES_DEV][3];
-    double z[2 * MAX_CLONES_DEV][2];
+template <int NMEAS>
+struct TriScratchT {     // poses and rays of the 2 * n_init stereo measurements of one feature
+    double R[NMEAS][9];
+    double t[NMEAS][3];
+    double z[NMEAS][2];
 };
+typedef TriScratchT<2 * MAX_CLONES_DEV> TriScratch;
+#define TRI_SMALL_CLONES 32       // the wave-per-feature variant triangulates over at most this many clones
 
 // Levenberg-Marquardt inverse-depth triangulation, executed by wave 0 of the workgroup.
 // feature.hpp:289-450; parameters feature.hpp:46-52.
-__device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, TriScratch &ts, double *pos_out) {
+template <class TS>
+__device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, TS &ts, double *pos_out) {
     const int lane = threadIdx.x & 63;
     const int n_meas = 2 * F.n_init;
     // first camera pose (camera -> world): R0 = R(q)^T, t0 = p
@@ -439,16 +444,20 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
     __shared__ int sCloneOfObs_all[NSUB][MAXC];
     extern __shared__ double s_arena_all[];
     double *s_arena = s_arena_all + (size_t)sub * arena_doubles;
-    TriScratch &sTri = *reinterpret_cast<TriScratch *>(s_arena);
+    typedef typename std::conditional<WAVE, TriScratchT<2 * TRI_SMALL_CLONES>, TriScratch>::type TriT;
+    TriT &sTri = *reinterpret_cast<TriT *>(s_arena);
     __shared__ double sW_all[NSUB][4 * MAXC];
+    __shared__ double sRo_all[NSUB][4 * MAXC];      // projected residual r_o (also written to global for the stacked system)
     __shared__ double sPos_all[NSUB][3];
     __shared__ int sValid_all[NSUB];
     __shared__ double sRed[8];
-    double *sBeta = sBeta_all[sub], *sVV = sVV_all[sub], *sW = sW_all[sub], *sPos = sPos_all[sub];
+    double *sBeta = sBeta_all[sub], *sVV = sVV_all[sub], *sW = sW_all[sub], *sPos = sPos_all[sub], *sRo = sRo_all[sub];
     int *sObsOfClone = sObsOfClone_all[sub], *sCloneOfObs = sCloneOfObs_all[sub];
     int &sValid = sValid_all[sub];
     auto GSYNC = [&]() {
-        if (WAVE) { __builtin_amdgcn_wave_barrier(); __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+        // one wave: its LDS operations execute in program order, only the compiler has to be kept from reordering
+        // them (no global memory is written and read back inside a feature: the residual travels through sRo)
+        if (WAVE) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     };
     auto gsum = [&](double v) { return WAVE ? wave_sum(v) : block_sum(v, sRed); };
@@ -607,6 +616,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         for (int i = 3 + gt; i < rows; i += GS) {
             const double rv = sr[i] - sCoef[6 * M][0] * sV[0][i] - sCoef[6 * M][1] * sV[1][i] - sCoef[6 * M][2] * sV[2][i];
             r0[i - 3] = rv;
+            sRo[i - 3] = rv;
             Hrow0[(size_t)(i - 3) * ld + d] = rv;   // column d of the stacked matrix carries the residual ([H | r])
         }
         GSYNC();
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         const bool blocked = !WAVE && (rows <= lds_rows) && (MAXC == 32);
         if (blocked) {
             // packed row `rows` (columns 3 ..) carries r_o: the blocked factorisation leaves L^-1 r_o there
-            for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; SG(n, i) = r0[i]; }
+            for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; SG(n, i) = sRo[i]; }
             for (int i = gt; i < LNB * GATE_PAN_RS; i += GS) s_blk[i] = 0.0;       // panel buffer (scratch is dead)
             if (gt < 16) Mm[pk(rows, 3 + n) + gt] = 0.0;                          // readable slack behind the last row
             GSYNC();
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             for (int i = gt; i < n; i += GS) { bad |= !(SG(i, i) > 0.0); sW[i] = SG(n, i); }
             pd_ok = !__syncthreads_or(bad);
         } else {
-            for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; sW[i] = r0[i]; }
+            for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; sW[i] = sRo[i]; }
             GSYNC();
             for (int k = 0; k < n; ++k) {
                 const double dk = SG(k, k);
@@ -818,17 +828,17 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunc
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);
 }
-void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, hipStream_t st) {
+void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, int max_clones, hipStream_t st) {
     const int packed_max = ((GATE_LDS_ROWS + 1) * (GATE_LDS_ROWS + 2) / 2 + 16) * (int)sizeof(double);   // + the r_o row + slack
-    const int tri_doubles = (int)((sizeof(TriScratch) + 7) / 8);
+    const int tri_doubles = (int)((sizeof(TriScratchT<2 * TRI_SMALL_CLONES>) + 7) / 8);
     static std::once_flag attr_once;
     std::call_once(attr_once, [=]() {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<MAX_CLONES_DEV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * tri_doubles * 8);
     });
-    if (max_rows <= 16) {
-        // every feature has <= 4 Jacobian observations: one wavefront per feature, four per workgroup
+    if (max_rows <= 16 && max_clones <= TRI_SMALL_CLONES) {
+        // every feature has <= 4 Jacobian observations (and its triangulation fits the small scratch): one wavefront per feature, four per workgroup
         const int groups = (max_feat + 3) / 4;
         const int slots = groups < EKF_SLOTS ? (groups > 0 ? groups : 1) : EKF_SLOTS;
         hipLaunchKernelGGL((k_ekf_feature_blocks<4, true>), dim3(slots, n), dim3(WG), (size_t)4 * tri_doubles * 8, st, d, 16, tri_doubles);

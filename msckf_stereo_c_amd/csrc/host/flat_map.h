@@ -26,6 +26,12 @@ class FlatMap {
     bool empty() const { return v_.empty(); }
     void clear() { v_.clear(); }
     void reserve(size_t n) { v_.reserve(n); }
+    // positional access (valid until the next insert / erase)
+    value_type &nth(size_t i) { return v_[i]; }
+    const value_type &nth(size_t i) const { return v_[i]; }
+    size_t index_of(const_iterator it) const { return (size_t)(it - v_.begin()); }
+    const K &back_key() const { return v_.back().first; }
+    const K &front_key() const { return v_.front().first; }
 
     iterator find(const K &k) {
         if (!v_.empty() && v_.back().first == k) return v_.end() - 1;       // the newest key is the common query

@@ -309,17 +309,25 @@ void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
         if (zero_tail_total_ > total) total = zero_tail_total_;          // truncated snapshot of a longer message
         if (zero_tail_start_ < total) n_full = std::min(n_full, zero_tail_start_ + 1);
     }
-    for (size_t k = 0; k < n_full; ++k) {
-        const FeatureMeasurement &f = msg->features[k];
-        const FeatureIDType fid = (FeatureIDType)f.id;
-        auto it = map_server.find(fid);
-        if (it == map_server.end()) {
-            Feature &nf = map_server[fid];
+    // The reference walks the message in order and looks every id up in map_server.  Same result with one ordered
+    // sweep: the records are visited in ascending id (equal ids keep their message order, which is what decides the
+    // surviving observation and the tracked count when the uncleared message carries an id twice, Q1) while a cursor
+    // advances through the sorted store; ids beyond the last stored one are new features and append.
+    order_.resize(n_full);
+    for (size_t k = 0; k < n_full; ++k) order_[k] = std::make_pair((FeatureIDType)msg->features[k].id, (uint32_t)k);
+    std::stable_sort(order_.begin(), order_.end(), [](const std::pair<FeatureIDType, uint32_t> &a, const std::pair<FeatureIDType, uint32_t> &b) { return a.first < b.first; });
+    size_t cur = 0;
+    for (size_t q = 0; q < n_full; ++q) {
+        const FeatureIDType fid = order_[q].first;
+        const FeatureMeasurement &f = msg->features[order_[q].second];
+        while (cur < map_server.size() && map_server.nth(cur).first < fid) ++cur;
+        if (cur < map_server.size() && map_server.nth(cur).first == fid) {
+            map_server.nth(cur).second.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
+            ++tracked;
+        } else {
+            Feature &nf = map_server[fid];        // append (or the rare ordered insert); cur now points at it
             nf.id = fid;
             nf.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
-        } else {
-            it->second.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
-            ++tracked;
         }
     }
     tracked += (long long)(total - n_full);
@@ -473,7 +481,7 @@ void MsckfVio::findRedundantCamStates(std::vector<StateIDType> &rm) {
 
 // pruneCamStateBuffer, selection part (:1073-1153)
 void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
-    feats_.clear(); feat_ids_.clear(); obs_clone_.clear(); obs_z_.clear();
+    feats_.clear(); feat_ids_.clear(); feat_slots_.clear(); obs_clone_.clear(); obs_z_.clear();
     rm_cam_state_ids_.clear();
     prune_pending_ = false;
     std::memset(&upd, 0, sizeof(upd));
@@ -482,9 +490,14 @@ void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
     findRedundantCamStates(rm_cam_state_ids_);
     std::map<StateIDType, int> clone_index;
     { int k = 0; for (const auto &kv : state_server.cam_states) clone_index[kv.first] = k++; }
-    for (auto &item : map_server) {
-        Feature &feature = item.second;
-        std::vector<StateIDType> inv;
+    const StateIDType rm_lo = rm_cam_state_ids_.front(), rm_hi = rm_cam_state_ids_.back();   // sorted (findRedundantCamStates)
+    std::vector<StateIDType> inv;
+    for (size_t slot = 0; slot < map_server.size(); ++slot) {
+        Feature &feature = map_server.nth(slot).second;
+        // observation ids are ascending: a feature first seen after the newest removed clone (or last seen before the
+        // oldest) cannot involve either of them
+        if (feature.observations.empty() || feature.observations.front_key() > rm_hi || feature.observations.back_key() < rm_lo) continue;
+        inv.clear();
         for (const auto &cid : rm_cam_state_ids_) if (feature.observations.find(cid) != feature.observations.end()) inv.push_back(cid);
         if (inv.empty()) continue;
         if (inv.size() == 1) { feature.observations.erase(inv[0]); continue; }
@@ -519,6 +532,7 @@ void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
         for (int i = 0; i < 3; ++i) f.position[i] = feature.position[i];
         feats_.push_back(f);
         feat_ids_.push_back(feature.id);
+        feat_slots_.push_back(slot);
     }
     packClones();
     finishArgs(upd, 0, 0);   // Q12 dof = #involved, no row cap in the pruning path
@@ -531,7 +545,7 @@ void MsckfVio::phaseC(bool defer_device) {
         hostprof::Scope hp(hostprof::EKF_TAIL_PRUNE);
         // tail of pruneCamStateBuffer (:1100-1181)
         for (size_t j = 0; j < feats_.size(); ++j) {
-            Feature &feature = map_server[feat_ids_[j]];
+            Feature &feature = map_server.nth(feat_slots_[j]).second;     // store untouched since buildPruneUpdate
             if (feats_[j].needs_init && (feat_status_[j] & 1)) {
                 feature.is_initialized = true;
                 feature.position = Vector3(feats_[j].position[0], feats_[j].position[1], feats_[j].position[2]);

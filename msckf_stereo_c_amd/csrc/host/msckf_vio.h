@@ -164,6 +164,8 @@ class MsckfVio {
     std::vector<mskf_clone_state> clones_;
     std::vector<mskf_ekf_feature> feats_;
     std::vector<FeatureIDType> feat_ids_;
+    std::vector<size_t> feat_slots_;                       // positions of feat_ids_ in map_server (pruning update)
+    std::vector<std::pair<FeatureIDType, uint32_t>> order_;     // addFeatureObservations scratch
     std::vector<int32_t> obs_clone_;
     std::vector<double> obs_z_;
     std::vector<double> delta_x_, gamma_;
