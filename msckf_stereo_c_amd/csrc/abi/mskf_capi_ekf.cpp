@@ -14,9 +14,7 @@ void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
-void ekf_launch_rthin(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
-void ekf_launch_dx(const EkfStreamDev *d, int n, hipStream_t st);
 }
 
 namespace {
@@ -70,7 +68,7 @@ int mskf_ekf_stream_init(mskf_stream *s) {
     if ((rc = dev_alloc(&E.T, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.S, pl)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.W, pl)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.gate_T, 64)) != MSKF_OK) return rc;   // unused since the block-structured gate (kept for the descriptor)
+    { double *tmp = nullptr; if ((rc = dev_alloc(&tmp, (size_t)E.ld)) != MSKF_OK) return rc; E.act = (int *)tmp; }   // ld ints fit
     if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax)) != MSKF_OK) return rc;
     if ((rc = dev_alloc(&E.chi2, 128)) != MSKF_OK) return rc;
     double tab[100];
@@ -86,7 +84,7 @@ int mskf_ekf_stream_init(mskf_stream *s) {
 
 void mskf_ekf_stream_free(mskf_stream *s) {
     EkfStreamState &E = s->ekf_state;
-    double *ptrs[] = {E.P, E.T, E.S, E.W, E.gate_T, E.gate_S, E.chi2, E.Hs, E.rs};
+    double *ptrs[] = {E.P, E.T, E.S, E.W, (double *)E.act, E.gate_S, E.chi2, E.Hs, E.rs};
     for (double *p : ptrs) if (p) (void)hipFree(p);
     if (E.h_arena) (void)hipHostFree(E.h_arena);
     if (E.d_arena) (void)hipFree(E.d_arena);
@@ -115,7 +113,7 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
     D.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
     D.qc[2] = s->ekf.noise_acc * s->ekf.noise_acc;
     D.qc[3] = s->ekf.noise_acc_bias * s->ekf.noise_acc_bias;
-    D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.W = E.W; D.gate_T = E.gate_T; D.gate_S = E.gate_S; D.nmax = E.nmax;
+    D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.W = E.W; D.act = E.act; D.gate_S = E.gate_S; D.nmax = E.nmax;
     hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
     std::memcpy(D.R_c0_c1, T01.R.m, sizeof(D.R_c0_c1));
     for (int i = 0; i < 3; ++i) D.t_c0_c1[i] = T01.t[i];

@@ -32,17 +32,20 @@ struct EkfStreamDev {
     const double *obs_z;                 // n_obs x 4
     double *Hs;               // m_total x ld stacked (null-space projected) Jacobian, failed blocks zeroed
     double *rs;               // m_total
-    double *T;                // ld x ld work: T = R P, then Y = L^-1 [T | Q^T r]
-    double *S;                // ld x ld work: Gram matrix [H|r]^T [H|r], then its Cholesky factor L = R^T (+ the Q^T r row)
-    double *W;                // ld x ld work: S = T R^T + sigma^2 I, then its Cholesky factor
-    double *gate_T;           // EKF_SLOTS x (nmax x ld)
+    // The dense update works on the active columns only (compact index i <-> column act[i]): a stacked Jacobian is
+    // identically zero in the 21 IMU columns and in the columns of clones none of its features observed, and such
+    // columns contribute nothing to S, K or the covariance downdate.
+    double *T;                // na x (d+1) work: T = R P[act, :], then Y = L^-1 [T | Q^T r]
+    double *S;                // (na+1)^2 work (compact): Gram matrix [H_act|r]^T [H_act|r], then its Cholesky factor L = R^T (+ the Q^T r row)
+    double *W;                // na x na work (compact): S = T[:, act] R^T + sigma^2 I, then its Cholesky factor
+    int *act;                 // active columns of this update (the 6 columns of every clone a stacked feature observed), ascending; count in rows_out[2]
     double *gate_S;           // EKF_SLOTS x (nmax x nmax)
     int nmax;                 // 4 * max_clones
     double *delta_x;          // d
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
     double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
-    int *rows_out;            // [0] stacked rows, [1] rows used by the update (after QR: min(m, d))
+    int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)
     const mskf_imu_step *imu_steps;   // or: n_steps compact IMU records, Phi/Q formed on the device
@@ -57,7 +60,8 @@ struct EkfStreamDev {
 struct EkfStreamState {       // host-side bookkeeping of the device buffers of one stream
     int max_clones = 0, ld = 0, d = EKF_IMU_DIM;
     int max_rows = 0, max_feat = 0, max_obs = 0, nmax = 0;
-    double *P = nullptr, *Hs = nullptr, *rs = nullptr, *T = nullptr, *S = nullptr, *W = nullptr, *gate_T = nullptr, *gate_S = nullptr;
+    double *P = nullptr, *Hs = nullptr, *rs = nullptr, *T = nullptr, *S = nullptr, *W = nullptr, *gate_S = nullptr;
+    int *act = nullptr;       // ld ints: active column list of the current update
     double *chi2 = nullptr;
     // per-update staging: one pinned+device arena, laid out by the host
     char *h_arena = nullptr, *d_arena = nullptr;

@@ -819,6 +819,23 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
         __syncthreads();
         if (threadIdx.x == 0) S.feat_status[j] &= (uint8_t)~2;
     }
+    __syncthreads();
+    // active columns: the six columns of every clone observed by a stacked feature, ascending
+    __shared__ int s_clone_on[MAX_CLONES_DEV];
+    for (int c = threadIdx.x; c < MAX_CLONES_DEV; c += WG) s_clone_on[c] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < nf; j += WG) {
+        if (!(S.feat_status[j] & 2)) continue;
+        const EkfFeatDev &F = S.feats[j];
+        for (int o = 0; o < F.n_obs; ++o) s_clone_on[S.obs_clone[F.obs_start + o]] = 1;     // benign race: all writers store 1
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int na = 0;
+        for (int c = 0; c < S.n_clones; ++c)
+            if (s_clone_on[c]) for (int k = 0; k < 6; ++k) S.act[na++] = EKF_IMU_DIM + 6 * c + k;
+        S.rows_out[2] = na;
+    }
 }
 
 // ------------------------------------------------------------------------------------ launchers

@@ -11,7 +11,12 @@
 //                 variant factors G + lambda I (lambda = 1e-14 d max diag: G is rank deficient and an unpivoted
 //                 factorisation of it is unstable) and carries the extra Q^T r row through the panel solves.
 //  k_ekf_trsm   : Y = L^-1 [T | Q^T r] in place, one workgroup per 32-column strip and stream.
-//  k_ekf_dx     : delta_x = Y^T w (w = column d of Y).
+//  (delta_x = Y^T w, w = column d of Y, is computed by extra workgroups of the PUPD GEMM launch)
+//
+//  All of them work on the ACTIVE columns of the update only (compact index i <-> column act[i], count rows_out[2],
+//  built by k_ekf_cap): the stacked Jacobian is zero in the 21 IMU columns and in the columns of clones that no
+//  stacked feature observed, and those columns add nothing to S, K or the downdate.  The pruning update (hundreds of
+//  features, but only the two clones being removed) thus factors 12 x 12 systems instead of 180 x 180.
 //
 // Why Gram + Cholesky instead of Householder QR: the update only needs R^T R = H^T H and R^T (Q^T r) =
 // H^T r; forming them is one GEMM-shaped pass over the stacked Jacobian (MFMA-friendly, fully parallel
@@ -45,13 +50,15 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
     const int d = S.d, ld = S.ld;
+    const int na = S.rows_out[2];                  // active columns (compact index i <-> column act[i])
+    const int *__restrict__ act = S.act;
     const double *__restrict__ A; const double *__restrict__ B; double *C;
     int M, N, K;
     double alpha = 1.0, beta = 0.0, diag_add = 0.0;
-    if (MODE == GM_GRAM)      { A = S.Hs; B = S.Hs; C = S.S; M = N = d + 1; K = S.rows_out[1]; }
-    else if (MODE == GM_T)    { A = S.S;  B = S.P;  C = S.T; M = N = d; K = d; }
-    else if (MODE == GM_S2)   { A = S.T;  B = S.S;  C = S.W; M = N = d; K = d; diag_add = S.sigma2; }
-    else                      { A = S.T;  B = S.T;  C = S.P; M = N = d; K = d; alpha = -1.0; beta = 1.0; }
+    if (MODE == GM_GRAM)      { A = S.Hs; B = S.Hs; C = S.S; M = N = na + 1; K = S.rows_out[1]; }       // G_c = [H_act|r]^T [H_act|r]
+    else if (MODE == GM_T)    { A = S.S;  B = S.P;  C = S.T; M = na; N = d; K = na; }                   // T = R_c P[act, :]
+    else if (MODE == GM_S2)   { A = S.T;  B = S.S;  C = S.W; M = N = na; K = na; diag_add = S.sigma2; } // S = T[:, act] R_c^T + sigma^2 I
+    else                      { A = S.T;  B = S.T;  C = S.P; M = N = d; K = na; alpha = -1.0; beta = 1.0; }   // P -= Y^T Y
     const int tiles_n = (N + GT - 1) / GT, tiles_m = (M + GT - 1) / GT;
     const int tile = blockIdx.x;
     if (MODE == GM_PUPD && tile >= tiles_m * tiles_n) {
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         const int c = c0 + cl;
         double s2 = 0;
         if (c < d)
-            for (int k = ks; k < d; k += 8) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
+            for (int k = ks; k < na; k += 8) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
         s_part[ks][cl] = s2;
         __syncthreads();
         if (ks == 0 && c < d) {
@@ -87,6 +94,12 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     int k_begin = 0;
     if (TR::KMIN_I) k_begin = (i0 / GK) * GK;
     if (TR::KMIN_J) k_begin = (j0 / GK) * GK;
+    // gathered source columns of this thread's fixed (i = lo / j = lo) operand lanes
+    int colA = i0 + lo, colB = j0 + lo;
+    if (MODE == GM_GRAM) {
+        colA = (i0 + lo < na) ? act[i0 + lo] : d;       // compact index na is the residual column d of [H | r]
+        colB = (j0 + lo < na) ? act[j0 + lo] : d;
+    }
     double ra[4], rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
@@ -95,11 +108,17 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
             const int ii = TR::TA ? lo : hi + 8 * e, kk = TR::TA ? hi + 8 * e : lo;
             const int gi = i0 + ii, gk = k0 + kk;
             double v = 0.0;
-            if (gi < M && gk < K && !(TR::KMIN_I && gk < gi)) v = TR::TA ? A[(size_t)gk * ld + gi] : A[(size_t)gi * ld + gk];
+            if (gi < M && gk < K && !(TR::KMIN_I && gk < gi)) {
+                if (MODE == GM_S2) v = A[(size_t)gi * ld + act[gk]];              // T[:, act]
+                else v = A[(size_t)gk * ld + (MODE == GM_GRAM ? colA : gi)];
+            }
             ra[e] = v;
             const int gj = j0 + lo, gkb = k0 + hi + 8 * e;
             double w = 0.0;
-            if (gj < N && gkb < K && !(TR::KMIN_J && gkb < gj)) w = B[(size_t)gkb * ld + gj];
+            if (gj < N && gkb < K && !(TR::KMIN_J && gkb < gj)) {
+                if (MODE == GM_T) w = B[(size_t)act[gkb] * ld + gj];             // P[act, :]
+                else w = B[(size_t)gkb * ld + (MODE == GM_GRAM ? colB : gj)];
+            }
             rb[e] = w;
         }
     };
@@ -146,8 +165,9 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
     CholArgs c;
-    if (which == 0) { c.A = S.S; c.n = S.d; c.n_extra = 1; c.lda = S.ld; c.semidef = 1; }   // G = [H|r]^T [H|r]
-    else { c.A = S.W; c.n = S.d; c.n_extra = 0; c.lda = S.ld; c.semidef = 0; }               // S = T R^T + sigma^2 I
+    const int na = S.rows_out[2];
+    if (which == 0) { c.A = S.S; c.n = na; c.n_extra = 1; c.lda = S.ld; c.semidef = 1; }   // G_c = [H_act|r]^T [H_act|r]
+    else { c.A = S.W; c.n = na; c.n_extra = 0; c.lda = S.ld; c.semidef = 0; }               // S = T[:, act] R^T + sigma^2 I
     const int n = c.n, nt = c.n + c.n_extra, lda = c.lda;
     double *A = c.A;
     extern __shared__ double s_dyn[];
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
         if (tid == 0) s_tol = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3])) * (double)n * 1e-14;
         __syncthreads();
         const double lam = s_tol;
-        for (int i = EKF_IMU_DIM + tid; i < n; i += 256) A[(size_t)i * lda + i] += lam;   // clone block only, as the LDS kernel
+        for (int i = tid; i < n; i += 256) A[(size_t)i * lda + i] += lam;
         __syncthreads();
     }
     const double tol = 0.0;
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, i
     }
     if (which == 0) {
         __syncthreads();
-        for (int k = tid; k < S.d; k += 256) S.T[(size_t)k * S.ld + S.d] = A[(size_t)S.d * lda + k];
+        for (int k = tid; k < n; k += 256) S.T[(size_t)k * S.ld + S.d] = A[(size_t)n * lda + k];
     }
 }
 
@@ -265,8 +285,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
     double *A = which == 0 ? S.S : S.W;
-    const int off = EKF_IMU_DIM, lda = S.ld;
-    const int n = S.d - off;                       // active columns
+    const int off = 0, lda = S.ld;                 // compact storage: index i <-> column act[i]
+    const int n = S.rows_out[2];                   // active columns
     const int nt = n + (which == 0 ? 1 : 0);       // rows incl. the extra row
     const bool semidef = which == 0;
     extern __shared__ double s_dyn[];
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     }
     const double tol = 0.0;      // a pivot <= 0 (cannot happen for G + lambda I or for S >= sigma^2 I) zeroes its column
     chol_blocked_lds<CHOL_WAVES>(sM, [](int i, int j) { return pk(i, j); }, n, nt, tol, sPanT, CHOL_PAN_RS, s_cb);
-    // store back; the trivial IMU block: L = 0 (Gram) or sigma I (S)
+    // store back
     for (int i = wave; i < nt; i += CHOL_WAVES) {
         double *dst = A + (size_t)(off + i) * lda + off;
         const double *src = sM + pk(i, 0);
@@ -324,34 +344,20 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
         for (int k = 0; k < 3; ++k) { const int j = lane + 64 * k; if (j <= i && j < n) dst[j] = src[j]; }
     }
     if (which == 0) {
-        // column d of T <- (Q^T r) = row d of L, so the TRSM carries w = L2^-1 Q^T r along (IMU part is zero)
-        for (int k = tid; k < S.d; k += CHOL_THREADS) S.T[(size_t)k * lda + S.d] = (k < off) ? 0.0 : sM[pk(n, k - off)];
+        // column d of T <- (Q^T r) = the extra row of L, so the TRSM carries w = L2^-1 Q^T r along
+        for (int k = tid; k < n; k += CHOL_THREADS) S.T[(size_t)k * lda + S.d] = sM[pk(n, k)];
     }
-    const double l0 = semidef ? 0.0 : sqrt(S.sigma2);
-    const int rows_all = S.d + (which == 0 ? 1 : 0);
-    for (int e = tid; e < rows_all * off; e += CHOL_THREADS) {
-        const int i = e / off, j = e - i * off;
-        if (j <= i) A[(size_t)i * lda + j] = (i == j) ? l0 : 0.0;
-    }
-}
-
-// ------------------------------------------------------------------------------------ r_thin column
-// column d of T <- row d of L (= (Q^T r)^T), so the TRSM carries w = L2^-1 Q^T r along
-__global__ __launch_bounds__(256) void k_ekf_rthin(const EkfStreamDev *streams) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_feat <= 0) return;
-    for (int k = threadIdx.x; k < S.d; k += 256) S.T[(size_t)k * S.ld + S.d] = S.S[(size_t)S.d * S.ld + k];
 }
 
 // ------------------------------------------------------------------------------------ TRSM
-// Y = L^-1 B in place, L = lower Cholesky factor in S.W (d x d), B = S.T (d x (d+1)).  One workgroup per
-// 32-column strip; the strip (d x 32 doubles) stays in LDS for the whole solve, L is staged 16 rows at a time.
+// Y = L^-1 B in place, L = lower Cholesky factor in S.W (na x na), B = S.T (na x (d+1)).  One workgroup per
+// 32-column strip; the strip (na x 32 doubles) stays in LDS for the whole solve, L is staged 16 rows at a time.
 #define TS_COLS 32
 #define TS_RB 16
 __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
-    const int n = S.d, ld = S.ld, ncols = S.d + 1;
+    const int n = S.rows_out[2], ld = S.ld, ncols = S.d + 1;      // na rows (compact), all d+1 columns
     const int c0 = blockIdx.x * TS_COLS;
     if (c0 >= ncols) return;
     const double *L = S.W;
@@ -432,18 +438,6 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     }
 }
 
-// ------------------------------------------------------------------------------------ delta_x
-__global__ __launch_bounds__(256) void k_ekf_dx(const EkfStreamDev *streams) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    const int d = S.d, ld = S.ld;
-    if (S.n_feat <= 0) return;
-    for (int c = threadIdx.x; c < d; c += 256) {
-        double s = 0;
-        for (int k = 0; k < d; ++k) s += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
-        S.delta_x[c] = s;
-    }
-}
-
 extern "C" {
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st) {
     const int t = (max_mn + GT - 1) / GT;
@@ -468,7 +462,6 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
     const size_t lds = (size_t)(CNB * (CNB + 1) + (size_t)(max_d + 2) * CNB) * sizeof(double);
     hipLaunchKernelGGL(k_ekf_chol, dim3(1, n), dim3(256), lds, st, d, which);
 }
-void ekf_launch_rthin(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_rthin, dim3(1, n), dim3(256), 0, st, d); }
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
     const size_t lds = (size_t)(TS_RB * (max_d + 1) + (size_t)max_d * TS_COLS) * sizeof(double);
@@ -476,5 +469,4 @@ void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     hipLaunchKernelGGL(k_ekf_trsm, dim3(strips, n), dim3(256), lds, st, d);
 }
-void ekf_launch_dx(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_dx, dim3(1, n), dim3(256), 0, st, d); }
 }
