@@ -91,10 +91,29 @@ def build_app(force=False, verbose=False):
     return target
 
 
+class _BuildLock:
+    """Exclusive advisory lock on the build directory: the ranks of a multi-process launch all call build_all()
+    at start-up; one of them (re)builds, the others wait and then find the libraries up to date."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(OUT, exist_ok=True)
+        self.f = open(os.path.join(OUT, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
 def build_all(force=False, verbose=False):
-    a = build_hip(force, verbose)
-    b = build_host(force, verbose)
-    build_app(force, verbose)
+    with _BuildLock():
+        a = build_hip(force, verbose)
+        b = build_host(force, verbose)
+        build_app(force, verbose)
     return a, b
 
 

@@ -18,7 +18,12 @@ _BUILD = os.path.join(_HERE, "_build")
 def build(force=False):
     have = os.path.exists(os.path.join(_BUILD, "liboracle.so")) and os.path.exists(os.path.join(_BUILD, "libmskf_synth.so"))
     if force or not have:
-        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        import fcntl
+        os.makedirs(_BUILD, exist_ok=True)
+        with open(os.path.join(_BUILD, ".lock"), "w") as lk:      # several ranks may get here at once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+            fcntl.flock(lk, fcntl.LOCK_UN)
 
 
 _lib = None
