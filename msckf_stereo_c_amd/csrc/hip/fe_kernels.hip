@@ -311,6 +311,14 @@ __device__ __forceinline__ long long wave_sum_rows(int v) {
            (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
 }
 
+// (double)b * 2^-20, exactly, for |b| < 2^51, in ONE double-precision instruction: b is added (scalar unit) to the bit
+// pattern of 1.5 * 2^32, whose mantissa LSB weighs 2^-20; subtracting 1.5 * 2^32 leaves b * 2^-20.  The plain form
+// (int64 -> double conversion, then the scaling) is five double-rate instructions per value, and FP64 issues at half
+// rate: these uniform conversions were a tenth of the kernel.
+__device__ __forceinline__ double lk_scaled_f64(long long b) {
+    return __longlong_as_double(b + 0x41F8000000000000LL) - 6442450944.0;
+}
+
 // Search/template windows are staged in LDS as a byte region of LK_RH rows x LK_RS columns whose left edge
 // is a multiple of 4 pixels; pixels outside the image are replicated from the border (px_clamped), so the
 // iteration loop needs neither clamps nor 64-bit addressing.
@@ -349,7 +357,6 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
     const bool row_ok = (lane >> 2) < LK_WIN;
     const int lane_off = lj * LK_RS + seg * 4;
     const uint8_t *s_Rb = (const uint8_t *)s_R;
-    const double FLT_SCALE = 1.0 / (double)(1 << 20);
     status = 1;
     float ncx = 0.f, ncy = 0.f;
     for (int l = MSKF_LEVELS - 1; l >= 0; --l) {
@@ -398,11 +405,13 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
             }
         }
         const long long A11s = wave_sum_rows(A11), A12s = wave_sum_rows(A12), A22s = wave_sum_rows(A22);
-        const double a11 = (double)A11s * FLT_SCALE, a12 = (double)A12s * FLT_SCALE, a22 = (double)A22s * FLT_SCALE;
+        const double a11 = lk_scaled_f64(A11s), a12 = lk_scaled_f64(A12s), a22 = lk_scaled_f64(A22s);   // (double)A * 2^-20
         double D = a11 * a22 - a12 * a12;
         const double dd = a11 - a22;
-        const double minEig = (a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12)) / (2.0 * LK_WIN * LK_WIN);
-        if (minEig < 1e-4 || D < 1.1920928955078125e-07) {
+        // minEig = numer / (2 * 15 * 15) < 1e-4  <=>  numer < 0x1.70a3d70a3d70bp-5: that constant is the smallest double
+        // whose quotient by 450.0 rounds to >= 1e-4 (division is monotonic), so the test is the same without dividing
+        const double numer = a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12);
+        if (numer < 0x1.70a3d70a3d70bp-5 || D < 1.1920928955078125e-07) {
             if (l == 0) status = 0;
             continue;
         }
@@ -442,7 +451,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
                 b2 += __mul24(diff, Iy[k]);
             }
             const long long b1s = wave_sum_rows(b1), b2s = wave_sum_rows(b2);
-            const double db1 = (double)b1s * FLT_SCALE, db2 = (double)b2s * FLT_SCALE;
+            const double db1 = lk_scaled_f64(b1s), db2 = lk_scaled_f64(b2s);
             const float dx = (float)((a12 * db2 - a22 * db1) * D);
             const float dy = (float)((a12 * db1 - a11 * db2) * D);
             wx += dx; wy += dy;
