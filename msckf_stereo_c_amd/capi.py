@@ -149,6 +149,15 @@ class Stream:
         _chk(self.L.mskf_fe_get_cell_maxima(self.h, _p(out), n, C.byref(got)))
         return out[:got.value]
 
+    def cell_candidates(self, min_score):
+        """Per-cell maxima whose score exceeds min_score (1/256 units), in cell order."""
+        n = self.fe_cfg.det_rows * self.fe_cfg.det_cols
+        out = np.zeros(n, CORNER)
+        got = C.c_int()
+        self.L.mskf_fe_get_cell_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        _chk(self.L.mskf_fe_get_cell_candidates(self.h, int(min_score), _p(out), n, C.byref(got)))
+        return out[:got.value]
+
     def track(self, pts, do_temporal, Hpred=None):
         pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
         n = len(pts)

@@ -64,6 +64,23 @@ def test_detector_flat_and_ties(gpu_ctx, oracle):
     s.close()
 
 
+def test_cell_candidates_are_the_maxima_above_threshold(gpu_ctx, oracle):
+    """mskf_fe_get_cell_candidates == the records of mskf_fe_get_cell_maxima with score > min_score, in cell order."""
+    syn = oracle.Synth(seed=5, width=752, height=480)
+    a, b = syn.render(7)
+    s, _ = _stream(gpu_ctx, oracle, 752, 480)
+    s.push_stereo(a, b)
+    full = s.cell_maxima()
+    for thr in (0, 10 * 256, 40 * 256, 10 ** 9):
+        cand = s.cell_candidates(thr)
+        want = full[full["score"] > thr]
+        assert len(cand) == len(want)
+        for f in ("x", "y", "score", "cell"):
+            assert np.array_equal(cand[f], want[f]), f
+    assert len(s.cell_candidates(10 * 256)) > 100
+    s.close()
+
+
 @pytest.mark.parametrize("w,h,seed", [(752, 480, 11), (376, 240, 12)])
 def test_lk_temporal_and_stereo_bit_exact(gpu_ctx, oracle, w, h, seed):
     syn = oracle.Synth(seed=seed, width=w, height=h)

@@ -266,3 +266,18 @@ def test_trajectory_error_against_ground_truth(oracle):
     assert r_gt["rmse"] < 0.03 and abs(r_gt["rmse"] - r_or["rmse"]) < 1e-6
     assert r_x["rmse"] < 1e-6
     run.close()
+
+
+def test_stress_shape_c3(oracle):
+    """SURVEY §8 config C3 image shape: 1280x720, 10x20 grid (~1000 features per frame); a 24-clone window so that the
+    pruning update with several hundred 2-observation features runs inside the 45 frames (the d = 321 / 381 algebra of
+    C3 / C5 is covered by test_gpu_kernels.py::test_ekf_update_many_clones).  Lockstep with the oracle."""
+    syn = oracle.Synth(seed=0x5EED00C3, width=1280, height=720)
+    fe = default_fe_cfg(grid_row=10, grid_col=20, grid_min=4, grid_max=5)
+    ekf = default_ekf_cfg(max_cam_state_size=24)
+    osys, run = _lockstep(oracle, syn, fe, ekf, 48, check_every=6)
+    assert len(run.dump()[0]) > 600
+    compare_msgs(osys, run)
+    assert osys.num_updates() == run.num_updates() > 5
+    compare_poses(osys, run)
+    run.close()
