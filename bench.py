@@ -111,8 +111,24 @@ def cgroup_cpu():
     return quota, thr
 
 
+def host_cores_available():
+    """Cores this process may use: the cgroup quota if there is one, else the affinity mask."""
+    quota, _ = cgroup_cpu()
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    return min(quota, aff) if quota else aff
+
+
 def main():
     args = parse()
+    # Every group runs a front-end and a filter thread that wait for the GPU between phases.  Spinning in those waits is the
+    # lower-latency choice while each thread has a core to itself; when the ranks of this node together run more such
+    # threads than there are cores (a shared quota), parked waits leave the cores to the threads that have host work.
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if "MSKF_WAIT" not in os.environ and 2 * args.groups * args.host_threads * local_world > host_cores_available():
+        os.environ["MSKF_WAIT"] = "block"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,7 +247,7 @@ def main():
                                       ", FE|EKF pipelined" if pipe else ""),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
                        "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1),
-                       "host_cpu_quota": cpu_quota,
+                       "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "roofline": roof, "kernels": kernels,
             "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
