@@ -281,3 +281,36 @@ def test_stress_shape_c3(oracle):
     assert osys.num_updates() == run.num_updates() > 5
     compare_poses(osys, run)
     run.close()
+
+
+def test_bench_scale_replicas_are_bit_identical(oracle):
+    """Size-independent property at the benchmark's shape (752x480, 30-clone window, 8x10 grid, several pipelined groups
+    of batched streams): streams fed the same sequence are bit-identical whatever their slot, group and thread — ids,
+    pixels, poses and covariance — through steady state with lost-feature and pruning updates; one of them is checked
+    against the oracle."""
+    w, h, n_frames = 752, 480, 80
+    fe = default_fe_cfg(grid_row=8, grid_col=10, grid_min=4, grid_max=5)
+    ekf = default_ekf_cfg(max_cam_state_size=30)
+    uniq = [oracle.Synth(seed=0x5EED0040 + i, width=w, height=h) for i in range(2)]
+    n_groups, per_group = 3, 6
+    run = R.Runner(uniq[0].calib, fe, ekf, n_groups, per_group, host_threads=1)
+    keep = []
+    syns = [uniq[s % 2] for s in range(n_groups * per_group)]
+    _attach_sequences(oracle, run, syns, n_frames, keep)
+    run.run(0, n_frames, threaded=True, pipelined=True)
+    for s in range(2, n_groups * per_group):
+        ref = s % 2
+        for x, y in zip(run.dump(ref)[:4], run.dump(s)[:4]):
+            assert np.array_equal(x, y), "stream %d differs from stream %d" % (s, ref)
+        pa, pb = run.poses(ref), run.poses(s)
+        assert len(pa) == len(pb) > 40
+        assert np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])
+        assert np.array_equal(run.cov(ref), run.cov(s))
+        assert run.num_updates(ref) == run.num_updates(s) > 20
+    assert run.num_clones(0) >= 28 and len(run.dump(0)[0]) > 250
+    osys = oracle.OracleSystem(uniq[0].calib, fe, ekf)
+    uniq[0].feed(osys, n_frames)
+    assert np.array_equal(osys.dump()[0], run.dump(0)[0])
+    op, gp = osys.poses(), run.poses(0)
+    assert np.abs(op["p"] - gp["p"]).max() < POS_TOL
+    run.close()
