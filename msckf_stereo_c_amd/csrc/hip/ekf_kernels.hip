@@ -455,9 +455,9 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
     int *sObsOfClone = sObsOfClone_all[sub], *sCloneOfObs = sCloneOfObs_all[sub];
     int &sValid = sValid_all[sub];
     auto GSYNC = [&]() {
-        // one wave: its LDS operations execute in program order, only the compiler has to be kept from reordering
-        // them (no global memory is written and read back inside a feature: the residual travels through sRo)
-        if (WAVE) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+        // one wave: its LDS operations execute in program order; drain the LDS counter and keep the compiler from
+        // reordering (no global memory is written and read back inside a feature: the residual travels through sRo)
+        if (WAVE) { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f) /* lgkmcnt(0) only */; asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     };
     auto gsum = [&](double v) { return WAVE ? wave_sum(v) : block_sum(v, sRed); };
@@ -824,7 +824,10 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
     __shared__ int s_clone_on[MAX_CLONES_DEV];
     for (int c = threadIdx.x; c < MAX_CLONES_DEV; c += WG) s_clone_on[c] = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < nf; j += WG) {
+    // stacked = passed the gate and in front of the cap.  The cap is applied by index here: thread 0 cleared the status
+    // bits of the capped features above, and another wave re-reading them could still be served the old L1 line.
+    const int cap_from = s_cap_from;
+    for (int j = threadIdx.x; j < cap_from; j += WG) {
         if (!(S.feat_status[j] & 2)) continue;
         const EkfFeatDev &F = S.feats[j];
         for (int o = 0; o < F.n_obs; ++o) s_clone_on[S.obs_clone[F.obs_start + o]] = 1;     // benign race: all writers store 1

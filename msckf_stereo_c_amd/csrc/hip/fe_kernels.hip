@@ -322,19 +322,21 @@ __device__ __forceinline__ double lk_scaled_f64(long long b) {
 // Search/template windows are staged in LDS as a byte region of LK_RH rows x LK_RS columns whose left edge
 // is a multiple of 4 pixels; pixels outside the image are replicated from the border (px_clamped), so the
 // iteration loop needs neither clamps nor 64-bit addressing.
-#define LK_RS 36
-#define LK_RH 32
+#define LK_RS 32              // staged columns (multiple of 8): the 17 columns a window reads + 15 of slack
+#define LK_RH 24              // staged rows: the 16 rows a window reads + 8 of slack
+#define LK_MARGIN 4           // slack on the left / top of a freshly staged search region
 __device__ __forceinline__ void lk_stage(const uint8_t *img, int w, int h, int x0, int y0, int rows, uint32_t *s_R) {
     const int lane = threadIdx.x & 63;
-    // rows of the odd-width pyramid levels are not dword aligned: the loads are declared align-1 (gfx950 global
-    // memory takes unaligned dword accesses)
-    typedef uint32_t __attribute__((aligned(1))) u32u;
+    // 8 bytes per load; rows of the odd-width pyramid levels are not aligned, so the loads are declared align-1
+    // (gfx950 global memory takes unaligned accesses)
+    typedef unsigned long long __attribute__((aligned(1))) u64u;
     const bool fast = x0 >= 0 && y0 >= 0 && x0 + LK_RS <= w && y0 + rows <= h;
     if (fast) {
         const uint8_t *src = img + (size_t)y0 * w + x0;
-        for (int i = lane; i < (LK_RS / 4) * rows; i += 64) {
-            const int r = i / (LK_RS / 4), c = i - r * (LK_RS / 4);
-            s_R[i] = *(const u32u *)(src + r * w + 4 * c);
+        unsigned long long *dst = (unsigned long long *)s_R;
+        for (int i = lane; i < (LK_RS / 8) * rows; i += 64) {
+            const int r = i / (LK_RS / 8), c = i - r * (LK_RS / 8);
+            dst[i] = *(const u64u *)(src + r * w + 8 * c);
         }
     } else {
         uint8_t *dst = (uint8_t *)s_R;
@@ -429,7 +431,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
             int ox = inx - bx0, oy = iny - by0;
             // the lanes read columns ox .. ox+16 and rows oy .. oy+15 of the staged region
             if (!staged || ox < 0 || ox > LK_RS - 17 || oy < 0 || oy > LK_RH - 16) {
-                bx0 = (inx - 8) & ~3; by0 = iny - 8;
+                bx0 = (inx - LK_MARGIN) & ~3; by0 = iny - LK_MARGIN;
                 __syncthreads();
                 lk_stage(imB, bw, bh, bx0, by0, LK_RH, s_R);
                 __syncthreads();
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams) {
     const int pt = blockIdx.x;
     if (pt >= S.n_pts) return;
     __shared__ int s_P[17 * 17];
-    __shared__ uint32_t s_R[LK_RS * LK_RH / 4];
+    __shared__ __attribute__((aligned(8))) uint32_t s_R[LK_RS * LK_RH / 4];
     const int W = S.curr0.w[0], H = S.curr0.h[0];
     const mskf_point2f pin = S.in_pts[pt];
     int st_bits = 0;

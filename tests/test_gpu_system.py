@@ -298,14 +298,19 @@ def test_bench_scale_replicas_are_bit_identical(oracle):
     syns = [uniq[s % 2] for s in range(n_groups * per_group)]
     _attach_sequences(oracle, run, syns, n_frames, keep)
     run.run(0, n_frames, threaded=True, pipelined=True)
+    names = ("ids", "lifetimes", "cam0 pixels", "cam1 pixels")
     for s in range(2, n_groups * per_group):
         ref = s % 2
-        for x, y in zip(run.dump(ref)[:4], run.dump(s)[:4]):
-            assert np.array_equal(x, y), "stream %d differs from stream %d" % (s, ref)
+        for nm, x, y in zip(names, run.dump(ref)[:4], run.dump(s)[:4]):
+            assert np.array_equal(x, y), "stream %d differs from its replica %d in %s" % (s, ref, nm)
         pa, pb = run.poses(ref), run.poses(s)
-        assert len(pa) == len(pb) > 40
-        assert np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])
-        assert np.array_equal(run.cov(ref), run.cov(s))
+        assert len(pa) == len(pb) > 40, "stream %d: %d poses, replica %d: %d" % (s, len(pb), ref, len(pa))
+        if not (np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])):
+            bad = np.nonzero(np.any(pa["p"] != pb["p"], axis=1) | np.any(pa["q"] != pb["q"], axis=1))[0]
+            raise AssertionError("stream %d pose differs from replica %d first at pose %d of %d, max |dp| %.3e"
+                                 % (s, ref, bad[0], len(pa), np.abs(pa["p"] - pb["p"]).max()))
+        dP = np.abs(run.cov(ref) - run.cov(s)).max()
+        assert dP == 0.0, "stream %d covariance differs from replica %d by %.3e" % (s, ref, dP)
         assert run.num_updates(ref) == run.num_updates(s) > 20
     assert run.num_clones(0) >= 28 and len(run.dump(0)[0]) > 250
     osys = oracle.OracleSystem(uniq[0].calib, fe, ekf)
