@@ -782,7 +782,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
 __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     __shared__ int s_cap_from;
-    __shared__ int s_rows[1024];
+    __shared__ int s_rows[1024], s_off[1024];
     __shared__ unsigned char s_st[1024];
     const int nf = S.n_feat;
     if (nf <= 0) return;
@@ -790,7 +790,11 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
     for (int base = 0; base < nf; base += 1024) {
         const int cnt = min(1024, nf - base);
         __syncthreads();
-        for (int j = threadIdx.x; j < cnt; j += WG) { s_st[j] = S.feat_status[base + j]; s_rows[j] = 4 * S.feats[base + j].n_obs - 3; }
+        for (int j = threadIdx.x; j < cnt; j += WG) {
+            s_st[j] = S.feat_status[base + j];
+            s_rows[j] = 4 * S.feats[base + j].n_obs - 3;
+            s_off[j] = S.feats[base + j].row_off;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             int stack = base == 0 ? 0 : S.rows_out[0];
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
             int m_eff = base == 0 ? 0 : S.rows_out[1];
             if (cap_from == nf) {
                 for (int j = 0; j < cnt; ++j) {
-                    if (s_st[j] & 2) { stack += s_rows[j]; m_eff = S.feats[base + j].row_off + s_rows[j]; }
+                    if (s_st[j] & 2) { stack += s_rows[j]; m_eff = s_off[j] + s_rows[j]; }
                     if (S.apply_row_cap && stack > S.max_stack_rows) { cap_from = base + j + 1; break; }
                 }
             }
