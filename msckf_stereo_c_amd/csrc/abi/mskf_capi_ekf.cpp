@@ -7,6 +7,7 @@
 
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_phiq(const EkfStreamDev *d, int n, int max_steps, hipStream_t st);
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, int max_clones, hipStream_t st);
@@ -227,11 +228,14 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     if (!ctx || n <= 0 || !streams || !n_steps || !steps || !J) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
+    size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64), scratch = 0;
     for (int i = 0; i < n; ++i) {
         if (!streams[i] || streams[i]->ctx_ekf != ctx || n_steps[i] < 0 || (n_steps[i] && !steps[i])) return MSKF_ERR_INVALID;
         bytes += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64) + align_up(sizeof(double) * 6 * EKF_IMU_DIM, 64);
+        scratch += align_up(sizeof(double) * 2 * EKF_IMU_DIM * EKF_IMU_DIM * (size_t)n_steps[i], 64);   // Phi_k, Q_k (device only)
     }
+    const size_t copy_cap = bytes;
+    bytes += scratch;
     if (!ctx->pred_done) MSKF_HIPCHK(hipEventCreateWithFlags(&ctx->pred_done, hipEventDisableTiming));
     if (ctx->pred_pending) { MSKF_HIPCHK(hipEventSynchronize(ctx->pred_done)); ctx->pred_pending = false; }
     if (bytes > ctx->pred_arena.cap) {
@@ -243,12 +247,17 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     EkfStreamDev *D = (EkfStreamDev *)h;
     size_t off = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
     bool any = false;
+    size_t soff = copy_cap;          // Phi/Q scratch lives behind the copied part of the device arena
+    int max_steps = 0;
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         EkfStreamState &E = s->ekf_state;
         base_desc(s, D[i]);
         D[i].n_steps = n_steps[i];
         if (n_steps[i] > 0) {
+            D[i].PhiQ = (const double *)(dv + soff);       // filled by k_ekf_phiq, consumed by k_ekf_propagate
+            soff += align_up(sizeof(double) * 2 * EKF_IMU_DIM * EKF_IMU_DIM * (size_t)n_steps[i], 64);
+            max_steps = std::max(max_steps, (int)n_steps[i]);
             std::memcpy(h + off, steps[i], sizeof(mskf_imu_step) * (size_t)n_steps[i]);
             D[i].imu_steps = (const mskf_imu_step *)(dv + off);
             off += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64);
@@ -268,6 +277,7 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_PROPAGATE);
+        ekf_launch_phiq((const EkfStreamDev *)dv, n, max_steps, st);
         ekf_launch_propagate((const EkfStreamDev *)dv, n, st);
         mskf_t_end(ctx, ts, n);
     }

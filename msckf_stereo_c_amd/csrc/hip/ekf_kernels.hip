@@ -54,6 +54,77 @@ __device__ __forceinline__ void mat3t_vec(const double *A, const double *v, doub
     for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
 }
 
+// Phi (3rd-order expm of F dt with the observability fix-ups) and Q = Phi G Qc G^T Phi^T dt of one IMU step
+// (processModel, msckf_vio.cpp:417-458), by all WG threads.  sA: scratch (F dt), sB: scratch, receives Q.
+__device__ __forceinline__ void build_phi_q(const mskf_imu_step &st, const double *qc, double *sPhi, double *sA, double *sB) {
+    constexpr int N = EKF_IMU_DIM;
+    const int tid = threadIdx.x;
+    // F dt, Phi = I + Fdt + Fdt^2/2 + Fdt^3/6, fix-ups, Q
+    for (int i = tid; i < N * N; i += WG) sA[i] = 0.0;
+    __syncthreads();
+    if (tid < 9) {
+        const int r = tid / 3, c = tid % 3;
+        const double g[3] = {st.gyro[0], st.gyro[1], st.gyro[2]}, a[3] = {st.acc[0], st.acc[1], st.acc[2]};
+        const double skg[9] = {0, -g[2], g[1], g[2], 0, -g[0], -g[1], g[0], 0};
+        const double ska[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+        double rs = 0;
+        for (int k = 0; k < 3; ++k) rs += st.R_t[3 * r + k] * ska[3 * k + c];
+        sA[r * N + c] = -skg[3 * r + c] * st.dt;                     // F(0,0) = -[w]x
+        sA[r * N + 3 + c] = (r == c ? -1.0 : 0.0) * st.dt;           // F(0,3) = -I
+        sA[(6 + r) * N + c] = -rs * st.dt;                           // F(6,0) = -R^T [a]x
+        sA[(6 + r) * N + 9 + c] = -st.R_t[3 * r + c] * st.dt;        // F(6,9) = -R^T
+        sA[(12 + r) * N + 6 + c] = (r == c ? 1.0 : 0.0) * st.dt;     // F(12,6) = I
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += WG) {
+        const int r = i / N, c = i % N;
+        double s2 = 0;
+        for (int k = 0; k < N; ++k) s2 += sA[r * N + k] * sA[k * N + c];
+        sB[i] = s2;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += WG) {
+        const int r = i / N, c = i % N;
+        double s3 = 0;
+        for (int k = 0; k < N; ++k) s3 += sB[r * N + k] * sA[k * N + c];
+        sPhi[i] = (r == c ? 1.0 : 0.0) + sA[i] + 0.5 * sB[i] + (1.0 / 6.0) * s3;
+    }
+    __syncthreads();
+    if (tid < 9) {
+        const int r = tid / 3, c = tid % 3;
+        // A - (A u - w) s^T for the velocity and position rows (:449-455); uses the un-fixed A
+        double a1u = 0, a2u = 0;
+        for (int k = 0; k < 3; ++k) { a1u += sPhi[(6 + r) * N + k] * st.u[k]; a2u += sPhi[(12 + r) * N + k] * st.u[k]; }
+        const double v1 = sPhi[(6 + r) * N + c] - (a1u - st.w1[r]) * st.s[c];
+        const double v2 = sPhi[(12 + r) * N + c] - (a2u - st.w2[r]) * st.s[c];
+        __builtin_amdgcn_wave_barrier();
+        sPhi[(6 + r) * N + c] = v1;
+        sPhi[(12 + r) * N + c] = v2;
+        sPhi[r * N + c] = st.Phi00[3 * r + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += WG) {
+        const int r = i / N, c = i % N;
+        double q = 0;
+        for (int k = 0; k < 12; ++k) q += sPhi[r * N + k] * qc[k / 3] * sPhi[c * N + k];
+        sB[i] = q * st.dt;
+    }
+    __syncthreads();
+    }
+
+// Phi_k, Q_k of every IMU step of every stream, one workgroup per (step, stream): they do not depend on the
+// covariance, so only the P recursion itself stays serial in k_ekf_propagate.
+__global__ __launch_bounds__(WG) void k_ekf_phiq(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    const int step = blockIdx.x;
+    if (step >= S.n_steps || !S.imu_steps || !S.PhiQ) return;
+    constexpr int N = EKF_IMU_DIM;
+    __shared__ double sPhi[N * N], sA[N * N], sB[N * N];
+    build_phi_q(S.imu_steps[step], S.qc, sPhi, sA, sB);
+    double *out = const_cast<double *>(S.PhiQ) + (size_t)step * 2 * N * N;
+    for (int i = threadIdx.x; i < N * N; i += WG) { out[i] = sPhi[i]; out[N * N + i] = sB[i]; }
+}
+
 // ------------------------------------------------------------------------------------ propagate (+ augment)
 // Per IMU step: P_II <- sym(Phi P_II Phi^T + Q) (in LDS); the clone cross terms are propagated once with the
 // composed transition  P_IC <- (Phi_n ... Phi_1) P_IC  (one pass over P instead of one per IMU sample),
@@ -69,61 +140,8 @@ __global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *stream
     for (int i = tid; i < N * N; i += WG) { sP[i] = P[(size_t)(i / N) * ld + (i % N)]; sTot[i] = (i / N == i % N) ? 1.0 : 0.0; }
     for (int step = 0; step < S.n_steps; ++step) {
         __syncthreads();
-        if (S.imu_steps) {
-            // processModel (msckf_vio.cpp:417-458): F dt, Phi = I + Fdt + Fdt^2/2 + Fdt^3/6, fix-ups, Q
-            const mskf_imu_step &st = S.imu_steps[step];
-            double *sA = sT, *sB = sQ;          // Fdt, Fdt^2 scratch
-            for (int i = tid; i < N * N; i += WG) sA[i] = 0.0;
-            __syncthreads();
-            if (tid < 9) {
-                const int r = tid / 3, c = tid % 3;
-                const double g[3] = {st.gyro[0], st.gyro[1], st.gyro[2]}, a[3] = {st.acc[0], st.acc[1], st.acc[2]};
-                const double skg[9] = {0, -g[2], g[1], g[2], 0, -g[0], -g[1], g[0], 0};
-                const double ska[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
-                double rs = 0;
-                for (int k = 0; k < 3; ++k) rs += st.R_t[3 * r + k] * ska[3 * k + c];
-                sA[r * N + c] = -skg[3 * r + c] * st.dt;                     // F(0,0) = -[w]x
-                sA[r * N + 3 + c] = (r == c ? -1.0 : 0.0) * st.dt;           // F(0,3) = -I
-                sA[(6 + r) * N + c] = -rs * st.dt;                           // F(6,0) = -R^T [a]x
-                sA[(6 + r) * N + 9 + c] = -st.R_t[3 * r + c] * st.dt;        // F(6,9) = -R^T
-                sA[(12 + r) * N + 6 + c] = (r == c ? 1.0 : 0.0) * st.dt;     // F(12,6) = I
-            }
-            __syncthreads();
-            for (int i = tid; i < N * N; i += WG) {
-                const int r = i / N, c = i % N;
-                double s2 = 0;
-                for (int k = 0; k < N; ++k) s2 += sA[r * N + k] * sA[k * N + c];
-                sB[i] = s2;
-            }
-            __syncthreads();
-            for (int i = tid; i < N * N; i += WG) {
-                const int r = i / N, c = i % N;
-                double s3 = 0;
-                for (int k = 0; k < N; ++k) s3 += sB[r * N + k] * sA[k * N + c];
-                sPhi[i] = (r == c ? 1.0 : 0.0) + sA[i] + 0.5 * sB[i] + (1.0 / 6.0) * s3;
-            }
-            __syncthreads();
-            if (tid < 9) {
-                const int r = tid / 3, c = tid % 3;
-                // A - (A u - w) s^T for the velocity and position rows (:449-455); uses the un-fixed A
-                double a1u = 0, a2u = 0;
-                for (int k = 0; k < 3; ++k) { a1u += sPhi[(6 + r) * N + k] * st.u[k]; a2u += sPhi[(12 + r) * N + k] * st.u[k]; }
-                const double v1 = sPhi[(6 + r) * N + c] - (a1u - st.w1[r]) * st.s[c];
-                const double v2 = sPhi[(12 + r) * N + c] - (a2u - st.w2[r]) * st.s[c];
-                __builtin_amdgcn_wave_barrier();
-                sPhi[(6 + r) * N + c] = v1;
-                sPhi[(12 + r) * N + c] = v2;
-                sPhi[r * N + c] = st.Phi00[3 * r + c];
-            }
-            __syncthreads();
-            for (int i = tid; i < N * N; i += WG) {
-                const int r = i / N, c = i % N;
-                double q = 0;
-                for (int k = 0; k < 12; ++k) q += sPhi[r * N + k] * S.qc[k / 3] * sPhi[c * N + k];
-                sB[i] = q * st.dt;
-            }
-            __syncthreads();
-            // sQ aliases sB: already in place
+        if (S.imu_steps && !S.PhiQ) {
+            build_phi_q(S.imu_steps[step], S.qc, sPhi, sT, sQ);       // scratch sT, Q lands in sQ
         } else {
             const double *PhiQ = S.PhiQ + (size_t)step * 2 * N * N;
             for (int i = tid; i < N * N; i += WG) { sPhi[i] = PhiQ[i]; sQ[i] = PhiQ[N * N + i]; }
@@ -848,6 +866,9 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
 // ------------------------------------------------------------------------------------ launchers
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_propagate, dim3(1, n), dim3(WG), 0, st, d); }
+void ekf_launch_phiq(const EkfStreamDev *d, int n, int max_steps, hipStream_t st) {
+    if (max_steps > 0) hipLaunchKernelGGL(k_ekf_phiq, dim3(max_steps, n), dim3(WG), 0, st, d);
+}
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_augment, dim3(1, n), dim3(WG), 0, st, d); }
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);
