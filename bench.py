@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--grid", type=str, default="8x10x4x5", help="rows x cols x min x max features per cell")
     ap.add_argument("--prime", type=int, default=75, help="untimed frames before warmup: gravity init + clone window fill")
     ap.add_argument("--loop", type=int, default=100, help="frames per trajectory period")
-    ap.add_argument("--cpu-frames", type=int, default=150, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=250, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("MSKF_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
@@ -246,7 +246,7 @@ def main():
                                    % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads,
                                       ", FE|EKF pipelined" if pipe else ""),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
-                       "ekf_updates_stream0": n_upd, "render_s": round(render_s, 1),
+                       "ekf_updates_stream0": n_upd, "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1),
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "roofline": roof, "kernels": kernels,
