@@ -29,7 +29,7 @@ typedef enum mskf_status {
     MSKF_OK = 0,
     MSKF_ERR_INVALID = -1,      /* bad argument */
     MSKF_ERR_HIP = -2,          /* a HIP runtime call failed (mskf_last_error() has the text) */
-    MSKF_ERR_UNSUPPORTED = -3,  /* e.g. equidistant distortion model on the device path */
+    MSKF_ERR_UNSUPPORTED = -3,  /* e.g. an unknown distortion model */
     MSKF_ERR_CAPACITY = -4,     /* more points / clones / rows than the stream was created for */
     MSKF_ERR_NO_DEVICE = -5
 } mskf_status;

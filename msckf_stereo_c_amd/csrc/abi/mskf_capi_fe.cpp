@@ -136,10 +136,11 @@ void fill_pyr(const mskf_stream *s, int idx, PyrDev &p) {
 extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
                                   mskf_stream **out) {
     if (!ctx || !calib || !fe || !ekf || !out) return MSKF_ERR_INVALID;
-    if (calib->cam0_model != MSKF_MODEL_RADTAN || calib->cam1_model != MSKF_MODEL_RADTAN) {
-        mskf_set_error("only the radtan distortion model is implemented on the device path");
-        return MSKF_ERR_UNSUPPORTED;
-    }
+    for (int m : {calib->cam0_model, calib->cam1_model})
+        if (m != MSKF_MODEL_RADTAN && m != MSKF_MODEL_EQUIDISTANT) {
+            mskf_set_error("unknown distortion model (radtan and equidistant are implemented)");
+            return MSKF_ERR_UNSUPPORTED;
+        }
     if (calib->width < 64 || calib->height < 64 || fe->det_rows <= 0 || fe->det_cols <= 0 || fe->grid_row <= 0 || fe->grid_col <= 0)
         return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
@@ -169,6 +170,7 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
 
     for (int i = 0; i < 4; ++i) {
         s->cam0.K[i] = calib->cam0_intrinsics[i]; s->cam0.D[i] = calib->cam0_distortion[i];
+        s->cam0.model = calib->cam0_model; s->cam1.model = calib->cam1_model;
         s->cam1.K[i] = calib->cam1_intrinsics[i]; s->cam1.D[i] = calib->cam1_distortion[i];
     }
     // image_processor.cpp:63-72 (loadParameters) and :544,:587-591 (stereoMatch)

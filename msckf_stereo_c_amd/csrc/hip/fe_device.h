@@ -14,7 +14,9 @@ struct PyrDev {
 
 struct CamDev {
     double K[4];  // fx fy cx cy
-    double D[4];  // k1 k2 p1 p2
+    double D[4];  // radtan: k1 k2 p1 p2; equidistant: k1 k2 k3 k4
+    int model;    // MSKF_MODEL_RADTAN / MSKF_MODEL_EQUIDISTANT
+    int pad_;
 };
 
 // Per VIO stream, per launch: everything the point kernels need.

@@ -227,19 +227,101 @@ extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, 
 }
 
 // ------------------------------------------------------------------------------------------ point math
-// cv::undistortPoints radtan, 5 iterations, then R, then P = {1,1,0,0}
+// Deterministic atan / tan for the equidistant (fisheye) camera model.  cv::fisheye::distortPoints needs atan(r),
+// cv::fisheye::undistortPoints needs tan(theta); libm and the GPU math library do not round them identically, so both
+// sides evaluate the SAME sequence of IEEE double operations (+ - * / only, no contraction): argument reduction to a
+// small interval and an odd Taylor polynomial.  Accuracy ~2e-16 relative (checked against libm in the tests).
+
+// atan(x), x >= 0:  x > 1 -> pi/2 - atan(1/x);  then atan(x) = atan(c) + atan((x - c) / (1 + x c)) with the nearest
+// c in {0, 1/4, 1/2, 3/4, 1} (|z| <= 1/8 -> 11 odd terms leave < 1e-21)
+__device__ __forceinline__ double det_atan(double x) {
+    const bool inv = x > 1.0;
+    if (inv) x = 1.0 / x;
+    double c = 0.0, ac = 0.0;
+    if (x > 0.875)      { c = 1.0;  ac = 0.78539816339744830962; }
+    else if (x > 0.625) { c = 0.75; ac = 0.64350110879328438680; }
+    else if (x > 0.375) { c = 0.5;  ac = 0.46364760900080611621; }
+    else if (x > 0.125) { c = 0.25; ac = 0.24497866312686415417; }
+    const double z = (x - c) / (1.0 + x * c);
+    const double z2 = z * z;
+    double p = 1.0 / 21.0;
+    p = 1.0 / 19.0 - z2 * p;
+    p = 1.0 / 17.0 - z2 * p;
+    p = 1.0 / 15.0 - z2 * p;
+    p = 1.0 / 13.0 - z2 * p;
+    p = 1.0 / 11.0 - z2 * p;
+    p = 1.0 / 9.0 - z2 * p;
+    p = 1.0 / 7.0 - z2 * p;
+    p = 1.0 / 5.0 - z2 * p;
+    p = 1.0 / 3.0 - z2 * p;
+    p = 1.0 - z2 * p;
+    const double a = ac + z * p;
+    return inv ? 1.5707963267948966192 - a : a;
+}
+// tan(t), 0 <= t <= pi/2:  t > pi/4 -> 1 / tan(pi/2 - t);  tan = sin / cos with Taylor series on [0, pi/4]
+__device__ __forceinline__ double det_tan(double t) {
+    const bool inv = t > 0.78539816339744830962;
+    if (inv) t = 1.5707963267948966192 - t;
+    const double t2 = t * t;
+    double s = 1.0 / 121645100408832000.0;              // 1/19!
+    s = 1.0 / 355687428096000.0 - t2 * s;                // 1/17!
+    s = 1.0 / 1307674368000.0 - t2 * s;                  // 1/15!
+    s = 1.0 / 6227020800.0 - t2 * s;                     // 1/13!
+    s = 1.0 / 39916800.0 - t2 * s;                       // 1/11!
+    s = 1.0 / 362880.0 - t2 * s;                         // 1/9!
+    s = 1.0 / 5040.0 - t2 * s;                           // 1/7!
+    s = 1.0 / 120.0 - t2 * s;                            // 1/5!
+    s = 1.0 / 6.0 - t2 * s;                              // 1/3!
+    s = t * (1.0 - t2 * s);
+    double c = 1.0 / 6402373705728000.0;                 // 1/18!
+    c = 1.0 / 20922789888000.0 - t2 * c;                 // 1/16!
+    c = 1.0 / 87178291200.0 - t2 * c;                    // 1/14!
+    c = 1.0 / 479001600.0 - t2 * c;                      // 1/12!
+    c = 1.0 / 3628800.0 - t2 * c;                        // 1/10!
+    c = 1.0 / 40320.0 - t2 * c;                          // 1/8!
+    c = 1.0 / 720.0 - t2 * c;                            // 1/6!
+    c = 1.0 / 24.0 - t2 * c;                             // 1/4!
+    c = 0.5 - t2 * c;                                    // 1/2!
+    c = 1.0 - t2 * c;
+    return inv ? c / s : s / c;
+}
+
+
+// cv::undistortPoints (radtan: 5 fixed-point iterations; equidistant: cv::fisheye::undistortPoints, Newton on theta,
+// <= 10 iterations), then R, then P = {1,1,0,0}.  Same operation sequence as oracle/o_image.cpp undistort_point.
 __device__ __forceinline__ void undistort_pt(const CamDev &cam, const double *R, float u, float v, float &xo, float &yo) {
     const double fx = cam.K[0], fy = cam.K[1], cx = cam.K[2], cy = cam.K[3];
-    const double k1 = cam.D[0], k2 = cam.D[1], p1 = cam.D[2], p2 = cam.D[3];
     double x = ((double)u - cx) / fx, y = ((double)v - cy) / fy;
-    const double x0 = x, y0 = y;
-    for (int j = 0; j < 5; ++j) {
-        const double r2 = x * x + y * y;
-        const double icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2);
-        const double deltaX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
-        const double deltaY = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
+    if (cam.model == MSKF_MODEL_EQUIDISTANT) {
+        const double *k = cam.D;
+        double theta_d = sqrt(x * x + y * y);
+        const double half_pi = 1.5707963267948966;
+        theta_d = theta_d > half_pi ? half_pi : (theta_d < -half_pi ? -half_pi : theta_d);
+        double scale = 0.0;
+        if (theta_d > 1e-8) {
+            double theta = theta_d;
+            for (int j = 0; j < 10; ++j) {
+                const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+                const double k0t2 = k[0] * t2, k1t4 = k[1] * t4, k2t6 = k[2] * t6, k3t8 = k[3] * t8;
+                const double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) /
+                                   (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+                theta = theta - fix;
+                if (fabs(fix) < 1e-8) break;
+            }
+            scale = det_tan(theta) / theta_d;
+        }
+        x = x * scale; y = y * scale;
+    } else {
+        const double k1 = cam.D[0], k2 = cam.D[1], p1 = cam.D[2], p2 = cam.D[3];
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1.0 + (k2 * r2 + k1) * r2);
+            const double deltaX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+            const double deltaY = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
     }
     if (R) {
         const double X = R[0] * x + R[1] * y + R[2];
@@ -254,15 +336,27 @@ __device__ __forceinline__ void undistort_pt(const CamDev &cam, const double *R,
     yo = (float)(y * 1.0 + 0.0);
 }
 
+// cg::project_points with zero rvec / tvec: (x, y) is the ray (x, y, 1); oracle/o_image.cpp distort_point
 __device__ __forceinline__ void distort_pt(const CamDev &cam, float xf, float yf, float &uo, float &vo) {
     const double fx = cam.K[0], fy = cam.K[1], cx = cam.K[2], cy = cam.K[3];
-    const double k1 = cam.D[0], k2 = cam.D[1], p1 = cam.D[2], p2 = cam.D[3];
     const double x = (double)xf, y = (double)yf;
-    const double r2 = x * x + y * y, r4 = r2 * r2;
-    const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
-    const double cdist = 1.0 + k1 * r2 + k2 * r4;
-    const double xd = x * cdist + p1 * a1 + p2 * a2;
-    const double yd = y * cdist + p1 * a3 + p2 * a1;
+    double xd, yd;
+    if (cam.model == MSKF_MODEL_EQUIDISTANT) {
+        const double *k = cam.D;
+        const double r = sqrt(x * x + y * y);
+        const double theta = det_atan(r);
+        const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+        const double theta_d = theta * (1 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8);
+        const double scale = (r > 1e-8) ? theta_d / r : 1.0;
+        xd = x * scale; yd = y * scale;
+    } else {
+        const double k1 = cam.D[0], k2 = cam.D[1], p1 = cam.D[2], p2 = cam.D[3];
+        const double r2 = x * x + y * y, r4 = r2 * r2;
+        const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+        const double cdist = 1.0 + k1 * r2 + k2 * r4;
+        xd = x * cdist + p1 * a1 + p2 * a2;
+        yd = y * cdist + p1 * a3 + p2 * a1;
+    }
     uo = (float)(xd * fx + cx);
     vo = (float)(yd * fy + cy);
 }

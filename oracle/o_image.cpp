@@ -2,6 +2,7 @@
 // Build with -ffp-contract=off: every floating-point expression below is a sequence of single
 // IEEE-754 operations in the written order (DESIGN.md §3 "arithmetic contract").
 #include "o_image.h"
+#include "o_math.h"
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -262,7 +263,7 @@ void undistort_point(const CamModel &cam, const double R[9], const double Pn[4],
                 theta = theta - fix;
                 if (std::fabs(fix) < 1e-8) break;
             }
-            scale = std::tan(theta) / theta_d;
+            scale = det_tan(theta) / theta_d;     // o_math.h: same operation sequence as the device
         }
         x = x * scale; y = y * scale;
     } else {
@@ -293,7 +294,7 @@ void distort_point(const CamModel &cam, float xf, float yf, float &uo, float &vo
     if (cam.model == MSKF_MODEL_EQUIDISTANT) {
         const double *k = cam.D;
         const double r = std::sqrt(x * x + y * y);
-        const double theta = std::atan(r);
+        const double theta = det_atan(r);
         const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
         const double theta_d = theta * (1 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8);
         const double scale = (r > 1e-8) ? theta_d / r : 1.0;

@@ -298,4 +298,63 @@ inline bool chol_solve(Mat S, Mat &B) {
     return true;
 }
 
+// Deterministic atan / tan for the equidistant (fisheye) camera model.  cv::fisheye::distortPoints needs atan(r),
+// cv::fisheye::undistortPoints needs tan(theta); libm and the GPU math library do not round them identically, so both
+// sides evaluate the SAME sequence of IEEE double operations (+ - * / only, no contraction): argument reduction to a
+// small interval and an odd Taylor polynomial.  Accuracy ~2e-16 relative (checked against libm in the tests).
+
+// atan(x), x >= 0:  x > 1 -> pi/2 - atan(1/x);  then atan(x) = atan(c) + atan((x - c) / (1 + x c)) with the nearest
+// c in {0, 1/4, 1/2, 3/4, 1} (|z| <= 1/8 -> 11 odd terms leave < 1e-21)
+static inline double det_atan(double x) {
+    const bool inv = x > 1.0;
+    if (inv) x = 1.0 / x;
+    double c = 0.0, ac = 0.0;
+    if (x > 0.875)      { c = 1.0;  ac = 0.78539816339744830962; }
+    else if (x > 0.625) { c = 0.75; ac = 0.64350110879328438680; }
+    else if (x > 0.375) { c = 0.5;  ac = 0.46364760900080611621; }
+    else if (x > 0.125) { c = 0.25; ac = 0.24497866312686415417; }
+    const double z = (x - c) / (1.0 + x * c);
+    const double z2 = z * z;
+    double p = 1.0 / 21.0;
+    p = 1.0 / 19.0 - z2 * p;
+    p = 1.0 / 17.0 - z2 * p;
+    p = 1.0 / 15.0 - z2 * p;
+    p = 1.0 / 13.0 - z2 * p;
+    p = 1.0 / 11.0 - z2 * p;
+    p = 1.0 / 9.0 - z2 * p;
+    p = 1.0 / 7.0 - z2 * p;
+    p = 1.0 / 5.0 - z2 * p;
+    p = 1.0 / 3.0 - z2 * p;
+    p = 1.0 - z2 * p;
+    const double a = ac + z * p;
+    return inv ? 1.5707963267948966192 - a : a;
+}
+// tan(t), 0 <= t <= pi/2:  t > pi/4 -> 1 / tan(pi/2 - t);  tan = sin / cos with Taylor series on [0, pi/4]
+static inline double det_tan(double t) {
+    const bool inv = t > 0.78539816339744830962;
+    if (inv) t = 1.5707963267948966192 - t;
+    const double t2 = t * t;
+    double s = 1.0 / 121645100408832000.0;              // 1/19!
+    s = 1.0 / 355687428096000.0 - t2 * s;                // 1/17!
+    s = 1.0 / 1307674368000.0 - t2 * s;                  // 1/15!
+    s = 1.0 / 6227020800.0 - t2 * s;                     // 1/13!
+    s = 1.0 / 39916800.0 - t2 * s;                       // 1/11!
+    s = 1.0 / 362880.0 - t2 * s;                         // 1/9!
+    s = 1.0 / 5040.0 - t2 * s;                           // 1/7!
+    s = 1.0 / 120.0 - t2 * s;                            // 1/5!
+    s = 1.0 / 6.0 - t2 * s;                              // 1/3!
+    s = t * (1.0 - t2 * s);
+    double c = 1.0 / 6402373705728000.0;                 // 1/18!
+    c = 1.0 / 20922789888000.0 - t2 * c;                 // 1/16!
+    c = 1.0 / 87178291200.0 - t2 * c;                    // 1/14!
+    c = 1.0 / 479001600.0 - t2 * c;                      // 1/12!
+    c = 1.0 / 3628800.0 - t2 * c;                        // 1/10!
+    c = 1.0 / 40320.0 - t2 * c;                          // 1/8!
+    c = 1.0 / 720.0 - t2 * c;                            // 1/6!
+    c = 1.0 / 24.0 - t2 * c;                             // 1/4!
+    c = 0.5 - t2 * c;                                    // 1/2!
+    c = 1.0 - t2 * c;
+    return inv ? c / s : s / c;
+}
+
 }  // namespace orc

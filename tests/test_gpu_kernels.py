@@ -272,6 +272,38 @@ def test_ekf_update_many_clones(gpu_ctx, oracle, n_clones, n_feat, seed):
     s.close()
 
 
+@pytest.mark.parametrize("models", [(1, 1), (1, 0)])
+def test_equidistant_model_stereo_bit_exact(gpu_ctx, oracle, models):
+    """Equidistant (fisheye) distortion model (image_processor.cpp:809-816,840): the stereo initial guess
+    (undistort with R_cam0_cam1, distort into cam1), the epipolar gate and the published undistorted coordinates go
+    through cv::fisheye-style undistort / distort with the deterministic atan / tan shared with the oracle."""
+    w, h = 752, 480
+    syn = oracle.Synth(seed=21, width=w, height=h)
+    a1, b1 = syn.render(30)
+    calib = oracle.euroc_calib(w, h)
+    calib.cam0_model, calib.cam1_model = models
+    fish = (-0.013, 0.021, -0.008, 0.0015)          # Kannala-Brandt k1..k4 of a mild fisheye
+    for i in range(4):
+        if models[0] == 1: calib.cam0_distortion[i] = fish[i]
+        if models[1] == 1: calib.cam1_distortion[i] = fish[i] * 0.9
+    fe = default_fe_cfg()
+    s = capi.Stream(gpu_ctx, calib, fe, default_ekf_cfg())
+    s.push_stereo(a1, b1)
+    cand, _ = oracle.detect(a1)
+    rng = np.random.default_rng(4)
+    cand = np.concatenate([cand, np.stack([rng.uniform(0, w, 64), rng.uniform(0, h, 64)], 1).astype(np.float32)])
+    got = s.track(cand, do_temporal=False)
+    ref_c1, ref_in = oracle.stereo_match(calib, fe, a1, b1, cand)
+    assert np.array_equal((got["status"] >> 1) & 1, ref_in)
+    assert np.array_equal(got["out1"], ref_c1)
+    K0, D0 = np.array(calib.cam0_intrinsics), np.array(calib.cam0_distortion)
+    K1, D1 = np.array(calib.cam1_intrinsics), np.array(calib.cam1_distortion)
+    assert np.array_equal(got["und0"], oracle.undistort(K0, D0, cand, model=models[0]))
+    assert np.array_equal(got["und1"], oracle.undistort(K1, D1, ref_c1, model=models[1]))
+    assert ref_in.sum() > 10
+    s.close()
+
+
 def test_track_capacity_and_errors(gpu_ctx, oracle):
     """Boundary behaviour of the C-ABI: capacity errors are reported, not crashed on."""
     s, calib = _stream(gpu_ctx, oracle, 376, 240)
@@ -286,7 +318,7 @@ def test_track_capacity_and_errors(gpu_ctx, oracle):
     with pytest.raises(capi.MskfError):
         s.push_stereo(np.zeros((100, 100), np.uint8), np.zeros((100, 100), np.uint8))   # wrong image size
     bad = oracle.euroc_calib(376, 240)
-    bad.cam0_model = 1
+    bad.cam0_model = 7
     with pytest.raises(capi.MskfError):
-        capi.Stream(gpu_ctx, bad, default_fe_cfg(), default_ekf_cfg())   # equidistant model: unsupported on device
+        capi.Stream(gpu_ctx, bad, default_fe_cfg(), default_ekf_cfg())   # unknown distortion model
     s.close()

@@ -243,3 +243,33 @@ def test_oracle_tracks_ground_truth(oracle):
     assert 55 <= len(ids) <= 85 and info.after_matching >= 50       # 4x5 grid, 3..4 features per cell
     # Q1: the feature message is never cleared
     assert len(sysm.msg()) > 60 * (n - 5)
+
+
+def test_deterministic_trig_and_fisheye_round_trip(oracle):
+    """The equidistant model uses a deterministic atan / tan (oracle/o_math.h, same operation sequence on the device):
+    distort(undistort(p)) returns p, and against numpy's libm the model functions agree to ~1e-7 px / 1e-15 relative."""
+    K = np.array([458.654, 457.296, 367.215, 248.375])
+    D = np.array([-0.013, 0.021, -0.008, 0.0015])
+    rng = np.random.default_rng(8)
+    pts = np.stack([rng.uniform(0, 752, 4000), rng.uniform(0, 480, 4000)], 1).astype(np.float32)
+    und = oracle.undistort(K, D, pts, model=1)
+    back = oracle.distort(K, D, und, model=1)
+    assert np.abs(back - pts).max() < 2e-3                      # float32 in/out around 1e3 px
+    # reference evaluation with libm (cv::fisheye::distortPoints)
+    x, y = und[:, 0].astype(np.float64), und[:, 1].astype(np.float64)
+    r = np.sqrt(x * x + y * y)
+    th = np.arctan(r)
+    thd = th * (1 + D[0] * th ** 2 + D[1] * th ** 4 + D[2] * th ** 6 + D[3] * th ** 8)
+    sc = np.where(r > 1e-8, thd / np.maximum(r, 1e-300), 1.0)
+    ref = np.stack([x * sc * K[0] + K[2], y * sc * K[1] + K[3]], 1)
+    assert np.abs(ref - back.astype(np.float64)).max() < 1e-4   # float32 output rounding only
+    # wide angles: rays up to ~80 degrees off axis
+    wide = np.stack([np.linspace(-5.5, 5.5, 401), np.linspace(5.0, -5.0, 401)], 1).astype(np.float32)
+    d = oracle.distort(K, D, wide, model=1).astype(np.float64)
+    x, y = wide[:, 0].astype(np.float64), wide[:, 1].astype(np.float64)
+    r = np.sqrt(x * x + y * y)
+    th = np.arctan(r)
+    thd = th * (1 + D[0] * th ** 2 + D[1] * th ** 4 + D[2] * th ** 6 + D[3] * th ** 8)
+    sc = np.where(r > 1e-8, thd / np.maximum(r, 1e-300), 1.0)
+    ref = np.stack([x * sc * K[0] + K[2], y * sc * K[1] + K[3]], 1)
+    assert np.abs(ref - d).max() < 1e-3 * (1 + np.abs(ref).max() / 1e4)
