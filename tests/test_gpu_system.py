@@ -319,3 +319,18 @@ def test_bench_scale_replicas_are_bit_identical(oracle):
     op, gp = osys.poses(), run.poses(0)
     assert np.abs(op["p"] - gp["p"]).max() < POS_TOL
     run.close()
+
+
+def test_c3_full_window_fallback_paths(oracle):
+    """C3 of SURVEY §8 end to end: 1280x720, 10x20 grid and a 50-clone window (d = 321) that fills and prunes, so the
+    gate matrices (up to 200 rows) and the 300-column factorisations run on the global-memory fallback paths inside a
+    real sequence.  Poses against the oracle at the usual bar."""
+    syn = oracle.Synth(seed=0x5EED0C33, width=1280, height=720)
+    fe = default_fe_cfg(grid_row=10, grid_col=20, grid_min=3, grid_max=4)
+    ekf = default_ekf_cfg(max_cam_state_size=50)
+    osys, run = _lockstep(oracle, syn, fe, ekf, 86, check_every=10)
+    assert run.num_clones() >= 48
+    assert osys.num_updates() == run.num_updates() > 20
+    compare_msgs(osys, run)
+    compare_poses(osys, run)
+    run.close()
