@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-enum { MSKF_MODEL_RADTAN = 0, MSKF_MODEL_EQUIDISTANT = 1 };
+enum { MSKF_MODEL_RADTAN = 0, MSKF_MODEL_EQUIDISTANT = 1 };   /* distortion_model of camchain yaml (image_processor.cpp:809-816,840); both run on the device */
 
 /* compat switches for the reference quirks of SURVEY.md §2.3 */
 enum {
