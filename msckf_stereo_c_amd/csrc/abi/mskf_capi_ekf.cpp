@@ -24,9 +24,12 @@ constexpr int kMaxRows = 65536;     // stacked-Jacobian row capacity per stream 
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int dev_alloc(double **p, size_t n) {
+// Zero-filled device buffer.  The fill is enqueued on the stream the buffer is going to be used on: the context
+// streams are hipStreamNonBlocking, so a hipMemset on the null stream is not ordered against their kernels (it is
+// asynchronous for device memory) and could land on top of data a kernel had already written.
+int dev_alloc(double **p, size_t n, hipStream_t st) {
     MSKF_HIPCHK(hipMalloc((void **)p, n * sizeof(double)));
-    MSKF_HIPCHK(hipMemset(*p, 0, n * sizeof(double)));
+    MSKF_HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double), st));
     return MSKF_OK;
 }
 
@@ -65,20 +68,22 @@ int mskf_ekf_stream_init(mskf_stream *s) {
     E.nmax = 4 * E.max_clones;
     int rc;
     const size_t pl = (size_t)E.ld * E.ld;
-    if ((rc = dev_alloc(&E.P, pl)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.T, pl)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.S, pl)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.W, pl)) != MSKF_OK) return rc;
-    { double *tmp = nullptr; if ((rc = dev_alloc(&tmp, (size_t)E.ld)) != MSKF_OK) return rc; E.act = (int *)tmp; }   // ld ints fit
-    if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.chi2, 128)) != MSKF_OK) return rc;
+    hipStream_t st = s->ctx->stream;     // the fills are drained below: the stream may be re-attached to another context later
+    if ((rc = dev_alloc(&E.P, pl, st)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.T, pl, st)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.S, pl, st)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.W, pl, st)) != MSKF_OK) return rc;
+    { double *tmp = nullptr; if ((rc = dev_alloc(&tmp, (size_t)E.ld, st)) != MSKF_OK) return rc; E.act = (int *)tmp; }   // ld ints fit
+    if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax, st)) != MSKF_OK) return rc;
+    if ((rc = dev_alloc(&E.chi2, 128, st)) != MSKF_OK) return rc;
+    EkfExtra *X = new EkfExtra();
+    s->ekf_extra = X;
+    if ((rc = dev_alloc(&X->P_alt, pl, st)) != MSKF_OK) return rc;
+    MSKF_HIPCHK(hipStreamSynchronize(st));
     double tab[100];
     tab[0] = 0.0;
     for (int i = 1; i < 100; ++i) tab[i] = s->ekf.chi2_mode == 1 ? mskf_chi2_ppf95[i - 1] : mskf_chi2_ppf05[i - 1];  // msckf_vio.cpp:181-185
     MSKF_HIPCHK(hipMemcpy(E.chi2, tab, sizeof(tab), hipMemcpyHostToDevice));
-    EkfExtra *X = new EkfExtra();
-    s->ekf_extra = X;
-    if ((rc = dev_alloc(&X->P_alt, pl)) != MSKF_OK) return rc;
     MSKF_HIPCHK(hipEventCreateWithFlags(&X->small_done, hipEventDisableTiming));
     return MSKF_OK;
 }
@@ -134,10 +139,11 @@ extern "C" int mskf_ekf_reset(mskf_stream *s, const double *P0) {
     if (!s || !P0) return MSKF_ERR_INVALID;
     EkfStreamState &E = s->ekf_state;
     MSKF_HIPCHK(hipSetDevice(s->ctx_ekf->device));
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
-    MSKF_HIPCHK(hipMemset(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld));
-    MSKF_HIPCHK(hipMemcpy2D(E.P, sizeof(double) * E.ld, P0, sizeof(double) * EKF_IMU_DIM, sizeof(double) * EKF_IMU_DIM, EKF_IMU_DIM,
-                            hipMemcpyHostToDevice));
+    hipStream_t st = s->ctx_ekf->stream;       // everything on the stream's own queue: the null stream is not ordered against it
+    MSKF_HIPCHK(hipMemsetAsync(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld, st));
+    MSKF_HIPCHK(hipMemcpy2DAsync(E.P, sizeof(double) * E.ld, P0, sizeof(double) * EKF_IMU_DIM, sizeof(double) * EKF_IMU_DIM, EKF_IMU_DIM,
+                                 hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipStreamSynchronize(st));
     E.d = EKF_IMU_DIM;
     return MSKF_OK;
 }
@@ -147,9 +153,10 @@ extern "C" int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d) {
     EkfStreamState &E = s->ekf_state;
     if (d < EKF_IMU_DIM || (d - EKF_IMU_DIM) % 6 || d > EKF_IMU_DIM + 6 * E.max_clones) return MSKF_ERR_CAPACITY;
     MSKF_HIPCHK(hipSetDevice(s->ctx_ekf->device));
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
-    MSKF_HIPCHK(hipMemset(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld));
-    MSKF_HIPCHK(hipMemcpy2D(E.P, sizeof(double) * E.ld, P, sizeof(double) * d, sizeof(double) * d, d, hipMemcpyHostToDevice));
+    hipStream_t st = s->ctx_ekf->stream;
+    MSKF_HIPCHK(hipMemsetAsync(E.P, 0, sizeof(double) * (size_t)E.ld * E.ld, st));
+    MSKF_HIPCHK(hipMemcpy2DAsync(E.P, sizeof(double) * E.ld, P, sizeof(double) * d, sizeof(double) * d, d, hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipStreamSynchronize(st));
     E.d = d;
     return MSKF_OK;
 }
@@ -459,8 +466,8 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             if (E.rs) (void)hipFree(E.rs);
             E.Hs = E.rs = nullptr;
             const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
-            if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld)) != MSKF_OK) return rc;
-            if ((rc = dev_alloc(&E.rs, (size_t)cap)) != MSKF_OK) return rc;
+            if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld, st)) != MSKF_OK) return rc;
+            if ((rc = dev_alloc(&E.rs, (size_t)cap, st)) != MSKF_OK) return rc;
             E.max_rows = cap;
         }
         max_feat = std::max(max_feat, a.n_feat);

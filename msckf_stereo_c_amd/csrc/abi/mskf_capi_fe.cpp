@@ -319,8 +319,8 @@ extern "C" int mskf_fe_push_stereo(mskf_stream *s, const uint8_t *cam0, const ui
         uint8_t *tmp0 = nullptr, *tmp1 = nullptr;
         MSKF_HIPCHK(hipMalloc((void **)&tmp0, (size_t)width * height));
         MSKF_HIPCHK(hipMalloc((void **)&tmp1, (size_t)width * height));
-        MSKF_HIPCHK(hipMemcpy2D(tmp0, width, cam0, pitch, width, height, hipMemcpyHostToDevice));
-        MSKF_HIPCHK(hipMemcpy2D(tmp1, width, cam1, pitch, width, height, hipMemcpyHostToDevice));
+        MSKF_HIPCHK(hipMemcpy2DAsync(tmp0, width, cam0, pitch, width, height, hipMemcpyHostToDevice, s->ctx->stream));
+        MSKF_HIPCHK(hipMemcpy2DAsync(tmp1, width, cam1, pitch, width, height, hipMemcpyHostToDevice, s->ctx->stream));
         const uint8_t *a[1] = {tmp0}, *b[1] = {tmp1};
         mskf_stream *ss[1] = {s};
         int rc = mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 1);

@@ -321,6 +321,43 @@ def test_bench_scale_replicas_are_bit_identical(oracle):
     run.close()
 
 
+def test_first_updates_identical_across_busy_groups(oracle):
+    """Regression: the stacked-Jacobian buffer is allocated at a stream's first update; its zero fill used to go to the
+    null stream, which is not ordered against the (non-blocking) context streams, and on a busy device it could land on
+    top of the feature kernel's rows — the first update of a few streams then silently did nothing.  Many groups running
+    freely through the first updates (frames 26-33) must leave every replica bit-identical, on several fresh runners."""
+    w, h, n_frames = 752, 480, 34
+    fe = default_fe_cfg(grid_row=8, grid_col=10, grid_min=4, grid_max=5)
+    ekf = default_ekf_cfg(max_cam_state_size=30)
+    uniq = [oracle.Synth(seed=0x5EED0050 + i, width=w, height=h) for i in range(2)]
+    n_groups, per_group = 6, 12
+    from msckf_stereo_c_amd.runner import IMU_SAMPLE
+    packs = []          # the replicas share the rendered frames of their sequence
+    for syn in uniq:
+        n_keys = syn.n_static + syn.n_loop
+        frames = np.empty((2, n_keys, h, w), np.uint8)
+        for k in range(n_frames + 1):
+            frames[0, k], frames[1, k] = syn.render(k)
+        imu = np.zeros((n_frames + 3) * 10 + 20, IMU_SAMPLE)
+        for j in range(len(imu)):
+            m = syn.imu(j)
+            imu[j] = (m.time_stamp, tuple(m.angular_velocity), tuple(m.linear_acceleration))
+        packs.append((frames, imu, n_keys, syn))
+    for attempt in range(4):
+        run = R.Runner(uniq[0].calib, fe, ekf, n_groups, per_group, host_threads=1)
+        for s in range(n_groups * per_group):
+            frames, imu, n_keys, syn = packs[s % 2]
+            run.set_sequence(s, frames.ctypes.data, frames.ctypes.data + n_keys * w * h, 0, w * h, syn.n_static, syn.n_loop,
+                             1403715273262142976, 50000000, imu)
+        run.run(0, n_frames, threaded=True, pipelined=False)
+        assert run.num_updates(0) >= 3
+        for s in range(2, n_groups * per_group):
+            a, b = run.cov(s % 2), run.cov(s)
+            assert a.shape == b.shape and np.array_equal(a, b), "attempt %d: stream %d covariance differs from its replica" % (attempt, s)
+            assert np.array_equal(run.poses(s % 2)["p"], run.poses(s)["p"])
+        run.close()
+
+
 def test_c3_full_window_fallback_paths(oracle):
     """C3 of SURVEY §8 end to end: 1280x720, 10x20 grid and a 50-clone window (d = 321) that fills and prunes, so the
     gate matrices (up to 200 rows) and the 300-column factorisations run on the global-memory fallback paths inside a
