@@ -55,7 +55,7 @@ void *mskf_ctx_hip_stream(mskf_ctx *ctx);
  * EKF feature / GEMM / Cholesky / TRSM kernels: algorithmic FP64 flops; others: streams).  Disabled by default; enabling costs two event records per launch. */
 enum {
     MSKF_K_PYR = 0, MSKF_K_DETECT, MSKF_K_LK, MSKF_K_EKF_PROPAGATE, MSKF_K_EKF_AUGMENT, MSKF_K_EKF_FEATURES,
-    MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_COUNT
+    MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_COUNT
 };
 int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
 /* arrays of MSKF_K_COUNT entries: accumulated milliseconds, launches and units since the last reset */

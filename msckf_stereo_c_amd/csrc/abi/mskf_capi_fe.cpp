@@ -437,13 +437,28 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_in.d, ctx->trk_in.h, in_bytes, hipMemcpyHostToDevice, st));
     MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-    const int ts_lk = mskf_t_begin(ctx, MSKF_K_LK);
-    fe_launch_lk(ctx->desc[1].d, n, max_pts, st);
-    mskf_t_end(ctx, ts_lk, 0);
+    // temporal track -> per-point gates + stereo guess -> stereo track -> per-point gates + undistortion
+    bool any_temporal = false;
+    for (int i = 0; i < n; ++i) any_temporal |= args[i].do_temporal && args[i].n > 0;
+    int ts_t = -1;
+    if (any_temporal) {
+        ts_t = mskf_t_begin(ctx, MSKF_K_LK);
+        fe_launch_lk(ctx->desc[1].d, n, max_pts, 0, st);
+        mskf_t_end(ctx, ts_t, 0);
+    }
+    const int ts_g0 = mskf_t_begin(ctx, MSKF_K_PT_GEOM);
+    fe_launch_pt_geom(ctx->desc[1].d, n, max_pts, 0, st);
+    mskf_t_end(ctx, ts_g0, 0);
+    const int ts_s = mskf_t_begin(ctx, MSKF_K_LK);
+    fe_launch_lk(ctx->desc[1].d, n, max_pts, 1, st);
+    mskf_t_end(ctx, ts_s, 0);
+    const int ts_g1 = mskf_t_begin(ctx, MSKF_K_PT_GEOM);
+    fe_launch_pt_geom(ctx->desc[1].d, n, max_pts, 1, st);
+    mskf_t_end(ctx, ts_g1, 0);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
     MSKF_HIPCHK(hipGetLastError());
     if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
-    long long tracks = 0;
+    long long tracks_t = 0, tracks_s = 0, pts = 0;
     for (int i = 0; i < n; ++i) {
         const mskf_fe_track_args &a = args[i];
         const size_t np = (size_t)a.n;
@@ -454,11 +469,16 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
         std::memcpy(a.und0, o + 2 * sizeof(mskf_point2f) * np, sizeof(mskf_point2f) * np);
         std::memcpy(a.und1, o + 3 * sizeof(mskf_point2f) * np, sizeof(mskf_point2f) * np);
         std::memcpy(a.status, o + 4 * sizeof(mskf_point2f) * np, np);
-        // units of the LK launch = point tracks executed: temporal (n) + stereo (tracked), or stereo only (n)
-        tracks += (long long)np;
-        if (a.do_temporal) for (size_t k = 0; k < np; ++k) tracks += (a.status[k] & 1);
+        // units of an LK launch = point tracks it executed: temporal (n of the temporal streams), stereo (the points that
+        // passed the temporal gate, or all n of a stereo-only stream)
+        pts += (long long)np;
+        if (a.do_temporal) { tracks_t += (long long)np; for (size_t k = 0; k < np; ++k) tracks_s += (a.status[k] & 1); }
+        else tracks_s += (long long)np;
     }
-    if (ts_lk >= 0) ctx->t_pending[ts_lk].units = tracks;
+    if (ts_t >= 0) ctx->t_pending[ts_t].units = tracks_t;
+    if (ts_s >= 0) ctx->t_pending[ts_s].units = tracks_s;
+    if (ts_g0 >= 0) ctx->t_pending[ts_g0].units = pts;
+    if (ts_g1 >= 0) ctx->t_pending[ts_g1].units = pts;
     mskf_t_collect(ctx);
     return MSKF_OK;
 }

@@ -17,7 +17,8 @@ void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_
 // spinning in hipStreamSynchronize, leaving the core to the other groups' host phases.
 int mskf_wait(mskf_ctx *c);
 void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, hipStream_t st);
-void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st);
+void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st);
+void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st);
 }
 
 void mskf_set_error(const std::string &s);

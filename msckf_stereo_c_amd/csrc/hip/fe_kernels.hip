@@ -477,11 +477,24 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
             lk_stage(imA, aw, ah, ax0, ay0, 18, s_R);
             __syncthreads();
             const int oxa = ipx - 1 - ax0;
-            for (int i = lane; i < 17 * 17; i += 64) {
-                const int r = i / 17, c = i - r * 17;
-                const uint8_t *q = s_Rb + r * LK_RS + oxa + c;
-                const int sv = (int)q[0] * w00 + (int)q[1] * w01 + (int)q[LK_RS] * w10 + (int)q[LK_RS + 1] * w11;
-                s_P[i] = (sv + 256) >> 9;
+            // lane (row = lane >> 2, seg) interpolates columns 5 seg .. 5 seg + 4 of its row (rows 0..15), lanes 0..3
+            // do row 16 in a second pass: five samples share six source bytes per row and no index is divided
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int r = pass == 0 ? (lane >> 2) : 16;
+                if (pass == 0 || lane < 4) {
+                    const int c0 = 5 * seg;
+                    const uint8_t *q = s_Rb + r * LK_RS + oxa + c0;       // columns <= oxa + 20 < LK_RS, rows <= 17: staged
+                    int t0[6], t1[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { t0[k] = q[k]; t1[k] = q[LK_RS + k]; }
+                    int *dst = s_P + r * 17 + c0;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int sv = t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11;
+                        if (c0 + k < 17) dst[k] = (sv + 256) >> 9;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -563,19 +576,20 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
     bx = ncx; by = ncy;
 }
 
-// One wavefront (= one 64-thread workgroup) per point; blockIdx.y = stream of the batch.
-__global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams) {
+// One wavefront (= one 64-thread workgroup) per point; blockIdx.y = stream of the batch.  Two launches per track
+// call: stereo = 0 is the temporal track prev0 -> curr0 (with the gyro-predicted start, :342-347), stereo = 1 the
+// stereo track curr0 -> curr1 of the points that survived.  The per-point double-precision geometry between and after
+// them (bounds gates, undistort / distort, epipolar gate) is k_pt_geom, one THREAD per point: inside this kernel all
+// 64 lanes of the wave would repeat the same ~2500 FP64 instructions per point, which was half of its VALU issue.
+__global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams, int stereo) {
     const FeStreamDev &S = streams[blockIdx.y];
     const int pt = blockIdx.x;
     if (pt >= S.n_pts) return;
     __shared__ int s_P[17 * 17];
     __shared__ __attribute__((aligned(8))) uint32_t s_R[LK_RS * LK_RH / 4];
-    const int W = S.curr0.w[0], H = S.curr0.h[0];
-    const mskf_point2f pin = S.in_pts[pt];
-    int st_bits = 0;
-    float c0x = pin.x, c0y = pin.y;
-    bool ok = true;
-    if (S.do_temporal) {
+    if (!stereo) {
+        if (!S.do_temporal) return;
+        const mskf_point2f pin = S.in_pts[pt];
         // predictFeatureTracking (:342-347): p2 = H p1, normalise, round to float
         const double *Hm = S.Hpred;
         const double px = (double)pin.x, py = (double)pin.y;
@@ -585,49 +599,88 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams) {
         float bx = (float)(X / Z), by = (float)(Y / Z);
         int st;
         lk_point(S.prev0, S.curr0, pin.x, pin.y, bx, by, st, s_P, s_R);
-        c0x = bx; c0y = by;
-        // :416-424
-        if (st && (c0y < 0 || c0y > (float)(H - 1) || c0x < 0 || c0x > (float)(W - 1))) st = 0;
-        ok = st != 0;
-        if (ok) st_bits |= 1;
-    } else {
-        st_bits |= 1;
-    }
-    float c1x = 0.f, c1y = 0.f, u0x = 0.f, u0y = 0.f, u1x = 0.f, u1y = 0.f;
-    if (ok) {
-        // stereo initial guess (:542-548)
-        float rx, ry;
-        undistort_pt(S.cam0, S.R01, c0x, c0y, rx, ry);
-        distort_pt(S.cam1, rx, ry, c1x, c1y);
-        int st;
-        lk_point(S.curr0, S.curr1, c0x, c0y, c1x, c1y, st, s_P, s_R);
-        // :575-583
-        const int W1 = S.curr1.w[0], H1 = S.curr1.h[0];
-        if (st && (c1y < 0 || c1y > (float)(H1 - 1) || c1x < 0 || c1x > (float)(W1 - 1))) st = 0;
-        // :601-617 (the undistorted points are also what publish() sends, :1154-1155)
-        undistort_pt(S.cam0, nullptr, c0x, c0y, u0x, u0y);
-        undistort_pt(S.cam1, nullptr, c1x, c1y, u1x, u1y);
-        if (st) {
-            const double *E = S.E;
-            const double x0 = (double)u0x, y0 = (double)u0y, x1 = (double)u1x, y1 = (double)u1y;
-            const double l0 = (E[0] * x0 + E[1] * y0) + E[2];
-            const double l1 = (E[3] * x0 + E[4] * y0) + E[5];
-            const double l2 = (E[6] * x0 + E[7] * y0) + E[8];
-            const double err = fabs((x1 * l0 + y1 * l1) + l2) / sqrt(l0 * l0 + l1 * l1);
-            if (err > S.epi_thresh) st = 0;
+        if ((threadIdx.x & 63) == 0) {
+            S.out0[pt] = mskf_point2f{bx, by};
+            S.status[pt] = (uint8_t)(st ? 1 : 0);
         }
-        if (st) st_bits |= 2;
+        return;
     }
+    if (!(__builtin_amdgcn_readfirstlane((int)S.status[pt]) & 1)) return;      // wave-uniform
+    const mskf_point2f c0 = S.out0[pt], g = S.out1[pt];
+    float c1x = g.x, c1y = g.y;
+    int st;
+    lk_point(S.curr0, S.curr1, c0.x, c0.y, c1x, c1y, st, s_P, s_R);
     if ((threadIdx.x & 63) == 0) {
-        S.out0[pt] = mskf_point2f{c0x, c0y};
         S.out1[pt] = mskf_point2f{c1x, c1y};
-        S.und0[pt] = mskf_point2f{u0x, u0y};
-        S.und1[pt] = mskf_point2f{u1x, u1y};
-        S.status[pt] = (uint8_t)st_bits;
+        S.status[pt] = (uint8_t)(1 | (st ? 2 : 0));
     }
 }
 
-extern "C" void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st) {
+// Per-point geometry of a track call, one thread per point.
+//   phase 0 (between the tracks): bounds gate of the temporal result (:416-424), stereo initial guess
+//            undistort(cam0, R01) -> distort(cam1) (:542-548); status bit 0 = the point goes on to the stereo track
+//   phase 1 (after the stereo track): bounds gate (:575-583), undistorted points (:601-604, also what publish()
+//            sends, :1154-1155), epipolar gate (:605-617); status bit 1 = stereo match accepted
+__global__ __launch_bounds__(64) void k_pt_geom(const FeStreamDev *streams, int phase) {
+    const FeStreamDev &S = streams[blockIdx.y];
+    const int pt = blockIdx.x * 64 + threadIdx.x;
+    if (pt >= S.n_pts) return;
+    if (phase == 0) {
+        const int W = S.curr0.w[0], H = S.curr0.h[0];
+        float c0x, c0y;
+        bool ok = true;
+        if (S.do_temporal) {
+            const mskf_point2f c0 = S.out0[pt];
+            c0x = c0.x; c0y = c0.y;
+            int st = S.status[pt] & 1;
+            if (st && (c0y < 0 || c0y > (float)(H - 1) || c0x < 0 || c0x > (float)(W - 1))) st = 0;
+            ok = st != 0;
+        } else {
+            const mskf_point2f pin = S.in_pts[pt];
+            c0x = pin.x; c0y = pin.y;
+            S.out0[pt] = pin;
+        }
+        float c1x = 0.f, c1y = 0.f;
+        if (ok) {
+            float rx, ry;
+            undistort_pt(S.cam0, S.R01, c0x, c0y, rx, ry);
+            distort_pt(S.cam1, rx, ry, c1x, c1y);
+        } else {
+            S.und0[pt] = mskf_point2f{0.f, 0.f};
+            S.und1[pt] = mskf_point2f{0.f, 0.f};
+        }
+        S.out1[pt] = mskf_point2f{c1x, c1y};
+        S.status[pt] = (uint8_t)(ok ? 1 : 0);
+        return;
+    }
+    const int bits = S.status[pt];
+    if (!(bits & 1)) return;
+    int st = bits & 2;
+    const mskf_point2f c0 = S.out0[pt], c1 = S.out1[pt];
+    const int W1 = S.curr1.w[0], H1 = S.curr1.h[0];
+    if (st && (c1.y < 0 || c1.y > (float)(H1 - 1) || c1.x < 0 || c1.x > (float)(W1 - 1))) st = 0;
+    float u0x, u0y, u1x, u1y;
+    undistort_pt(S.cam0, nullptr, c0.x, c0.y, u0x, u0y);
+    undistort_pt(S.cam1, nullptr, c1.x, c1.y, u1x, u1y);
+    if (st) {
+        const double *E = S.E;
+        const double x0 = (double)u0x, y0 = (double)u0y, x1 = (double)u1x, y1 = (double)u1y;
+        const double l0 = (E[0] * x0 + E[1] * y0) + E[2];
+        const double l1 = (E[3] * x0 + E[4] * y0) + E[5];
+        const double l2 = (E[6] * x0 + E[7] * y0) + E[8];
+        const double err = fabs((x1 * l0 + y1 * l1) + l2) / sqrt(l0 * l0 + l1 * l1);
+        if (err > S.epi_thresh) st = 0;
+    }
+    S.und0[pt] = mskf_point2f{u0x, u0y};
+    S.und1[pt] = mskf_point2f{u1x, u1y};
+    S.status[pt] = (uint8_t)(1 | (st ? 2 : 0));
+}
+
+extern "C" void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st) {
     if (max_pts <= 0) return;
-    hipLaunchKernelGGL(k_lk_points, dim3(max_pts, n_streams), dim3(64), 0, st, streams_dev);
+    hipLaunchKernelGGL(k_lk_points, dim3(max_pts, n_streams), dim3(64), 0, st, streams_dev, stereo);
+}
+extern "C" void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st) {
+    if (max_pts <= 0) return;
+    hipLaunchKernelGGL(k_pt_geom, dim3((max_pts + 63) / 64, n_streams), dim3(64), 0, st, streams_dev, phase);
 }
