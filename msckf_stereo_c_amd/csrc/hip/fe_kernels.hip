@@ -459,7 +459,7 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
         const uint8_t *imA = A.lvl[l];
         const uint8_t *imB = B.lvl[l];
         const int aw = A.w[l], ah = A.h[l], bw = B.w[l], bh = B.h[l];
-        const float sc = 1.0f / (float)(1 << l);
+        const float sc = __int_as_float((127 - l) << 23);        // 2^-l exactly, without the division
         const float pwx = ax * sc - (float)LK_HALF, pwy = ay * sc - (float)LK_HALF;
         if (l == MSKF_LEVELS - 1) { ncx = bx * sc; ncy = by * sc; }
         else { ncx = ncx * 2.0f; ncy = ncy * 2.0f; }
@@ -500,16 +500,23 @@ __device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, f
         __syncthreads();
         int Pv[4], Ix[4], Iy[4];
         int A11 = 0, A12 = 0, A22 = 0;
+        {
+            // Scharr gradients of the lane's four pixels from a shared 3 x 6 neighbourhood: horizontal differences per
+            // row and vertical differences per column are formed once (integer arithmetic: any grouping is exact)
+            const int *pu = s_P + lj * 17 + seg * 4;        // row above, column left of the first pixel
+            int u[6], m[6], dn[6];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = seg * 4 + k;
-            Pv[k] = 0; Ix[k] = 0; Iy[k] = 0;
-            if (row_ok && i < LK_WIN) {
-                const int *p = s_P + (lj + 1) * 17 + (i + 1);
-                const int sx = 3 * (p[-17 + 1] - p[-17 - 1]) + 10 * (p[1] - p[-1]) + 3 * (p[17 + 1] - p[17 - 1]);
-                const int sy = 3 * (p[17 - 1] - p[-17 - 1]) + 10 * (p[17] - p[-17]) + 3 * (p[17 + 1] - p[-17 + 1]);
-                const int gx = (sx + 16) >> 5, gy = (sy + 16) >> 5;
-                Pv[k] = p[0]; Ix[k] = gx; Iy[k] = gy;
+            for (int c = 0; c < 6; ++c) { u[c] = pu[c]; m[c] = pu[17 + c]; dn[c] = pu[34 + c]; }
+            int e[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) e[c] = dn[c] - u[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool on = row_ok && seg * 4 + k < LK_WIN;
+                const int sx = 3 * ((u[k + 2] - u[k]) + (dn[k + 2] - dn[k])) + 10 * (m[k + 2] - m[k]);
+                const int sy = 3 * (e[k] + e[k + 2]) + 10 * e[k + 1];
+                const int gx = on ? (sx + 16) >> 5 : 0, gy = on ? (sy + 16) >> 5 : 0;
+                Pv[k] = on ? m[k + 1] : 0; Ix[k] = gx; Iy[k] = gy;
                 A11 += __mul24(gx, gx); A12 += __mul24(gx, gy); A22 += __mul24(gy, gy);
             }
         }
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams, in
     const FeStreamDev &S = streams[blockIdx.y];
     const int pt = blockIdx.x;
     if (pt >= S.n_pts) return;
-    __shared__ int s_P[17 * 17];
+    __shared__ int s_P[17 * 17 + 3];     // + slack: the last lanes read one entry past the template (masked pixel)
     __shared__ __attribute__((aligned(8))) uint32_t s_R[LK_RS * LK_RH / 4];
     if (!stereo) {
         if (!S.do_temporal) return;
