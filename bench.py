@@ -36,11 +36,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "512")), help="VIO streams per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "768")), help="VIO streams per GPU")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "8")), help="host thread groups per GPU")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("MSKF_BENCH_HOST_THREADS", "1")), help="host threads per group")
     ap.add_argument("--no-pipeline", action="store_true", help="run front-end and filter of a group in lockstep on one thread")
-    ap.add_argument("--unique", type=int, default=4, help="distinct rendered sequences per GPU (streams cycle over them)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct rendered sequences per GPU (streams cycle over them); "
+                    "0 = one per stream of a group, so that no two streams of a launch read the same image (no L2 sharing)")
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--clones", type=int, default=30)
@@ -155,6 +156,8 @@ def main():
     n_streams = n_groups * per_group
     n_keys = 25 + args.loop
     total_frames = args.prime + args.warmup + args.steps
+    if args.unique <= 0:
+        args.unique = min(per_group, 128)
 
     t_r0 = time.perf_counter()
     syns, frames = render_sequences(oracle_py, args, rank, n_keys)
@@ -226,10 +229,11 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
         # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
-        # separately, profiles/r01_pmc_hbm_traffic.json); only comparable when a launch covers the same 32 streams
+        # separately, profiles/r01_pmc_hbm_traffic.json); only comparable when a launch covers the same number of streams
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"].get(dom)
-            if pmc and per_group == 64:
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            pmc = pmc_all["kernels"].get(dom)
+            if pmc and per_group == pmc_all.get("streams_per_launch", 64):
                 roof["traffic"] = (pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
                 roof["traffic_note"] = "bytes/launch, raw FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (no gfx950 correction applied)"
         except Exception:

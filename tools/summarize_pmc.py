@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r01_pmc_hbm_traffic.json.
 
-usage: tools/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>"
+usage: tools/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>" [streams per launch]
 Values are RAW counter KB per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE under-reports wide coalesced
 16 B/lane streams by 2x on gfx950; other access widths are uncalibrated, so no factor is applied).
 """
@@ -27,10 +27,11 @@ def agg(path, counter):
 
 def main():
     fetch, write, out, cmd = sys.argv[1:5]
+    spl = int(sys.argv[5]) if len(sys.argv) > 5 else 96
     ft, fc = agg(fetch, "FETCH_SIZE")
     wt, wc = agg(write, "WRITE_SIZE")
-    res = {"command": cmd,
-           "note": "KB per launch, RAW FETCH_SIZE / WRITE_SIZE (separate passes); default workload = 64 streams per launch; "
+    res = {"command": cmd, "streams_per_launch": spl,
+           "note": "KB per launch, RAW FETCH_SIZE / WRITE_SIZE (separate passes); "
                    "gfx950 FETCH_SIZE halves wide 16 B/lane streams, narrower widths are uncalibrated: no factor applied",
            "kernels": {k: {"launches": fc[k], "fetch_kb_per_launch": round(ft[k] / fc[k], 1),
                            "write_kb_per_launch": round(wt.get(k, 0) / max(wc.get(k, 1), 1), 1)} for k in sorted(ft)}}
