@@ -51,7 +51,7 @@ int mskf_ctx_sync(mskf_ctx *ctx);
 void *mskf_ctx_hip_stream(mskf_ctx *ctx);
 
 /* Optional per-kernel timing with HIP events recorded on the context's own stream (bench / roofline).
- * `units` are the algorithmic work units of a launch (LK: point tracks; pyramid: output pixels;
+ * `units` are the algorithmic work units of a launch (LK: point tracks, one launch per temporal / stereo track; point geometry: points; pyramid: output pixels;
  * EKF feature / GEMM / Cholesky / TRSM kernels: algorithmic FP64 flops; others: streams).  Disabled by default; enabling costs two event records per launch. */
 enum {
     MSKF_K_PYR = 0, MSKF_K_DETECT, MSKF_K_LK, MSKF_K_EKF_PROPAGATE, MSKF_K_EKF_AUGMENT, MSKF_K_EKF_FEATURES,

@@ -136,11 +136,15 @@ class Stream:
                 self.ctx.streams.remove(self)
 
     # ---- front-end
-    def push_stereo(self, cam0, cam1, t=0.0):
+    def push_stereo(self, cam0, cam1, t=0.0, pitch=None):
+        """cam0 / cam1: h x w images, or (pitch given) h x pitch buffers whose first w = calib.width columns are the image."""
         cam0 = np.ascontiguousarray(cam0, dtype=np.uint8)
         cam1 = np.ascontiguousarray(cam1, dtype=np.uint8)
         h, w = cam0.shape
-        _chk(self.L.mskf_fe_push_stereo(self.h, _p(cam0), _p(cam1), w, h, w, t))
+        if pitch is not None:
+            assert cam0.shape[1] == pitch and cam1.shape == cam0.shape
+            w = self.calib.width
+        _chk(self.L.mskf_fe_push_stereo(self.h, _p(cam0), _p(cam1), w, h, w if pitch is None else pitch, t))
 
     def cell_maxima(self):
         n = self.fe_cfg.det_rows * self.fe_cfg.det_cols

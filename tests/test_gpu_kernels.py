@@ -35,6 +35,21 @@ def test_pyramid_bit_exact(gpu_ctx, oracle, w, h):
     s.close()
 
 
+def test_pitched_host_images_are_repacked(gpu_ctx, oracle):
+    """mskf_fe_push_stereo with pitch > width (padded rows, cv::Mat::step): the padding never reaches the pyramid."""
+    w, h, pitch = 376, 240, 384
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+    b = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+    s, _ = _stream(gpu_ctx, oracle, w, h)
+    s.push_stereo(a, b, pitch=pitch)
+    for role, img in ((1, a[:, :w]), (2, b[:, :w])):
+        ref = oracle.build_pyramid(np.ascontiguousarray(img))
+        for lvl in range(4):
+            assert np.array_equal(s.get_level(role, lvl), ref[lvl]), (role, lvl)
+    s.close()
+
+
 @pytest.mark.parametrize("w,h,seed", [(752, 480, 1), (376, 240, 2), (1280, 720, 3)])
 def test_detector_bit_exact(gpu_ctx, oracle, w, h, seed):
     syn = oracle.Synth(seed=seed, width=w, height=h)
