@@ -26,7 +26,9 @@ enum {
     MSKF_COMPAT_Q1_MSG_ACCUMULATE = 1 << 0, /* feature message never cleared (image_processor.cpp:1157-1164) */
     MSKF_COMPAT_Q2_PREV_ALIAS     = 1 << 1, /* prev/curr image timestamps alias -> R_p_c == I (image_processor.cpp:192) */
     MSKF_COMPAT_Q4_RESPONSE_INDEX = 1 << 2, /* responses read in detection order after the sieve (image_processor.cpp:698) */
-    MSKF_COMPAT_REFERENCE         = 7
+    MSKF_COMPAT_Q5_NO_RANSAC      = 1 << 3, /* both twoPointRansac calls commented out (image_processor.cpp:482-500); cleared: the
+                                               2-point RANSAC of :911-1135 runs on the cam0 and cam1 temporal pairs */
+    MSKF_COMPAT_REFERENCE         = 15
 };
 
 typedef struct mskf_calib {

@@ -91,6 +91,18 @@ int mskfh_get_hostprof(double *out, int capacity, int reset) {
 const char *mskfh_hostprof_name(int slot) { return cg::hostprof::name(slot); }
 
 // ---- per-stream inspection
+// ImageProcessor::twoPointRansac on undistorted point pairs (host arithmetic only, no device involved)
+void mskfh_two_point_ransac(int n, const mskf_point2f *pts1_und, const mskf_point2f *pts2_und, const double *R_p_c, const double *intrinsics,
+                            double inlier_error, double success_probability, unsigned long long *draws, int32_t *markers) {
+    std::vector<cg::Point2f> a(n), b(n);
+    for (int i = 0; i < n; ++i) { a[i] = cg::Point2f(pts1_und[i].x, pts1_und[i].y); b[i] = cg::Point2f(pts2_und[i].x, pts2_und[i].y); }
+    hm::Mat3 R;
+    for (int i = 0; i < 9; ++i) R.m[i] = R_p_c[i];
+    std::vector<int> m;
+    cg::two_point_ransac(a, b, R, intrinsics, inlier_error, success_probability, *draws, m);
+    for (int i = 0; i < n; ++i) markers[i] = m[i];
+}
+
 int mskfh_num_features(void *h, int stream) {
     std::vector<ImageProcessor::FeatureIDType> ids; std::vector<int> life; std::vector<Point2f> a, b;
     ((MultiRunner *)h)->system(stream).imgproc_ptr_->dumpCurrent(ids, life, a, b);

@@ -257,12 +257,15 @@ void ImageProcessor::phasePrepare1(mskf_fe_track_args &args) {
     hostprof::Scope hp(hostprof::FE_PREPARE);
     hm::Mat3 cam0_R_p_c, cam1_R_p_c;
     integrateImuData(cam0_R_p_c, cam1_R_p_c);
-    t_ids_.clear(); t_lifetime_.clear(); in_pts_.clear();
+    cam0_R_p_c_ = cam0_R_p_c; cam1_R_p_c_ = cam1_R_p_c;
+    const bool ransac = !(cfg_.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC);
+    t_ids_.clear(); t_lifetime_.clear(); in_pts_.clear(); t_und0_.clear(); t_und1_.clear();
     for (const auto &item : *prev_features_ptr)
         for (const auto &pf : item.second) {
             t_ids_.push_back(pf.id);
             t_lifetime_.push_back(pf.lifetime);
             in_pts_.push_back(mskf_point2f{pf.cam0_point.x, pf.cam0_point.y});
+            if (ransac) { t_und0_.push_back(pf.und0); t_und1_.push_back(pf.und1); }
         }
     fill_args(args, (int)in_pts_.size(), 1, in_pts_, out0_, out1_, und0_, und1_, status_);
     computeHpred(cam0_R_p_c, args.Hpred);
@@ -322,12 +325,31 @@ void ImageProcessor::trackFeaturesTail() {
     before_tracking = (int)t_ids_.size();
     if (t_ids_.empty()) return;   // :383
     after_tracking = 0; after_matching = 0; after_ransac = 0;
+    // Q5: the reference has both twoPointRansac calls commented out (:482-500); with the switch cleared they run on the
+    // matched cam0 and cam1 temporal pairs and a feature must be an inlier of both
+    const bool ransac = !(cfg_.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC);
+    std::vector<int> keep;
+    if (ransac) {
+        std::vector<Point2f> p0, c0v, p1, c1v;
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < status_.size(); ++i) {
+            if ((status_[i] & 3) != 3) continue;
+            idx.push_back(i);
+            p0.push_back(t_und0_[i]); p1.push_back(t_und1_[i]);
+            c0v.push_back(Point2f(und0_[i].x, und0_[i].y)); c1v.push_back(Point2f(und1_[i].x, und1_[i].y));
+        }
+        std::vector<int> in0, in1;
+        twoPointRansac(p0, c0v, cam0_R_p_c_, calib_.cam0_intrinsics, processor_config.ransac_threshold, 0.99, in0);
+        twoPointRansac(p1, c1v, cam1_R_p_c_, calib_.cam1_intrinsics, processor_config.ransac_threshold, 0.99, in1);
+        keep.assign(status_.size(), 0);
+        for (size_t k = 0; k < idx.size(); ++k) keep[idx[k]] = in0[k] != 0 && in1[k] != 0;
+    }
     for (size_t i = 0; i < status_.size(); ++i) {
         if (!(status_[i] & 1)) continue;
         ++after_tracking;
         if (!(status_[i] & 2)) continue;
         ++after_matching;
-        // Q5: RANSAC disabled
+        if (ransac && !keep[i]) continue;
         const Point2f c0(out0_[i].x, out0_[i].y);
         int row = static_cast<int>(c0.y / grid_height);
         int col = static_cast<int>(c0.x / grid_width);
@@ -343,6 +365,128 @@ void ImageProcessor::trackFeaturesTail() {
         g.und1 = Point2f(und1_[i].x, und1_[i].y);
         ++after_ransac;
     }
+}
+
+// Counter-based stand-in for cg::uniform_integer(lo, hi): splitmix64 of the draw counter, reduced to [lo, hi]
+static int uniformInteger(unsigned long long &ransac_draws, int lo, int hi) {
+    uint64_t z = 0x5EED5EED5EED5EEDULL + 0x9E3779B97F4A7C15ULL * (++ransac_draws);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return lo + (int)(z % (uint64_t)(hi - lo + 1));
+}
+
+// :888-908 (single precision, as cg::Point2f arithmetic)
+static void rescalePoints(std::vector<Point2f> &pts1, std::vector<Point2f> &pts2, float &scaling_factor) {
+    scaling_factor = 0.0f;
+    for (size_t i = 0; i < pts1.size(); ++i) {
+        scaling_factor += std::sqrt(pts1[i].x * pts1[i].x + pts1[i].y * pts1[i].y);
+        scaling_factor += std::sqrt(pts2[i].x * pts2[i].x + pts2[i].y * pts2[i].y);
+    }
+    scaling_factor = (float)(pts1.size() + pts2.size()) / scaling_factor * std::sqrt(2.0f);
+    for (size_t i = 0; i < pts1.size(); ++i) {
+        pts1[i].x *= scaling_factor; pts1[i].y *= scaling_factor;
+        pts2[i].x *= scaling_factor; pts2[i].y *= scaling_factor;
+    }
+}
+
+void ImageProcessor::twoPointRansac(const std::vector<Point2f> &pts1_undistorted, const std::vector<Point2f> &pts2_undistorted,
+                                    const hm::Mat3 &R_p_c, const double intrinsics[4], double inlier_error,
+                                    double success_probability, std::vector<int> &inlier_markers) {
+    two_point_ransac(pts1_undistorted, pts2_undistorted, R_p_c, intrinsics, inlier_error, success_probability, ransac_draws, inlier_markers);
+}
+
+// :911-1135
+void two_point_ransac(const std::vector<Point2f> &pts1_undistorted, const std::vector<Point2f> &pts2_undistorted,
+                      const hm::Mat3 &R_p_c, const double intrinsics[4], double inlier_error,
+                      double success_probability, unsigned long long &ransac_draws, std::vector<int> &inlier_markers) {
+    const size_t n = pts1_undistorted.size();
+    double norm_pixel_unit = 2.0 / (intrinsics[0] + intrinsics[1]);
+    const int iter_num = static_cast<int>(std::ceil(std::log(1 - success_probability) / std::log(1 - 0.7 * 0.7)));
+    inlier_markers.assign(n, 1);     // :925-926
+    if (n == 0) return;
+    std::vector<Point2f> prev = pts1_undistorted, curr = pts2_undistorted;
+    // compensate the previous points with the relative rotation (:936-944)
+    for (Point2f &pt : prev) {
+        const hm::Vec3 rotated = R_p_c * hm::Vec3((double)pt.x, (double)pt.y, 1.0);
+        pt = Point2f((float)rotated[0], (float)rotated[1]);
+    }
+    float scale = 0.0f;
+    rescalePoints(prev, curr, scale);
+    norm_pixel_unit *= scale;
+    // per pair: difference, its length, and the epipolar coefficients of (tx, ty, tz) (:949-1012)
+    struct Pair { double len, tx, ty, tz; };
+    std::vector<Pair> pairs(n);
+    double length_sum = 0.0;
+    int candidates = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float dx = prev[i].x - curr[i].x, dy = prev[i].y - curr[i].y;
+        Pair &q = pairs[i];
+        q.len = std::sqrt((double)(dx * dx + dy * dy));
+        q.tx = (double)dy;
+        q.ty = (double)(-dx);
+        q.tz = (double)(prev[i].x * curr[i].y - prev[i].y * curr[i].x);
+        if (q.len > 50.0 * norm_pixel_unit) inlier_markers[i] = 0;      // :961-967
+        else { length_sum += q.len; ++candidates; }
+    }
+    const double mean_length = length_sum / candidates;
+    if (candidates < 3) { inlier_markers.assign(n, 0); return; }       // :974-977
+    const double tol = inlier_error * norm_pixel_unit;
+    if (mean_length < norm_pixel_unit) {                                // degenerate (pure rotation) case, :985-1001
+        for (size_t i = 0; i < n; ++i)
+            if (inlier_markers[i] && pairs[i].len > tol) inlier_markers[i] = 0;
+        return;
+    }
+    std::vector<int> pool;
+    for (size_t i = 0; i < n; ++i) if (inlier_markers[i]) pool.push_back((int)i);
+    const int m = (int)pool.size();
+    auto coeff = [&](int i, int k) { return k == 0 ? pairs[i].tx : (k == 1 ? pairs[i].ty : pairs[i].tz); };
+    std::vector<int> best, support;
+    for (int it = 0; it < iter_num; ++it) {
+        // two distinct pairs (:1025-1033)
+        const int first = uniformInteger(ransac_draws, 0, m - 1);
+        const int step = uniformInteger(ransac_draws, 1, m - 1);
+        const int second = first + step < m ? first + step : first + step - m;
+        const int i1 = pool[first], i2 = pool[second];
+        // the coefficient column with the smallest L1 norm is fixed to 1, the 2x2 system gives the other two (:1036-1065)
+        double l1[3];
+        for (int k = 0; k < 3; ++k) l1[k] = std::fabs(coeff(i1, k)) + std::fabs(coeff(i2, k));
+        int fixed = 0;
+        for (int k = 1; k < 3; ++k) if (l1[k] < l1[fixed]) fixed = k;
+        const int ka = fixed == 0 ? 1 : 0, kb = fixed == 2 ? 1 : 2;
+        double t[3];
+        {
+            const double a0 = coeff(i1, ka), a1 = coeff(i2, ka), b0 = coeff(i1, kb), b1 = coeff(i2, kb);
+            const double r0 = -coeff(i1, fixed), r1 = -coeff(i2, fixed);
+            const double det = a0 * b1 - b0 * a1;
+            const double v00 = b1 / det, v01 = -b0 / det, v10 = -a1 / det, v11 = a0 / det;
+            t[fixed] = 1.0;
+            t[ka] = v00 * r0 + v01 * r1;
+            t[kb] = v10 * r0 + v11 * r1;
+        }
+        support.clear();
+        for (size_t i = 0; i < n; ++i) {
+            if (!inlier_markers[i]) continue;
+            const double err = (pairs[i].tx * t[0] + pairs[i].ty * t[1]) + pairs[i].tz * t[2];
+            if (std::fabs(err) < tol) support.push_back((int)i);
+        }
+        if (support.size() < 0.2 * n) continue;                         // :1078-1079
+        // refit on the support set: ((A^T A)^-1 A^T)(-c), left to right (:1082-1112)
+        double saa = 0, sab = 0, sbb = 0;
+        for (int i : support) { const double a = coeff(i, ka), b = coeff(i, kb); saa += a * a; sab += a * b; sbb += b * b; }
+        const double det = saa * sbb - sab * sab;
+        const double v00 = sbb / det, v01 = -sab / det, v10 = -sab / det, v11 = saa / det;
+        double ua = 0, ub = 0;
+        for (int i : support) {
+            const double a = coeff(i, ka), b = coeff(i, kb), r = -coeff(i, fixed);
+            ua += (v00 * a + v01 * b) * r;
+            ub += (v10 * a + v11 * b) * r;
+        }
+        (void)ua; (void)ub;       // the refitted model only feeds best_error, which nothing reads (:1114-1121)
+        if (support.size() > best.size()) best = support;
+    }
+    inlier_markers.assign(n, 0);
+    for (int i : best) inlier_markers[i] = 1;
 }
 
 // :622-688

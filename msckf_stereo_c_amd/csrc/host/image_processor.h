@@ -21,6 +21,12 @@ namespace cg {
 mskf_calib calib_from_yaml(const YAML::Node &cfg_cam_imu);
 mskf_fe_cfg fe_cfg_from_yaml(const YAML::Node &cfg_imgproc);
 
+// twoPointRansac of image_processor.cpp:911-1135 on points already undistorted to normalised coordinates; `ransac_draws`
+// is the state of the counter-based draw generator (see ImageProcessor::twoPointRansac)
+void two_point_ransac(const std::vector<Point2f> &pts1_undistorted, const std::vector<Point2f> &pts2_undistorted,
+                      const hm::Mat3 &R_p_c, const double intrinsics[4], double inlier_error, double success_probability,
+                      unsigned long long &ransac_draws, std::vector<int> &inlier_markers);
+
 class ImageProcessor {
   public:
     // reference constructor (image_processor.cpp:32-42); config paths as in the reference (Q16)
@@ -96,6 +102,16 @@ class ImageProcessor {
     void setGridPosition(float x, float y);                                         // CornerDetector::set_grid_position
     void integrateImuData(hm::Mat3 &cam0_R_p_c, hm::Mat3 &cam1_R_p_c);
     void computeHpred(const hm::Mat3 &R_p_c, double H[9]) const;
+  public:
+    // twoPointRansac (image_processor.cpp:911-1135; dead code in the reference, runs when MSKF_COMPAT_Q5_NO_RANSAC is
+    // cleared).  pts1 / pts2: previous / current points ALREADY undistorted to normalised coordinates (the device
+    // returns them with every track, :929-930 happen there).  Host code: a few hundred points, seven sequential
+    // hypotheses, index-order sums — see DESIGN.md section 7.
+    void twoPointRansac(const std::vector<cg::Point2f> &pts1_undistorted, const std::vector<cg::Point2f> &pts2_undistorted,
+                        const hm::Mat3 &R_p_c, const double intrinsics[4], double inlier_error, double success_probability,
+                        std::vector<int> &inlier_markers);
+    unsigned long long ransac_draws = 0;    // state of the counter-based draw generator (cg::uniform_integer is in the absent vikit_cg)
+  private:
     void initializeFirstFrameTail();
     void trackFeaturesTail();
     void addNewFeaturesHead();
@@ -132,6 +148,8 @@ class ImageProcessor {
     std::vector<uint8_t> status_;
     std::vector<FeatureIDType> t_ids_;
     std::vector<int> t_lifetime_;
+    std::vector<cg::Point2f> t_und0_, t_und1_;    // undistorted previous points of the tracked features (RANSAC input)
+    hm::Mat3 cam0_R_p_c_, cam1_R_p_c_;            // integrateImuData result of this frame
     std::vector<double> cand_responses_det_;     // responses in detection order (Q4)
     std::vector<double> cand_responses_sieved_;  // responses in sieve order
     std::vector<mskf_corner> cell_max_;

@@ -58,7 +58,7 @@ CORNER = np.dtype([("x", "<f4"), ("y", "<f4"), ("score", "<i4"), ("cell", "<i4")
 FEATURE_MEAS = np.dtype([("id", "<u4"), ("_pad", "<u4"), ("u0", "<f8"), ("v0", "<f8"), ("u1", "<f8"), ("v1", "<f8")])
 POSE = np.dtype([("t", "<f8"), ("p", "<f8", 3), ("q", "<f8", 4)])
 
-COMPAT_REFERENCE = 7
+COMPAT_REFERENCE = 15     # Q1 | Q2 | Q4 | Q5 (include/mskf_types.h)
 
 
 def default_fe_cfg(grid_row=4, grid_col=5, grid_min=3, grid_max=4, compat=COMPAT_REFERENCE):

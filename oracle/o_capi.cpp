@@ -94,6 +94,22 @@ void orc_stereo_match(const mskf_calib *calib, const mskf_fe_cfg *cfg, const uin
     for (int i = 0; i < n; ++i) { pts1[i] = b[i]; inliers[i] = m[i]; }
 }
 
+// twoPointRansac (image_processor.cpp:911-1135) on one camera's temporal pairs; `draws` is the state of the draw counter
+void orc_two_point_ransac(const mskf_calib *calib, const mskf_fe_cfg *cfg, int cam, int n, const mskf_point2f *pts1, const mskf_point2f *pts2,
+                          const double *R_p_c, double inlier_error, double success_probability, unsigned long long *draws, int32_t *markers) {
+    ImageProcessor ip(*calib, *cfg);
+    CamModel c;
+    for (int i = 0; i < 4; ++i) { c.K[i] = cam ? calib->cam1_intrinsics[i] : calib->cam0_intrinsics[i]; c.D[i] = cam ? calib->cam1_distortion[i] : calib->cam0_distortion[i]; }
+    c.model = cam ? calib->cam1_model : calib->cam0_model;
+    M3 R; for (int i = 0; i < 9; ++i) R.m[i] = R_p_c[i];
+    ip.ransac_draws = *draws;
+    std::vector<mskf_point2f> a(pts1, pts1 + n), b(pts2, pts2 + n);
+    std::vector<int> m;
+    ip.twoPointRansac(a, b, R, c, inlier_error, success_probability, m);
+    for (int i = 0; i < n; ++i) markers[i] = m[i];
+    *draws = ip.ransac_draws;
+}
+
 // ---------------------------------------------------------------- System
 void *orc_system_create(const mskf_calib *c, const mskf_fe_cfg *f, const mskf_ekf_cfg *e) { return new OSystem(*c, *f, *e); }
 void orc_system_destroy(void *h) { delete (OSystem *)h; }

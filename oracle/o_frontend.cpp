@@ -1,6 +1,7 @@
 // oracle/o_frontend.cpp — TEST INFRASTRUCTURE ONLY (CPU oracle).  See o_frontend.h.
 #include "o_frontend.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 
 namespace orc {
@@ -204,9 +205,22 @@ void ImageProcessor::trackFeatures() {
     }
     after_matching = (int)curr_matched_cam0.size();
 
-    // Q5: both twoPointRansac calls are commented out (:482-500)
+    // Q5: both twoPointRansac calls are commented out (:482-500); with the switch cleared they run as written there
+    std::vector<int> cam0_ransac_inliers, cam1_ransac_inliers;
+    const bool ransac = !(cfg_.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC);
+    if (ransac) {
+        std::vector<mskf_point2f> prev_matched_cam0, prev_matched_cam1;
+        for (size_t i = 0; i < match_inliers.size(); ++i) {
+            if (!match_inliers[i]) continue;
+            prev_matched_cam0.push_back(prev_tracked_cam0[i]);
+            prev_matched_cam1.push_back(prev_tracked_cam1[i]);
+        }
+        twoPointRansac(prev_matched_cam0, curr_matched_cam0, cam0_R_p_c, cam0_, cfg_.ransac_threshold, 0.99, cam0_ransac_inliers);
+        twoPointRansac(prev_matched_cam1, curr_matched_cam1, cam1_R_p_c, cam1_, cfg_.ransac_threshold, 0.99, cam1_ransac_inliers);
+    }
     after_ransac = 0;
     for (size_t i = 0; i < curr_matched_cam0.size(); ++i) {
+        if (ransac && (cam0_ransac_inliers[i] == 0 || cam1_ransac_inliers[i] == 0)) continue;
         int row = static_cast<int>(curr_matched_cam0[i].y / grid_height);
         int col = static_cast<int>(curr_matched_cam0[i].x / grid_width);
         int code = row * cfg_.grid_col + col;  // Q7: col may equal grid_col
@@ -218,6 +232,138 @@ void ImageProcessor::trackFeatures() {
         g.cam1_point = curr_matched_cam1[i];
         ++after_ransac;
     }
+}
+
+// Counter-based replacement of cg::uniform_integer(lo, hi) (vikit_cg, absent): splitmix64 of a per-processor draw
+// counter, reduced to [lo, hi].  The product's host mirror uses the same definition (image_processor.cpp there).
+int ImageProcessor::uniformInteger(int lo, int hi) {
+    unsigned long long z = 0x5EED5EED5EED5EEDULL + 0x9E3779B97F4A7C15ULL * (++ransac_draws);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return lo + (int)(z % (unsigned long long)(hi - lo + 1));
+}
+
+// :888-908, float arithmetic as written (Point2f members are float)
+void ImageProcessor::rescalePoints(std::vector<mskf_point2f> &pts1, std::vector<mskf_point2f> &pts2, float &scaling_factor) {
+    scaling_factor = 0.0f;
+    for (size_t i = 0; i < pts1.size(); ++i) {
+        scaling_factor += std::sqrt(pts1[i].x * pts1[i].x + pts1[i].y * pts1[i].y);
+        scaling_factor += std::sqrt(pts2[i].x * pts2[i].x + pts2[i].y * pts2[i].y);
+    }
+    scaling_factor = (float)(pts1.size() + pts2.size()) / scaling_factor * std::sqrt(2.0f);
+    for (size_t i = 0; i < pts1.size(); ++i) {
+        pts1[i].x *= scaling_factor; pts1[i].y *= scaling_factor;
+        pts2[i].x *= scaling_factor; pts2[i].y *= scaling_factor;
+    }
+}
+
+namespace {
+// x of [a b] x = rhs with columns a, b of two entries: inverse by adjugate / determinant, then the product
+inline void solve2(const double a[2], const double b[2], const double rhs[2], double x[2]) {
+    const double det = a[0] * b[1] - b[0] * a[1];
+    const double i00 = b[1] / det, i01 = -b[0] / det, i10 = -a[1] / det, i11 = a[0] / det;
+    x[0] = i00 * rhs[0] + i01 * rhs[1];
+    x[1] = i10 * rhs[0] + i11 * rhs[1];
+}
+}  // namespace
+
+// :911-1135.  Float where the reference holds cg::Point2f, double elsewhere; sums run in index order.
+void ImageProcessor::twoPointRansac(const std::vector<mskf_point2f> &pts1, const std::vector<mskf_point2f> &pts2, const M3 &R_p_c,
+                                    const CamModel &cam, double inlier_error, double success_probability,
+                                    std::vector<int> &inlier_markers) {
+    const size_t n = pts1.size();
+    double norm_pixel_unit = 2.0 / (cam.K[0] + cam.K[1]);
+    const int iter_num = static_cast<int>(std::ceil(std::log(1 - success_probability) / std::log(1 - 0.7 * 0.7)));
+    inlier_markers.assign(n, 1);
+    if (n == 0) return;
+    std::vector<mskf_point2f> p1(n), p2(n);
+    undistortPoints(pts1, cam, p1);
+    undistortPoints(pts2, cam, p2);
+    for (auto &pt : p1) {   // :938-944, no perspective division
+        const V3 h = R_p_c * V3((double)pt.x, (double)pt.y, 1.0);
+        pt.x = (float)h[0]; pt.y = (float)h[1];
+    }
+    float scaling_factor = 0.0f;
+    rescalePoints(p1, p2, scaling_factor);
+    norm_pixel_unit *= scaling_factor;
+    std::vector<mskf_point2f> diff(n);
+    for (size_t i = 0; i < n; ++i) diff[i] = mskf_point2f{p1[i].x - p2[i].x, p1[i].y - p2[i].y};
+    std::vector<double> dist(n);
+    double mean_pt_distance = 0.0;
+    int raw_inlier_cntr = 0;
+    for (size_t i = 0; i < n; ++i) {
+        dist[i] = std::sqrt((double)(diff[i].x * diff[i].x + diff[i].y * diff[i].y));
+        if (dist[i] > 50.0 * norm_pixel_unit) inlier_markers[i] = 0;
+        else { mean_pt_distance += dist[i]; ++raw_inlier_cntr; }
+    }
+    mean_pt_distance /= raw_inlier_cntr;
+    if (raw_inlier_cntr < 3) { inlier_markers.assign(n, 0); return; }
+    if (mean_pt_distance < norm_pixel_unit) {   // degenerate motion, :992-1001
+        for (size_t i = 0; i < n; ++i) {
+            if (inlier_markers[i] == 0) continue;
+            if (dist[i] > inlier_error * norm_pixel_unit) inlier_markers[i] = 0;
+        }
+        return;
+    }
+    std::vector<double> ct(3 * n);   // coeff_t rows: tx, ty, tz
+    for (size_t i = 0; i < n; ++i) {
+        ct[3 * i + 0] = (double)diff[i].y;
+        ct[3 * i + 1] = (double)(-diff[i].x);
+        ct[3 * i + 2] = (double)(p1[i].x * p2[i].y - p1[i].y * p2[i].x);
+    }
+    std::vector<int> raw_inlier_idx;
+    for (size_t i = 0; i < n; ++i) if (inlier_markers[i] != 0) raw_inlier_idx.push_back((int)i);
+    std::vector<int> best_inlier_set;
+    const int m = (int)raw_inlier_idx.size();
+    for (int iter_idx = 0; iter_idx < iter_num; ++iter_idx) {
+        const int select_idx1 = uniformInteger(0, m - 1);
+        const int select_idx_diff = uniformInteger(1, m - 1);
+        const int select_idx2 = select_idx1 + select_idx_diff < m ? select_idx1 + select_idx_diff : select_idx1 + select_idx_diff - m;
+        const int pair1 = raw_inlier_idx[select_idx1], pair2 = raw_inlier_idx[select_idx2];
+        const double c[3][2] = {{ct[3 * pair1 + 0], ct[3 * pair2 + 0]}, {ct[3 * pair1 + 1], ct[3 * pair2 + 1]}, {ct[3 * pair1 + 2], ct[3 * pair2 + 2]}};
+        const double l1[3] = {std::fabs(c[0][0]) + std::fabs(c[0][1]), std::fabs(c[1][0]) + std::fabs(c[1][1]), std::fabs(c[2][0]) + std::fabs(c[2][1])};
+        int base = 0;
+        for (int k = 1; k < 3; ++k) if (l1[k] < l1[base]) base = k;      // std::min_element: first minimum
+        const int ia = base == 0 ? 1 : 0, ib = base == 2 ? 1 : 2;       // the two other columns, ascending
+        double model[3], sol[2];
+        {
+            const double rhs[2] = {-c[base][0], -c[base][1]};
+            solve2(c[ia], c[ib], rhs, sol);
+            model[base] = 1.0; model[ia] = sol[0]; model[ib] = sol[1];
+        }
+        std::vector<int> inlier_set;
+        for (size_t i = 0; i < n; ++i) {
+            if (inlier_markers[i] == 0) continue;
+            const double e = (ct[3 * i] * model[0] + ct[3 * i + 1] * model[1]) + ct[3 * i + 2] * model[2];
+            if (std::fabs(e) < inlier_error * norm_pixel_unit) inlier_set.push_back((int)i);
+        }
+        if (inlier_set.size() < 0.2 * n) continue;
+        // least-squares refit over the inliers: ((A^T A)^-1 A^T) (-c_base), evaluated left to right
+        double saa = 0, sab = 0, sbb = 0;
+        for (int idx : inlier_set) {
+            const double a = ct[3 * idx + ia], b = ct[3 * idx + ib];
+            saa += a * a; sab += a * b; sbb += b * b;
+        }
+        const double det = saa * sbb - sab * sab;
+        const double i00 = sbb / det, i01 = -sab / det, i10 = -sab / det, i11 = saa / det;
+        double s0 = 0, s1 = 0;
+        for (int idx : inlier_set) {
+            const double a = ct[3 * idx + ia], b = ct[3 * idx + ib], r = -ct[3 * idx + base];
+            s0 += (i00 * a + i01 * b) * r;
+            s1 += (i10 * a + i11 * b) * r;
+        }
+        double better[3];
+        better[base] = 1.0; better[ia] = s0; better[ib] = s1;
+        double this_error = 0.0;
+        for (int idx : inlier_set)
+            this_error += std::fabs((ct[3 * idx] * better[0] + ct[3 * idx + 1] * better[1]) + ct[3 * idx + 2] * better[2]);
+        this_error /= inlier_set.size();
+        (void)this_error;   // only compared through the set size in the reference (:1118-1121)
+        if (inlier_set.size() > best_inlier_set.size()) best_inlier_set = inlier_set;
+    }
+    inlier_markers.assign(n, 0);
+    for (int idx : best_inlier_set) inlier_markers[idx] = 1;
 }
 
 void ImageProcessor::undistortPoints(const std::vector<mskf_point2f> &in, const CamModel &cam,

@@ -62,6 +62,15 @@ class ImageProcessor {
     void undistortPoints(const std::vector<mskf_point2f> &in, const CamModel &cam, std::vector<mskf_point2f> &out,
                          const M3 &R = M3::eye());
     void distortPoints(const std::vector<mskf_point2f> &in, const CamModel &cam, std::vector<mskf_point2f> &out);
+  public:
+    // :911-1135 (dead code in the reference, Q5); draws come from a counter-based generator because
+    // cg::uniform_integer lives in the absent vikit_cg
+    void twoPointRansac(const std::vector<mskf_point2f> &pts1, const std::vector<mskf_point2f> &pts2, const M3 &R_p_c,
+                        const CamModel &cam, double inlier_error, double success_probability, std::vector<int> &inlier_markers);
+    unsigned long long ransac_draws = 0;   // state of the draw counter
+  private:
+    int uniformInteger(int lo, int hi);
+    static void rescalePoints(std::vector<mskf_point2f> &pts1, std::vector<mskf_point2f> &pts2, float &scaling_factor);   // :888-908
 
     mskf_calib calib_;
     mskf_fe_cfg cfg_;

@@ -15,15 +15,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 
 
+_built = False
+
+
 def build(force=False):
-    have = os.path.exists(os.path.join(_BUILD, "liboracle.so")) and os.path.exists(os.path.join(_BUILD, "libmskf_synth.so"))
-    if force or not have:
-        import fcntl
-        os.makedirs(_BUILD, exist_ok=True)
-        with open(os.path.join(_BUILD, ".lock"), "w") as lk:      # several ranks may get here at once
-            fcntl.flock(lk, fcntl.LOCK_EX)
-            subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
-            fcntl.flock(lk, fcntl.LOCK_UN)
+    """make decides what is stale (the libraries under _build/ travel with the tree, the sources may be newer)."""
+    global _built
+    if _built and not force:
+        return
+    import fcntl
+    os.makedirs(_BUILD, exist_ok=True)
+    with open(os.path.join(_BUILD, ".lock"), "w") as lk:      # several ranks may get here at once
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+        fcntl.flock(lk, fcntl.LOCK_UN)
+    _built = True
 
 
 _lib = None
@@ -299,6 +305,19 @@ def stereo_match(calib, fe_cfg, cam0, cam1, pts0):
     cam1 = np.ascontiguousarray(cam1)
     lib().orc_stereo_match(C.byref(calib), C.byref(fe_cfg), _p(cam0), _p(cam1), len(a), _p(a), _p(b), _p(m))
     return b, m
+
+
+def two_point_ransac(calib, fe_cfg, cam, pts1, pts2, R_p_c, inlier_error=3.0, success_probability=0.99, draws=0):
+    """ImageProcessor::twoPointRansac (image_processor.cpp:911-1135) -> (markers, draw counter afterwards)."""
+    a = np.ascontiguousarray(pts1, dtype=np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(pts2, dtype=np.float32).reshape(-1, 2)
+    R = np.ascontiguousarray(R_p_c, dtype=np.float64).reshape(9)
+    m = np.zeros(len(a), np.int32)
+    d = C.c_ulonglong(draws)
+    f = lib().orc_two_point_ransac
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    f(C.byref(calib), C.byref(fe_cfg), cam, len(a), _p(a), _p(b), _p(R), inlier_error, success_probability, C.byref(d), _p(m))
+    return m, d.value
 
 
 def ekf_update_problem(calib, ekf_cfg, gravity, clones, P, positions, obs_start, obs_clone, obs_z, dof_offset):

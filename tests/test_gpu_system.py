@@ -178,7 +178,7 @@ def test_pipelined_run_is_identical_to_lockstep(oracle):
         r.close()
 
 
-def _lockstep(oracle, syn, fe, ekf, n_frames, frame_hook=None, check_every=1):
+def _lockstep(oracle, syn, fe, ekf, n_frames, frame_hook=None, check_every=1, after_frame=None):
     """Run oracle and GPU path in lockstep on (possibly modified) frames of `syn`; returns (osys, run)."""
     osys = oracle.OracleSystem(syn.calib, fe, ekf)
     run = R.Runner(syn.calib, fe, ekf, 1, 1)
@@ -202,16 +202,54 @@ def _lockstep(oracle, syn, fe, ekf, n_frames, frame_hook=None, check_every=1):
         view.backend()
         if k % check_every == 0:
             compare_frame(k, osys, run)
+        if after_frame:
+            after_frame(k, osys, run)
     return osys, run
 
 
 def test_compat_switches_off(oracle):
-    """compat_flags = 0: cleared message (no Q1), true previous timestamp (no Q2), sieve-order responses (no Q4)."""
+    """compat_flags = 0: cleared message (no Q1), true previous timestamp (no Q2), sieve-order responses (no Q4) and the
+    2-point RANSAC of image_processor.cpp:911-1135 on both cameras (no Q5)."""
     syn = oracle.Synth(seed=0x5EED0030, width=376, height=240)
     fe, ekf = default_fe_cfg(compat=0), default_ekf_cfg()
     osys, run = _lockstep(oracle, syn, fe, ekf, 60)
     compare_msgs(osys, run)
     assert len(run.msg()) == len(run.dump()[0])          # message holds exactly the live features
+    compare_poses(osys, run)
+    run.close()
+
+
+def test_ransac_rejects_independently_moving_patch(oracle):
+    """RANSAC on (compat_flags = 0): a textured patch drifting across both images carries features whose temporal flow
+    contradicts the camera motion; they pass the stereo gate and must be dropped by the 2-point RANSAC — in the same
+    frames, with the same survivors (ids, pixels, counters), by the GPU path and the oracle."""
+    syn = oracle.Synth(seed=0x5EED0033, width=376, height=240)
+    fe, ekf = default_fe_cfg(compat=0), default_ekf_cfg()
+    rng = np.random.default_rng(5)
+    patch = (rng.integers(0, 2, (12, 12)) * 160 + 40).astype(np.uint8).repeat(5, axis=0).repeat(5, axis=1)   # 60 x 60 blocks
+
+    def hook(k, a, b):
+        if k < 30:
+            return a, b
+        a, b = a.copy(), b.copy()
+        x = 40 + 4 * (k - 30)
+        y = 60 + 2 * (k - 30)
+        if x + 60 + 8 < a.shape[1] and y + 60 < a.shape[0]:
+            a[y:y + 60, x + 8:x + 68] = patch                # 8 px of disparity: a consistent stereo pair
+            b[y:y + 60, x:x + 60] = patch
+        return a, b
+
+    rejected = []
+
+    def after(k, osys, run):
+        info = run.dump()[4]
+        assert info.after_ransac <= info.after_matching
+        rejected.append(info.after_matching - info.after_ransac)
+
+    osys, run = _lockstep(oracle, syn, fe, ekf, 70, frame_hook=hook, after_frame=after)
+    assert sum(rejected[:30]) <= 2                           # static scene: (almost) nothing to reject
+    assert sum(rejected[31:]) >= 5, rejected                 # features riding on the patch are thrown out
+    compare_msgs(osys, run)
     compare_poses(osys, run)
     run.close()
 
