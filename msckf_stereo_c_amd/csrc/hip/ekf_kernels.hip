@@ -431,7 +431,6 @@ __device__ bool triangulate_wave(const EkfStreamDev &S, const EkfFeatDev &F, TS 
 // Mm is symmetric and kept in packed lower form (row i at i(i+1)/2): 120 rows = 56.7 KiB, so with the
 // 32-clone instantiation (19 KiB static) two workgroups share a CU.
 #define GATE_LDS_ROWS 120
-#define GATE_PAN_RS 128          // k-major Cholesky panel stride (>= GATE_LDS_ROWS - 2 rows, multiple of 16)
 __device__ __forceinline__ size_t pk(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // i >= j
 // Work group of a feature: the whole 256-thread workgroup (WAVE = false), or one wavefront (WAVE = true: four
 // features per workgroup side by side, wave-level barriers only) for launches whose features all have <= MAXC = 4
@@ -446,9 +445,10 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
     const int sub = WAVE ? (int)(threadIdx.x >> 6) : 0;
     const int d = S.d, ld = S.ld;
     // Jacobian / reflector scratch, one block per feature in flight: it is dead once the gate matrix is reflected,
-    // and the 16-wide Cholesky panel (LNB x GATE_PAN_RS doubles) of the workgroup variant reuses it
+    // and the 16-wide Cholesky panel (LNB x PAN_RS doubles) of the workgroup variant reuses it
     constexpr int BLK_DOUBLES = (12 + 24 + 4 + 12) * MAXC + 3 * (6 * MAXC + 1);
-    static_assert(MAXC != 32 || BLK_DOUBLES >= LNB * GATE_PAN_RS, "panel does not fit the dead scratch");
+    constexpr int PAN_RS = WAVE ? 16 : ((4 * MAXC + 15) / 16) * 16;      // k-major Cholesky panel stride: rows rounded up to 16
+    static_assert(WAVE || BLK_DOUBLES >= LNB * PAN_RS, "panel does not fit the dead scratch");
     __shared__ double s_blk_all[NSUB][BLK_DOUBLES];
     double *s_blk = s_blk_all[sub];
     double (*sHf)[3] = reinterpret_cast<double (*)[3]>(s_blk);
@@ -744,14 +744,16 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         // needs no separate triangular solve.
 #define SG(i, j) Mm[pk((i) + 3, (j) + 3)]
         bool pd_ok = true;
-        const bool blocked = !WAVE && (rows <= lds_rows) && (MAXC == 32);
+        // workgroup variant: blocked factorisation (chol_block.h) whether the gate matrix sits in LDS or, for features
+        // with more rows than fit, in the stream's global scratch (same code through a generic pointer)
+        const bool blocked = !WAVE;
         if (blocked) {
             // packed row `rows` (columns 3 ..) carries r_o: the blocked factorisation leaves L^-1 r_o there
             for (int i = gt; i < n; i += GS) { SG(i, i) += S.sigma2; SG(n, i) = sRo[i]; }
-            for (int i = gt; i < LNB * GATE_PAN_RS; i += GS) s_blk[i] = 0.0;       // panel buffer (scratch is dead)
+            for (int i = gt; i < LNB * PAN_RS; i += GS) s_blk[i] = 0.0;            // panel buffer (scratch is dead)
             if (gt < 16) Mm[pk(rows, 3 + n) + gt] = 0.0;                          // readable slack behind the last row
             GSYNC();
-            chol_blocked_lds<WG / 64>(Mm, [](int i, int j) { return (int)pk(i + 3, j + 3); }, n, n + 1, 0.0, s_blk, GATE_PAN_RS, s_cb);
+            chol_blocked_lds<WG / 64>(Mm, [](int i, int j) { return (int)pk(i + 3, j + 3); }, n, n + 1, 0.0, s_blk, PAN_RS, s_cb);
             int bad = 0;
             for (int i = gt; i < n; i += GS) { bad |= !(SG(i, i) > 0.0); sW[i] = SG(n, i); }
             pd_ok = !__syncthreads_or(bad);
