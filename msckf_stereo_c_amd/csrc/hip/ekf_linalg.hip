@@ -157,105 +157,42 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
 }
 
 // ------------------------------------------------------------------------------------ Cholesky
-#define CNB 16
-struct CholArgs { double *A; int n, n_extra, lda, semidef; };
-
-// in-place lower Cholesky of the leading n x n block; rows [n, n+n_extra) only take part in the panel solves
-__global__ __launch_bounds__(256) void k_ekf_chol(const EkfStreamDev *streams, int which) {
+// Fallback for active blocks that do not fit LDS (more than CHOL_LDS_MAX_ROWS rows: 50- and 60-clone windows): the same
+// blocked factorisation (chol_block.h) run in place on the row-major global matrix through a generic pointer — diagonal
+// block in registers, panel solve per row, trailing update on the matrix cores — with only the 16-wide panel in LDS.
+// A row is read up to 15 entries right of its diagonal as filler: those are the mirrored upper triangle and, for the
+// last rows, columns [n, n+16) of the ld-wide row (ld - n >= 21: the IMU columns are not part of the compact block).
+#define CHOLG_THREADS 512
+__global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *streams, int which, int pan_rs) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
-    CholArgs c;
-    const int na = S.rows_out[2];
-    if (which == 0) { c.A = S.S; c.n = na; c.n_extra = 1; c.lda = S.ld; c.semidef = 1; }   // G_c = [H_act|r]^T [H_act|r]
-    else { c.A = S.W; c.n = na; c.n_extra = 0; c.lda = S.ld; c.semidef = 0; }               // S = T[:, act] R^T + sigma^2 I
-    const int n = c.n, nt = c.n + c.n_extra, lda = c.lda;
-    double *A = c.A;
+    const int n = S.rows_out[2];                          // active columns
+    const int nt = n + (which == 0 ? 1 : 0);              // + the extra Q^T r row of the Gram factorisation
+    const int lda = S.ld;
+    double *A = which == 0 ? S.S : S.W;                   // G_c = [H_act|r]^T [H_act|r]  /  S = T[:, act] R^T + sigma^2 I
     extern __shared__ double s_dyn[];
-    double *sD = s_dyn;                  // [CNB][CNB+1]
-    double *sPanel = s_dyn + CNB * (CNB + 1);   // [nt][CNB]
-    __shared__ double s_tol;
+    double *sPanT = s_dyn;                                // [LNB][pan_rs]
+    __shared__ double s_tol, s_mx[CHOLG_THREADS / 64];
+    __shared__ CholBlockShared s_cb;
     const int tid = threadIdx.x;
-    if (c.semidef) {
+    for (int e = tid; e < LNB * pan_rs; e += CHOLG_THREADS) sPanT[e] = 0.0;
+    if (which == 0) {
         // regularised factorisation G + lambda I, lambda = 1e-14 d max(diag G) (see k_ekf_chol_lds)
         double mx = 0;
-        for (int i = tid; i < n; i += 256) mx = fmax(mx, A[(size_t)i * lda + i]);
+        for (int i = tid; i < n; i += CHOLG_THREADS) mx = fmax(mx, A[(size_t)i * lda + i]);
         for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
-        __shared__ double s_mx[4];
         if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
         __syncthreads();
-        if (tid == 0) s_tol = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3])) * (double)n * 1e-14;
+        if (tid == 0) { double m = 0; for (int i = 0; i < CHOLG_THREADS / 64; ++i) m = fmax(m, s_mx[i]); s_tol = m * (double)S.d * 1e-14; }
         __syncthreads();
         const double lam = s_tol;
-        for (int i = tid; i < n; i += 256) A[(size_t)i * lda + i] += lam;
-        __syncthreads();
+        for (int i = tid; i < n; i += CHOLG_THREADS) A[(size_t)i * lda + i] += lam;
     }
-    const double tol = 0.0;
-    for (int kb = 0; kb < n; kb += CNB) {
-        const int nb = min(CNB, n - kb);
-        // 1. diagonal block
-        __syncthreads();
-        for (int e = tid; e < CNB * CNB; e += 256) {
-            const int i = e / CNB, j = e % CNB;
-            sD[i * (CNB + 1) + j] = (i < nb && j <= i) ? A[(size_t)(kb + i) * lda + kb + j] : 0.0;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            for (int j = 0; j < nb; ++j) {
-                const double piv = sD[j * (CNB + 1) + j];
-                const bool skip = !(piv > tol);
-                const double l = skip ? 0.0 : sqrt(piv);
-                const double inv = skip ? 0.0 : 1.0 / l;
-                __builtin_amdgcn_wave_barrier();
-                if (tid >= j && tid < nb) sD[tid * (CNB + 1) + j] = (tid == j) ? l : sD[tid * (CNB + 1) + j] * inv;
-                __builtin_amdgcn_wave_barrier();
-                // trailing update inside the block: (i, c) with j < c <= i < nb
-                for (int e = tid; e < CNB * CNB; e += 64) {
-                    const int i = e / CNB, cc = e % CNB;
-                    if (cc > j && cc <= i && i < nb) sD[i * (CNB + 1) + cc] -= sD[i * (CNB + 1) + j] * sD[cc * (CNB + 1) + j];
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < CNB * CNB; e += 256) {
-            const int i = e / CNB, j = e % CNB;
-            if (i < nb && j <= i) A[(size_t)(kb + i) * lda + kb + j] = sD[i * (CNB + 1) + j];
-        }
-        // 2. panel below: x L11^T = a, one thread per row
-        const int r0 = kb + nb;
-        for (int i = r0 + tid; i < nt; i += 256) {
-            double x[CNB];
-#pragma unroll
-            for (int j = 0; j < CNB; ++j) {
-                double s = (j < nb) ? A[(size_t)i * lda + kb + j] : 0.0;
-#pragma unroll
-                for (int cc = 0; cc < j; ++cc) s -= x[cc] * sD[j * (CNB + 1) + cc];
-                const double ljj = sD[j * (CNB + 1) + j];
-                x[j] = (j < nb && ljj != 0.0) ? s / ljj : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < CNB; ++j) {
-                if (j < nb) A[(size_t)i * lda + kb + j] = x[j];
-                sPanel[(size_t)(i - r0) * CNB + j] = x[j];
-            }
-        }
-        __syncthreads();
-        // 3. trailing update A22 -= L21 L21^T (lower part; extra rows against all columns < n)
-        const int rem = nt - r0;
-        const int remc = n - r0;           // columns that still get factored
-        for (int e = tid; e < rem * remc; e += 256) {
-            const int a = e / remc, b = e - a * remc;
-            if (b > a) continue;
-            const double *pa = sPanel + (size_t)a * CNB, *pb = sPanel + (size_t)b * CNB;
-            double s = 0;
-#pragma unroll
-            for (int cc = 0; cc < CNB; ++cc) s += pa[cc] * pb[cc];
-            A[(size_t)(r0 + a) * lda + r0 + b] -= s;
-        }
-    }
+    __syncthreads();
+    chol_blocked_lds<CHOLG_THREADS / 64>(A, [lda](int i, int j) { return i * lda + j; }, n, nt, 0.0, sPanT, pan_rs, s_cb);
     if (which == 0) {
-        __syncthreads();
-        for (int k = tid; k < n; k += 256) S.T[(size_t)k * S.ld + S.d] = A[(size_t)n * lda + k];
+        // column d of T <- (Q^T r) = the extra row of L, so the TRSM carries w = L2^-1 Q^T r along
+        for (int k = tid; k < n; k += CHOLG_THREADS) S.T[(size_t)k * lda + S.d] = A[(size_t)n * lda + k];
     }
 }
 
@@ -459,8 +396,8 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
         hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(CHOL_THREADS), lds, st, d, which);
         return;
     }
-    const size_t lds = (size_t)(CNB * (CNB + 1) + (size_t)(max_d + 2) * CNB) * sizeof(double);
-    hipLaunchKernelGGL(k_ekf_chol, dim3(1, n), dim3(256), lds, st, d, which);
+    const int pan_rs = (nt + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_ekf_chol, dim3(1, n), dim3(CHOLG_THREADS), (size_t)LNB * pan_rs * sizeof(double), st, d, which, pan_rs);
 }
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
