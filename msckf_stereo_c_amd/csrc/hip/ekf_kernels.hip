@@ -665,8 +665,9 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         GSYNC();
         // two-sided reflectors in one pass: Q = Q_1 Q_2 Q_3 = I - V T V^T (compact WY, T 3x3 upper triangular), so
         //   Q^T Mm Q = Mm - Z V^T - V Z^T,   Z = W T - 1/2 V (T^T G T),   W = Mm V,   G = V^T W
-        // (Mm symmetric, lower stored).  The LDS case keeps W and Z in the dead H_f / coefficient scratch.
-        if (rows <= lds_rows) {
+        // (Mm symmetric, lower stored; in LDS or, for features with more rows than fit, in the stream's global scratch).
+        // W and Z (rows x 3 each) live in the dead H_f / coefficient scratch.
+        {
             double (*sWm)[3] = sHf;                 // rows x 3, H_f is dead after step 4
             double (*sZ)[3] = sCoef;                // rows x 3 (<= 4 MAXC), the coefficients are dead after step 5
             if (gt < rows) {
@@ -714,28 +715,6 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
                 double *mi = Mm + pk(i, 0);
                 for (int c = gt & 63; c <= i; c += 64)
                     mi[c] -= z0 * sV[0][c] + z1 * sV[1][c] + z2 * sV[2][c] + a0 * sZ[c][0] + a1 * sZ[c][1] + a2 * sZ[c][2];
-            }
-            GSYNC();
-        } else
-        for (int k = 0; k < 3; ++k) {
-            const double beta = sBeta[k];
-            if (beta == 0.0) continue;     // uniform
-            for (int i = gt; i < rows; i += GS) {
-                double t = 0;
-                const double *mi = Mm + pk(i, 0);
-                for (int c = 0; c <= i; ++c) t += mi[c] * sV[k][c];
-                for (int c = i + 1; c < rows; ++c) t += Mm[pk(c, i)] * sV[k][c];
-                sW[i] = t;
-            }
-            GSYNC();
-            double pa = 0;
-            for (int i = gt; i < rows; i += GS) pa += sV[k][i] * sW[i];
-            const double alpha = gsum(pa);
-            const double b2a = beta * beta * alpha;
-            for (int e = gt; e < rows * rows; e += GS) {
-                const int i = e / rows, c = e - i * rows;
-                if (c > i) continue;
-                Mm[pk(i, c)] += -beta * (sV[k][i] * sW[c] + sW[i] * sV[k][c]) + b2a * sV[k][i] * sV[k][c];
             }
             GSYNC();
         }
