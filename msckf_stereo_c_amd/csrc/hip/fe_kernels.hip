@@ -37,10 +37,25 @@ __global__ __launch_bounds__(256) void k_pyr_down(const PyrJob *jobs) {
     __shared__ uint16_t s_h[SH][PD_TW];
     const int tid = threadIdx.x;
     const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
-    for (int i = tid; i < SW * SH; i += 256) {
-        const int r = i / SW, c = i - r * SW;
-        const int sy = reflect101(sy0 + r, job.sh), sx = reflect101(sx0 + c, job.sw);
-        s_src[r][c] = job.src[(size_t)sy * job.sw + sx];
+    if (sx0 >= 0 && sy0 >= 0 && sx0 + SW <= job.sw && sy0 + SH <= job.sh) {
+        // interior tile: whole (unaligned) dwords, 33 per row
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        constexpr int DW = SW / 4;
+        const uint8_t *base = job.src + (size_t)sy0 * job.sw + sx0;
+        for (int i = tid; i < DW * SH; i += 256) {
+            const int r = i / DW, c = i - r * DW;
+            *reinterpret_cast<uint32_t *>(&s_src[r][4 * c]) = *reinterpret_cast<const u32u *>(base + (size_t)r * job.sw + 4 * c);
+        }
+    } else {
+        // border tile: reflect-101 indices once per row / column, then bytes
+        __shared__ int s_ix[SW], s_iy[SH];
+        if (tid < SW) s_ix[tid] = reflect101(sx0 + tid, job.sw);
+        else if (tid - SW < SH) s_iy[tid - SW] = reflect101(sy0 + tid - SW, job.sh);
+        __syncthreads();
+        for (int i = tid; i < SW * SH; i += 256) {
+            const int r = i / SW, c = i - r * SW;
+            s_src[r][c] = job.src[(size_t)s_iy[r] * job.sw + s_ix[c]];
+        }
     }
     __syncthreads();
     for (int i = tid; i < SH * PD_TW; i += 256) {
