@@ -166,9 +166,11 @@ def main():
     if args.host_images:
         h_frames = torch.from_numpy(frames).pin_memory()
         base, on_device = h_frames.data_ptr(), 0
+        del frames
     else:
         d_frames = torch.from_numpy(frames).cuda(local_rank)  # resident in HBM before the timed region
         base, on_device = d_frames.data_ptr(), 2              # borrowed in place
+        del frames                                            # the host copy (GBs per rank) is not needed any more
     calib = syns[0].calib
     run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads)
     run.keep_trajectory(False)
