@@ -2,22 +2,25 @@
 """bench.py — throughput of the MI355X hot path (stereo KLT front-end + MSCKF update) on synthetic
 EuRoC-shaped streams.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
-One process per GPU (for N > 1 launched by torch.distributed.run, one rank per GPU, RCCL only for the
-barrier and the max/sum aggregation: the streams are independent units, no data-path collective).
-A "step" is one stereo frame of EVERY stream of the batch: full front-end (pyramids, detector, temporal
-LK, stereo LK, gates) + back-end (IMU propagation, augmentation, triangulation, Jacobians, gating, QR,
-Kalman update, clone pruning).  Inputs (rendered stereo pairs) are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0.
+One process per GPU.  With --gpus N > 1 and no WORLD_SIZE in the environment this process only SPAWNS the N ranks
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous) before importing torch or touching HIP, relays
+rank 0's JSON line and exits non-zero if any rank fails; under torch.distributed.run the ranks are already there.
+RCCL is used only for the barrier and the scalar reductions {time MAX, frames SUM, sentinel-hash gather}: the streams
+are independent units (stream s -> rank s mod N), no data-path collective.
+A "step" is one stereo frame of EVERY stream of the batch: full front-end (pyramids, detector, temporal LK, stereo
+LK, gates) + back-end (IMU propagation, augmentation, triangulation, Jacobians, gating, QR, Kalman update, clone
+pruning).  Inputs (rendered stereo pairs) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,42 +32,107 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LK_BYTES_PER_TRACK = 4 * (17 * 17 + 16 * 16)      # 4 levels x (17x17 template + 16x16 search footprint) u8
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6                           # FP64 matrix peak
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+
+# BASELINE.json configs: image, clone window, grid rows x cols x min x max, streams per GPU, groups
+CONFIGS = {
+    "c2": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=768, groups=8, loop=100, cpu_frames=150, cpu_all_frames=80,
+               name="configs[1] Single MI355X: 752x480 stereo, 30 cam clones, 400 features/frame, 200 Hz IMU"),
+    "c3": dict(width=1280, height=720, clones=50, grid="10x20x4x5", streams=128, groups=8, loop=60, cpu_frames=60, cpu_all_frames=30,
+               name="configs[2] Single MI355X stress: 1280x720 stereo, 50 cam clones, 1000 features/frame"),
+    "c4": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=8, groups=1, loop=100, cpu_frames=150, cpu_all_frames=80,
+               name="configs[3] 8xMI355X: 64 EuRoC-shaped streams sharded 8/GPU"),
+    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=8, groups=8, loop=30, cpu_frames=16, cpu_all_frames=6,
+               name="configs[4] 4K stereo streams, 2000 features/frame, 60 cam clones"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MSKF_BENCH_STREAMS", "768")), help="VIO streams per GPU")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("MSKF_BENCH_GROUPS", "8")), help="host thread groups per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (c2 = the metric's own)")
+    ap.add_argument("--streams", type=int, default=None, help="VIO streams per GPU")
+    ap.add_argument("--groups", type=int, default=None, help="host thread groups per GPU")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("MSKF_BENCH_HOST_THREADS", "1")), help="host threads per group")
     ap.add_argument("--no-pipeline", action="store_true", help="run front-end and filter of a group in lockstep on one thread")
-    ap.add_argument("--unique", type=int, default=0, help="distinct rendered sequences per GPU (streams cycle over them); "
-                    "0 = one per stream of a group, so that no two streams of a launch read the same image (no L2 sharing)")
-    ap.add_argument("--width", type=int, default=752)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--clones", type=int, default=30)
-    ap.add_argument("--grid", type=str, default="8x10x4x5", help="rows x cols x min x max features per cell")
-    ap.add_argument("--prime", type=int, default=75, help="untimed frames before warmup: gravity init + clone window fill")
-    ap.add_argument("--loop", type=int, default=100, help="frames per trajectory period")
-    ap.add_argument("--cpu-frames", type=int, default=250, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct rendered sequences per GPU (streams of a group cycle over them); "
+                    "0 = one per stream of a group, so that no two streams of a launch read the same image")
+    ap.add_argument("--stagger", type=int, default=-1, help="group g runs g*STAGGER frames ahead, so that the groups replaying the same "
+                    "sequences never read the same stereo pair at the same time (-1 = auto: loop // groups + 1, 0 = off)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--clones", type=int, default=None)
+    ap.add_argument("--grid", type=str, default=None, help="rows x cols x min x max features per cell")
+    ap.add_argument("--prime", type=int, default=None, help="untimed frames before warmup: gravity init + clone window fill")
+    ap.add_argument("--loop", type=int, default=None, help="frames per trajectory period")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the 1-core CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-all-frames", type=int, default=None, help="frames per stream of the all-cores CPU-oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("MSKF_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
-    return ap.parse_args()
+    ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reductions, "
+                    "JSON line) without any device work: for the gloo tests only, the line it prints says so")
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    for k in ("width", "height", "clones", "grid", "streams", "groups", "loop", "cpu_frames", "cpu_all_frames"):
+        if getattr(args, k) is None:
+            setattr(args, k, preset[k] if k not in ("streams", "groups") else int(os.environ.get("MSKF_BENCH_" + k.upper(), preset[k])))
+    if args.prime is None:
+        args.prime = 25 + 20 + args.clones      # static start, gravity/bias initialisation, clone window full
+    return args
 
 
+# ------------------------------------------------------------------------------------------ rank launcher
+def launch_ranks(args, argv):
+    """Spawn one rank per GPU (no torch / HIP in this process), relay rank 0's line, fail if any rank fails."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:          # a rank died: the others would wait in the next collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with status %d\n" % rc)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ workload
 def make_cfgs(args):
     from msckf_stereo_c_amd.ctypes_types import default_ekf_cfg, default_fe_cfg
     r, c, mn, mx = (int(x) for x in args.grid.split("x"))
     return default_fe_cfg(grid_row=r, grid_col=c, grid_min=mn, grid_max=mx), default_ekf_cfg(max_cam_state_size=args.clones)
 
 
-def render_sequences(oracle_py, args, rank, n_keys):
+def sequence_seed(rank, world, u):
+    """Seed of the u-th sequence of a rank.  Sequence 0 is the SENTINEL: the same seed on every rank, so that stream 0
+    of every GPU computes the same thing and the cross-rank hash comparison means something; the others follow the
+    sharding stream s -> rank s mod world: local sequence u is global stream u * world + rank."""
+    return 0x5EED0000 if u == 0 else 0x5EED0000 + u * world + rank
+
+
+def render_sequences(oracle_py, args, rank, world, n_keys):
     """Pre-render `unique` looping stereo sequences on the host (threads; the generator releases the GIL)."""
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
-    syns = [oracle_py.Synth(seed=0x5EED0000 + 64 * rank + u, width=args.width, height=args.height, n_static=25, n_loop=args.loop)
+    syns = [oracle_py.Synth(seed=sequence_seed(rank, world, u), width=args.width, height=args.height, n_static=25, n_loop=args.loop)
             for u in range(args.unique)]
     frames = np.empty((args.unique, 2, n_keys, args.height, args.width), np.uint8)
 
@@ -74,12 +142,13 @@ def render_sequences(oracle_py, args, rank, n_keys):
         frames[u, 0, k] = a
         frames[u, 1, k] = b
         syns[u]._cache.clear()
-    with ThreadPoolExecutor(max_workers=min(14, os.cpu_count() or 8)) as ex:
+    with ThreadPoolExecutor(max_workers=max(1, min(14, int(host_cores_available())))) as ex:
         list(ex.map(job, [(u, k) for u in range(args.unique) for k in range(n_keys)]))
     return syns, frames
 
 
 def imu_array(syn, n):
+    import numpy as np
     from msckf_stereo_c_amd.runner import IMU_SAMPLE
     out = np.zeros(n, IMU_SAMPLE)
     for j in range(n):
@@ -88,14 +157,82 @@ def imu_array(syn, n):
     return out
 
 
-def cpu_baseline(oracle_py, syn, fe, ekf, prime, frames):
-    """The CPU oracle (a port: the reference itself cannot be built here) on ONE stream, one core."""
-    osys = oracle_py.OracleSystem(syn.calib, fe, ekf)
-    syn.feed(osys, prime)
+def state_hash(ids, life, c0, c1, imu_state):
+    """64-bit hash of what a stream has computed: live feature ids, lifetimes, cam0/cam1 pixels, the IMU state."""
+    h = hashlib.blake2b(digest_size=8)
+    for a in (ids, life, c0, c1, imu_state):
+        h.update(memoryview(a).cast("B") if hasattr(a, "dtype") else bytes(a))
+    return int.from_bytes(h.digest(), "little", signed=True)
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, len(phys) or None, os.cpu_count()
+
+
+def cpu_baseline(oracle_py, args, fe, ekf, total_gpu_frames, gpu_dump):
+    """The CPU oracle (kind "port": the reference itself cannot be built here) timed on this box's host
+    cores, compiled like the reference (-O3, one thread per stream, headless).  Leg (i): one stream on one core (the
+    reference's execution model).  Leg (ii): one stream per usable core, all at once.  Frames are rendered before the
+    clock starts.  Leg (i) replays the sentinel sequence, so its feature ids at the frame the GPU stopped at are
+    compared with stream 0 of the GPU run (id check inside the bench; the parity tests proper are tests/ -m gpu)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    usable = max(1, int(host_cores_available()))
+    model, phys, logical = cpu_info()
+    n_all = usable if args.cpu_all_frames > 0 else 1
+    span = args.prime + max(args.cpu_frames, args.cpu_all_frames)
+    check_at = total_gpu_frames if (gpu_dump is not None and args.prime < total_gpu_frames <= args.prime + args.cpu_frames) else None
+    syns = [oracle_py.Synth(seed=sequence_seed(0, 1, u), width=args.width, height=args.height, n_static=25, n_loop=args.loop) for u in range(n_all)]
+    with ThreadPoolExecutor(max_workers=usable) as ex:     # render outside the clock
+        list(ex.map(lambda uk: syns[uk[0]].render(uk[1]), [(u, k) for u in range(n_all) for k in range(min(span, 25 + args.loop))]))
+    # ---- (i) one stream, one core
+    osys = oracle_py.OracleSystem(syns[0].calib, fe, ekf)
+    syns[0].feed(osys, args.prime)
+    id_check = None
     t0 = time.perf_counter()
-    syn.feed(osys, frames, start=prime)
-    dt = time.perf_counter() - t0
-    return frames / dt, dt
+    if check_at is not None:
+        syns[0].feed(osys, check_at - args.prime, start=args.prime)
+        o_ids, o_life, o_c0, o_c1, _ = osys.dump()
+        g_ids, g_life, g_c0, g_c1 = gpu_dump
+        id_check = {"frame": check_at, "features": int(len(o_ids)),
+                    "ids_equal": bool(np.array_equal(o_ids, g_ids)), "lifetimes_equal": bool(np.array_equal(o_life, g_life)),
+                    "pixels_equal": bool(np.array_equal(o_c0, g_c0) and np.array_equal(o_c1, g_c1))}
+        syns[0].feed(osys, args.prime + args.cpu_frames - check_at, start=check_at)
+    else:
+        syns[0].feed(osys, args.cpu_frames, start=args.prime)
+    dt1 = time.perf_counter() - t0
+    out = {"value": args.cpu_frames / dt1, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of one %dx%d stream (grid %s, %d clones) after %d priming frames, CPU oracle (-O3, 1 thread), %.1f s"
+                     % (args.cpu_frames, args.width, args.height, args.grid, args.clones, args.prime, dt1),
+           "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "usable_cores": usable}
+    # ---- (ii) one stream per usable core
+    if args.cpu_all_frames > 0 and usable > 1:
+        systems = [oracle_py.OracleSystem(s.calib, fe, ekf) for s in syns]
+        with ThreadPoolExecutor(max_workers=usable) as ex:
+            list(ex.map(lambda i: syns[i].feed(systems[i], args.prime), range(n_all)))
+            t0 = time.perf_counter()
+            list(ex.map(lambda i: syns[i].feed(systems[i], args.cpu_all_frames, start=args.prime), range(n_all)))
+            dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": n_all * args.cpu_all_frames / dt, "unit": "stereo frames/s", "cores": n_all,
+                            "sample": "%d streams x %d frames at once, one oracle thread per usable core, %.1f s" % (n_all, args.cpu_all_frames, dt)}
+    return out, id_check
 
 
 def cgroup_cpu():
@@ -122,17 +259,64 @@ def host_cores_available():
     return min(quota, aff) if quota else aff
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------ one rank
+def gather_hashes(h, world, device):
+    import torch
+    import torch.distributed as dist
+    if world <= 1 or not dist.is_initialized():
+        return [h]
+    t = torch.tensor([h], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]
+
+
+def rehearse(args, rank, world):
+    """Multi-rank plumbing without device work (CPU tests): rendezvous, barrier, the three reductions, one JSON line."""
+    import torch.distributed as dist
+    from msckf_stereo_c_amd.dist_util import aggregate_throughput, shard_streams
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    mine = shard_streams(args.streams * world, world, rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    elapsed, frames = aggregate_throughput(time.perf_counter() - t0, len(mine) * args.steps, world, device="cpu")
+    hashes = gather_hashes(0x5EED if os.environ.get("MSKF_REHEARSE_CORRUPT_RANK") != str(rank) else 0xBAD, world, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal of the rank plumbing (no device work, not a measurement)", "rehearsal": True,
+                          "value": frames / elapsed, "unit": "stub frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed * 1e3 / args.steps, "streams_total": int(frames / args.steps),
+                          "id_mismatch": sum(1 for h in hashes if h != hashes[0])}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)                    # nothing above has imported torch or touched HIP
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let bench.py spawn them)\n" % (args.gpus, world))
+        return 2
+    if args.rehearse:
+        return rehearse(args, rank, world)
     # Every group runs a front-end and a filter thread that wait for the GPU between phases.  Spinning in those waits is the
     # lower-latency choice while each thread has a core to itself; when the ranks of this node together run more such
     # threads than there are cores (a shared quota), parked waits leave the cores to the threads that have host work.
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     if "MSKF_WAIT" not in os.environ and 2 * args.groups * args.host_threads * local_world > host_cores_available():
         os.environ["MSKF_WAIT"] = "block"
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -155,12 +339,16 @@ def main():
     n_groups = max(1, args.streams // per_group)
     n_streams = n_groups * per_group
     n_keys = 25 + args.loop
-    total_frames = args.prime + args.warmup + args.steps
+    if args.stagger < 0:
+        args.stagger = (args.loop // n_groups + 1) if n_groups > 1 else 0
     if args.unique <= 0:
         args.unique = min(per_group, 128)
+    shared_in_group = args.unique < per_group
+    max_offset = args.stagger * (n_groups - 1) if args.unique < n_streams else 0
+    total_frames = args.prime + args.warmup + args.steps
 
     t_r0 = time.perf_counter()
-    syns, frames = render_sequences(oracle_py, args, rank, n_keys)
+    syns, frames = render_sequences(oracle_py, args, rank, world, n_keys)
     render_s = time.perf_counter() - t_r0
     frame_bytes = args.width * args.height
     if args.host_images:
@@ -174,7 +362,9 @@ def main():
     calib = syns[0].calib
     run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads)
     run.keep_trajectory(False)
-    imus = [imu_array(s, (total_frames + 3) * 10 + 20) for s in syns]
+    if max_offset:
+        run.set_stagger(args.stagger)
+    imus = [imu_array(s, (total_frames + max_offset + 3) * 10 + 20) for s in syns]
     for s in range(n_streams):
         u = s % args.unique
         cam0 = base + (u * 2 + 0) * n_keys * frame_bytes
@@ -189,7 +379,7 @@ def main():
             dist.barrier()
 
     pipe = not args.no_pipeline
-    run.run(0, args.prime, pipelined=pipe)                       # untimed: gravity/bias init, clone window fills, steady state
+    run.run(0, args.prime, pipelined=pipe)                       # untimed: gravity/bias init, clone window fills, group offsets
     run.run(args.prime, args.warmup, pipelined=pipe)             # W untimed warmup steps
     run.set_timing(not os.environ.get("MSKF_BENCH_NO_KERNEL_TIMING"))
     run.get_timing(reset=True)
@@ -210,8 +400,14 @@ def main():
     from msckf_stereo_c_amd.dist_util import aggregate_throughput
     elapsed, frames_total = aggregate_throughput(elapsed, n_streams * args.steps, world, device=red_dev)
 
+    # what stream 0 (the sentinel sequence, group 0: no offset) has computed; identical on every rank by construction
+    s_ids, s_life, s_c0, s_c1, _ = run.dump(0)
+    hashes = gather_hashes(state_hash(s_ids, s_life, s_c0, s_c1, run.imu_state(0)), world, red_dev)
+    id_mismatch = sum(1 for h in hashes if h != hashes[0])
+
     # sanity of the workload actually processed (steady state reached, filter alive)
-    n_feat = len(run.dump(0)[0])
+    feats = [len(run.dump(s)[0]) for s in range(0, n_streams, max(1, n_streams // 16))]
+    n_feat = int(round(sum(feats) / len(feats)))
     n_clones = run.num_clones(0)
     n_upd = run.num_updates(0)
 
@@ -221,54 +417,66 @@ def main():
         dom = max(timing, key=lambda k: timing[k][0])
         ms, launches, units = timing[dom]
         avg_s = max(ms * 1e-3 / max(launches, 1), 1e-12)
-        if dom in ("k_ekf_feature_blocks", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm"):
+        if dom in ("k_ekf_feature_blocks", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_qr"):
             achieved = units / max(launches, 1) / avg_s / 1e12           # units = algorithmic FP64 flops
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
         else:
-            per_unit = {"k_lk_points": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
+            per_unit = {"k_lk_points": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1, "k_pyr_detect": 2.25}.get(dom, 0)
             achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
         # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
-        # separately, profiles/r01_pmc_hbm_traffic.json); only comparable when a launch covers the same number of streams
+        # separately); only comparable when a launch covers the same number of streams
         try:
-            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            pmc_all = json.load(open(PMC_TRAFFIC_FILE))
             pmc = pmc_all["kernels"].get(dom)
-            if pmc and per_group == pmc_all.get("streams_per_launch", 64):
+            if pmc and per_group == pmc_all.get("streams_per_launch", 64) and args.config == pmc_all.get("config", "c2"):
                 roof["traffic"] = (pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
-                roof["traffic_note"] = "bytes/launch, raw FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (no gfx950 correction applied)"
+                roof["traffic_note"] = "bytes/launch, raw FETCH_SIZE+WRITE_SIZE of %s (no gfx950 correction applied)" % os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
         except Exception:
             pass
         roof["avg_launch_us"] = avg_s * 1e6
         roof["units_per_launch"] = units / max(launches, 1)
-        kernels = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)} for k, v in timing.items()}
+        kernels = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)} for k, v in timing.items() if v[1]}
+        # FP64 matrix-core rate of the dense update kernels alone (the meaningful MFMA number is per kernel)
+        gm = timing.get("k_ekf_gemm", (0, 0, 0))
+        mfma = {"kernel": "k_ekf_gemm", "tflops": (gm[2] / (gm[0] * 1e-3) / 1e12) if gm[0] > 0 else None, "peak": FP64_PEAK_TFLOPS}
+        if mfma["tflops"] is not None:
+            mfma["frac"] = mfma["tflops"] / FP64_PEAK_TFLOPS
+        seq_note = ("%d distinct looping sequences per GPU, one per stream of a group" % args.unique
+                    + ("" if not max_offset else "; the %d groups replay them %d frames apart (never the same stereo pair at the same time)"
+                       % (n_groups, args.stagger))
+                    + ("; SHARED inside a launch" if shared_in_group else ""))
         out = {
             "metric": "stereo frames/sec/node on EuRoC-shape input", "value": value, "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (host-resident images, PCIe-inclusive)" if args.host_images else ""),
-            "config": {"workload": "Single MI355X: %dx%d stereo, %d cam clones, grid %s (%d features/frame), 200 Hz IMU; "
-                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads%s)"
-                                   % (args.width, args.height, args.clones, args.grid, n_feat, n_streams, n_groups, args.host_threads,
-                                      ", FE|EKF pipelined" if pipe else ""),
+            "config": {"workload": "%s [%s]: %dx%d stereo, %d cam clones, grid %s (%d features/frame realised), 200 Hz IMU; "
+                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads%s); %s"
+                                   % (CONFIGS[args.config]["name"], args.config, args.width, args.height, args.clones, args.grid, n_feat, n_streams,
+                                      n_groups, args.host_threads, ", FE|EKF pipelined" if pipe else "", seq_note),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
                        "ekf_updates_stream0": n_upd, "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1),
+                       "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
-            "roofline": roof, "kernels": kernels,
+            "id_mismatch": id_mismatch,
+            "roofline": roof, "mfma": mfma, "kernels": kernels,
             "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
             "host_phases_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in phases.items()},
         }
         if not args.no_cpu and world == 1 and args.cpu_frames > 0:
-            fps, dt = cpu_baseline(oracle_py, syns[0], fe, ekf, args.prime, args.cpu_frames)
-            out["cpu_baseline"] = {"value": fps, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frames of one %dx%d stream after %d priming frames, CPU oracle (-O3, 1 thread), %.1f s"
-                                             % (args.cpu_frames, args.width, args.height, args.prime, dt)}
-        print(json.dumps(out))
+            for s in syns:
+                s._cache.clear()
+            del syns
+            out["cpu_baseline"], out["id_check_vs_oracle"] = cpu_baseline(oracle_py, args, fe, ekf, total_frames, (s_ids, s_life, s_c0, s_c1))
+        print(json.dumps(out), flush=True)
     run.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -87,7 +87,8 @@ int mskf_fe_push_stereo(mskf_stream *s, const uint8_t *cam0, const uint8_t *cam1
 int mskf_fe_push_stereo_device(mskf_stream *s, const uint8_t *d_cam0, const uint8_t *d_cam1, int width, int height,
                                double time_stamp);
 /* on_device: 0 = host images (copied in), 1 = device images (copied D2D), 2 = device images BORROWED: read in
- * place, the caller keeps each pair valid and unchanged until the second-next push of that stream. */
+ * place, the caller keeps each pair valid and unchanged until the second-next push of that stream.
+ * (3 is internal to mskf_fe_push_stereo: level 0 already copied into the stream's own planes.) */
 int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
                               const uint8_t *const *cam1, int on_device);
 

@@ -253,7 +253,11 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         if (!s || s->ctx != ctx || !cam0[i] || !cam1[i]) return MSKF_ERR_INVALID;
-        if (on_device == 2) {
+        if (on_device == 3) {
+            // level 0 already sits in the stream's own planes (mskf_fe_push_stereo with padded rows)
+            if (cam0[i] != s->pyr[s->i_curr0] || cam1[i] != s->pyr[s->i_curr1]) return MSKF_ERR_INVALID;
+            s->lvl0[s->i_curr0] = nullptr; s->lvl0[s->i_curr1] = nullptr;
+        } else if (on_device == 2) {
             // borrowed device images: level 0 is read in place (caller keeps them valid and unchanged until the
             // second-next push of this stream: the previous frame's cam0 is the LK template of the next frame)
             s->lvl0[s->i_curr0] = cam0[i];
@@ -314,19 +318,14 @@ extern "C" int mskf_fe_push_stereo(mskf_stream *s, const uint8_t *cam0, const ui
     if (width != s->w || height != s->h || pitch < width) { mskf_set_error("image size differs from the calibration"); return MSKF_ERR_INVALID; }
     s->time_stamp = time_stamp;
     if (pitch != width) {
-        // repack rows on the way in (2D copy), then run the batch path on the device-resident planes
+        // padded rows: 2D copies straight into the stream's own level-0 planes (dense, pitch = width), then the batch
+        // path with "level 0 already resident" (on_device = 3): no temporary allocation, nothing to free or leak
         MSKF_HIPCHK(hipSetDevice(s->ctx->device));
-        uint8_t *tmp0 = nullptr, *tmp1 = nullptr;
-        MSKF_HIPCHK(hipMalloc((void **)&tmp0, (size_t)width * height));
-        MSKF_HIPCHK(hipMalloc((void **)&tmp1, (size_t)width * height));
-        MSKF_HIPCHK(hipMemcpy2DAsync(tmp0, width, cam0, pitch, width, height, hipMemcpyHostToDevice, s->ctx->stream));
-        MSKF_HIPCHK(hipMemcpy2DAsync(tmp1, width, cam1, pitch, width, height, hipMemcpyHostToDevice, s->ctx->stream));
-        const uint8_t *a[1] = {tmp0}, *b[1] = {tmp1};
+        MSKF_HIPCHK(hipMemcpy2DAsync(s->pyr[s->i_curr0], width, cam0, pitch, width, height, hipMemcpyHostToDevice, s->ctx->stream));
+        MSKF_HIPCHK(hipMemcpy2DAsync(s->pyr[s->i_curr1], width, cam1, pitch, width, height, hipMemcpyHostToDevice, s->ctx->stream));
+        const uint8_t *a[1] = {s->pyr[s->i_curr0]}, *b[1] = {s->pyr[s->i_curr1]};
         mskf_stream *ss[1] = {s};
-        int rc = mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 1);
-        (void)hipStreamSynchronize(s->ctx->stream);
-        (void)hipFree(tmp0); (void)hipFree(tmp1);
-        return rc;
+        return mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 3);
     }
     const uint8_t *a[1] = {cam0}, *b[1] = {cam1};
     mskf_stream *ss[1] = {s};

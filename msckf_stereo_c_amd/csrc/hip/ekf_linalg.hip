@@ -401,9 +401,12 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
 }
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
-    const size_t lds = (size_t)(TS_RB * (max_d + 1) + (size_t)max_d * TS_COLS) * sizeof(double);
+    // the solve runs over the active rows only: n <= max_d - 21 (the IMU columns are never active).  A full 64-clone
+    // window (d = 405, n <= 384) needs 144 KiB; the limit is raised to the whole 160 KiB of a gfx950 CU.
+    const int max_n = max_d > EKF_IMU_DIM ? max_d - EKF_IMU_DIM : 1;
+    const size_t lds = (size_t)(TS_RB * (max_n + 1) + (size_t)max_n * TS_COLS) * sizeof(double);
     static std::once_flag attr_once;
-    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(k_ekf_trsm, dim3(strips, n), dim3(256), lds, st, d);
 }
 }

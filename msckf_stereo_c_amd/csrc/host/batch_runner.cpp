@@ -1,5 +1,6 @@
 // batch_runner.cpp — see batch_runner.h.
 #include "batch_runner.h"
+#include <algorithm>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
@@ -291,7 +292,7 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
 
 MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
                          int host_threads)
-    : n_groups_(n_groups), per_group_(per_group) {
+    : n_groups_(n_groups), per_group_(per_group), off_(n_groups, 0), next_(n_groups, 0) {
     for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads));
 }
 
@@ -315,7 +316,13 @@ int MultiRunner::step(const uint8_t *const *cam0, const uint8_t *const *cam1, in
 
 int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
     std::vector<int> rcs(n_groups_, MSKF_OK);
-    auto one = [&](int g) { return pipelined ? groups_[g]->run_pipelined(first, n) : groups_[g]->run(first, n); };
+    auto one = [&](int g) {
+        // frames [first + off, first + off + n) of the group, after catching up from where it stands
+        const int from = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
+        const int cnt = first + off_[g] + n - from;
+        next_[g] = from + cnt;
+        return pipelined ? groups_[g]->run_pipelined(from, cnt) : groups_[g]->run(from, cnt);
+    };
     if (!threaded || n_groups_ == 1) {
         for (int g = 0; g < n_groups_; ++g) { rcs[g] = one(g); if (rcs[g] != MSKF_OK) return rcs[g]; }
         return MSKF_OK;

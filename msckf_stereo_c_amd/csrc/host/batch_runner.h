@@ -106,11 +106,17 @@ class MultiRunner {
     void imu(int stream, const mskf_imu_sample &s) { int l; BatchGroup &g = group_of(stream, l); g.imu(l, s); }
     int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t);
     int run(int first, int n, bool threaded, bool pipelined = false);
+    // group g works `g * delta` frames ahead of the frame index passed to run(): replicas of one looping sequence in
+    // different groups then never read the same stereo pair at the same time (no cache sharing across groups).  The
+    // first run() after the call lets every group catch up through its own offset.
+    void set_stagger(int delta) { for (int g = 0; g < n_groups_; ++g) off_[g] = g * delta; }
+    int group_offset(int g) const { return off_[g]; }
     std::string error() const;
 
   private:
     int n_groups_, per_group_;
     std::vector<std::unique_ptr<BatchGroup>> groups_;
+    std::vector<int> off_, next_;   // per group: frame offset, next frame not yet processed
 };
 
 }  // namespace cg

@@ -49,6 +49,8 @@ void mskfh_runner_set_sequence(void *h, int stream, const uint8_t *cam0_base, co
 }
 // threaded: one host thread per group; pipelined: front-end and filter of each group run as a two-stage pipeline
 int mskfh_runner_run(void *h, int first, int n, int threaded, int pipelined) { return ((MultiRunner *)h)->run(first, n, threaded != 0, pipelined != 0); }
+void mskfh_runner_set_stagger(void *h, int delta) { ((MultiRunner *)h)->set_stagger(delta); }
+int mskfh_runner_group_offset(void *h, int g) { return ((MultiRunner *)h)->group_offset(g); }
 void mskfh_runner_keep_trajectory(void *h, int keep) {
     MultiRunner *r = (MultiRunner *)h;
     for (int i = 0; i < r->n_streams(); ++i) r->system(i).msckfvio_ptr()->keepTrajectory = keep != 0;

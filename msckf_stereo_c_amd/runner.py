@@ -34,6 +34,9 @@ def lib():
                                                 C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
         L.mskfh_runner_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mskfh_runner_keep_trajectory.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_set_stagger.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_group_offset.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_group_offset.restype = C.c_int
         for name in ("mskfh_num_features", "mskfh_msg_size", "mskfh_num_poses", "mskfh_state_dim", "mskfh_num_updates",
                      "mskfh_num_clones"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
@@ -108,6 +111,13 @@ class Runner:
         """Frames [first, first+n) of the attached sequences.  pipelined: front-end and filter of every group run
         as a two-stage pipeline on two HIP streams (identical results: the front-end never reads filter state)."""
         self._chk(self.L.mskfh_runner_run(self.h, first, n, int(threaded), int(pipelined)))
+
+    def set_stagger(self, delta):
+        """Group g works g * delta frames ahead of the index passed to run() (MultiRunner::set_stagger)."""
+        self.L.mskfh_runner_set_stagger(self.h, int(delta))
+
+    def group_offset(self, g):
+        return self.L.mskfh_runner_group_offset(self.h, g)
 
     def keep_trajectory(self, keep):
         self.L.mskfh_runner_keep_trajectory(self.h, int(keep))

@@ -265,9 +265,10 @@ def test_ekf_update_ill_conditioned(gpu_ctx, oracle, n_clones, n_feat):
     s.close()
 
 
-@pytest.mark.parametrize("n_clones,n_feat,seed", [(50, 40, 21), (60, 30, 22)])
+@pytest.mark.parametrize("n_clones,n_feat,seed", [(50, 40, 21), (60, 30, 22), (64, 30, 23)])
 def test_ekf_update_many_clones(gpu_ctx, oracle, n_clones, n_feat, seed):
-    """d = 321 / 381: global-memory Cholesky fallback, gating matrix outside LDS, > 1500 stacked rows (cap)."""
+    """d = 321 / 381 / 405 (the largest window mskf_stream_create accepts): global-memory Cholesky fallback, gating
+    matrix outside LDS, > 1500 stacked rows (cap), the triangular solve's strip at its LDS limit."""
     s, calib = _stream(gpu_ctx, oracle, 376, 240, max_cam_state_size=n_clones)
     cfg = default_ekf_cfg(max_cam_state_size=n_clones)
     pr = ekf_problems.make_problem(calib, seed=seed, n_clones=n_clones, n_feat=n_feat, min_obs=20)

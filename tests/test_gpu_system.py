@@ -396,16 +396,76 @@ def test_first_updates_identical_across_busy_groups(oracle):
         run.close()
 
 
-def test_c3_full_window_fallback_paths(oracle):
-    """C3 of SURVEY §8 end to end: 1280x720, 10x20 grid and a 50-clone window (d = 321) that fills and prunes, so the
-    gate matrices (up to 200 rows) and the 300-column factorisations run on the global-memory fallback paths inside a
-    real sequence.  Poses against the oracle at the usual bar."""
+def test_c3_full_size(oracle):
+    """BASELINE configs[2] (C3 of SURVEY §8) at full size, everything together: 1280x720, the 10x20x(4..5) grid
+    (~900-1000 features per frame) AND a 50-clone window (d = 321) that fills and prunes, so the gate matrices (up to
+    200 rows) and the 300-column factorisations run on the global-memory paths inside a real sequence.  Ids and pixels
+    bit-exact, poses against the oracle at the usual bar."""
     syn = oracle.Synth(seed=0x5EED0C33, width=1280, height=720)
-    fe = default_fe_cfg(grid_row=10, grid_col=20, grid_min=3, grid_max=4)
+    fe = default_fe_cfg(grid_row=10, grid_col=20, grid_min=4, grid_max=5)
     ekf = default_ekf_cfg(max_cam_state_size=50)
-    osys, run = _lockstep(oracle, syn, fe, ekf, 86, check_every=10)
-    assert run.num_clones() >= 48
+    osys, run = _lockstep(oracle, syn, fe, ekf, 86, check_every=5)
+    assert run.num_clones() >= 48 and len(run.dump()[0]) > 800
     assert osys.num_updates() == run.num_updates() > 20
     compare_msgs(osys, run)
     compare_poses(osys, run)
+    run.close()
+
+
+def test_c5_4k_60_clones(oracle):
+    """BASELINE configs[4] (C5 of SURVEY §8) shape: 3840x2160 stereo, 20x25x(4..5) grid (~1700-2000 features per frame),
+    max_cam_state_size = 60 (d = 381).  92 frames in lockstep with the oracle: the window fills to 60 clones and prunes,
+    lost-feature updates hit the 1500-row cap.  Feature ids, lifetimes and pixels bit-exact in every frame, poses at
+    1e-4 m / 1e-4 rad.  The frames are rendered ahead by a thread pool (the generator is the slow part at 4K)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_frames = 92
+    syn = oracle.Synth(seed=0x5EED00C5, width=3840, height=2160)
+    fe = default_fe_cfg(grid_row=20, grid_col=25, grid_min=4, grid_max=5)
+    ekf = default_ekf_cfg(max_cam_state_size=60)
+    import os
+    workers = max(2, min(14, len(os.sched_getaffinity(0))))
+    twins = [oracle.Synth(seed=0x5EED00C5, width=3840, height=2160) for _ in range(workers)]     # one generator per thread
+    rendered = {}
+
+    def job(k):
+        t = twins[k % workers]
+        a, b = t.render(k)
+        t._cache.clear()
+        return k, a, b
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for k, a, b in ex.map(job, range(n_frames)):
+            rendered[k] = (a, b)
+    syn.render = lambda k: rendered[k]
+    osys, run = _lockstep(oracle, syn, fe, ekf, n_frames, check_every=1)
+    assert run.num_clones() >= 58 and len(run.dump()[0]) > 1500
+    assert osys.num_updates() == run.num_updates() > 30
+    compare_msgs(osys, run)
+    compare_poses(osys, run)
+    Po, Pg = osys.cov(), run.cov()
+    assert Po.shape == Pg.shape == (21 + 6 * run.num_clones(),) * 2
+    assert np.abs(Po - Pg).max() / np.abs(Po).max() < 1e-5
+    run.close()
+
+
+def test_staggered_groups_run_ahead(oracle):
+    """MultiRunner::set_stagger (bench.py: replicas of a looping sequence in different groups are kept frames apart so
+    that they never read the same stereo pair at the same time): group g is g * delta frames ahead, and each group's
+    stream equals the oracle fed that many frames."""
+    w, h, n_frames, delta = 376, 240, 40, 7
+    fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
+    syn = oracle.Synth(seed=0x5EED0060, width=w, height=h)
+    keep = []
+    run = R.Runner(syn.calib, fe, ekf, 3, 1, host_threads=1)
+    _attach_sequences(oracle, run, [syn, syn, syn], n_frames + 2 * delta, keep)
+    run.set_stagger(delta)
+    run.run(0, 25, threaded=True, pipelined=True)
+    run.run(25, n_frames - 25, threaded=True, pipelined=True)
+    for g in range(3):
+        assert run.group_offset(g) == g * delta
+        osys = oracle.OracleSystem(syn.calib, fe, ekf)
+        syn.feed(osys, n_frames + g * delta)
+        for x, y in zip(osys.dump()[:4], run.dump(g)[:4]):
+            assert np.array_equal(x, y)
+        op, gp = osys.poses(), run.poses(g)
+        assert len(op) == len(gp) and np.abs(op["p"] - gp["p"]).max() < POS_TOL
     run.close()
