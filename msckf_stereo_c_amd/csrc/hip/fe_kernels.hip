@@ -13,6 +13,7 @@
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
 #include "fe_device.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ pyr_down
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -638,6 +639,305 @@ __global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams, in
     }
 }
 
+// ------------------------------------------------------------------------------------------ LK, four points per wavefront
+// k_lk_points4: the same arithmetic (bit for bit: every decision-bearing quantity is an integer or a fixed sequence of
+// double operations) with a 16-lane row of the wavefront per point: lane r of a row owns image row r of
+// the 16 x 16 search footprint, i.e. ALL 15 pixels of window row r.  What that buys over one wavefront per point:
+//   * the per-point scalar work of an iteration (weights, 2 x 2 solve, convergence tests) is issued once for four points;
+//   * the cross-lane reduction stays inside a DPP row (no cross-row step, no readlane);
+//   * a lane walks 16 consecutive bytes, so the bilinear sample is two packed 16-bit dot products
+//     (v_dot2_i32_i16 on byte pairs built with v_perm_b32) per row instead of four multiplies per pixel, the row below
+//     comes from the neighbouring lane through a DPP row shift fused into the add, and the b1 / b2 sums are packed dot
+//     products too (|diff| <= 8160 and |I| <= 4080 fit 16 bits).
+// Iterations run in lock step for the four points of a wave; a point that has converged idles until the others have.
+typedef short l4_v2s __attribute__((ext_vector_type(2)));
+#define L4_DW 6                // staged dwords per row (24 bytes: the 16 a window reads + alignment + slack)
+#define L4_TROWS 18            // template source rows: 17 interpolated rows need 18
+#define L4_SROWS 20            // staged search rows: the 16 a window reads + 4 of slack
+#define L4_MAXOX 8             // window column offset inside the staged rows: 0 .. 8
+#define L4_MAXOY (L4_SROWS - 16)
+
+__device__ __forceinline__ int l4_dot2(int pair, int w, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(l4_v2s, pair), __builtin_bit_cast(l4_v2s, w), acc, false);
+}
+// DPP row operations (a row = the 16 lanes of one point).  row_shl:n: lane i reads lane i + n, row_shr:n: lane i - n.
+#define L4_SHL1 0x101
+#define L4_SHR1 0x111
+template <int CTRL> __device__ __forceinline__ int l4_dpp0(int v) {        // lanes without a source read 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// 16-lane (row) sum of per-lane int32 partials whose total needs more than 32 bits: quad sums in 32 bits (four lanes of
+// |v| < 2^28.9 stay below 2^31), the last two butterflies in 64 bits.  Every lane of the row ends up with the sum.
+__device__ __forceinline__ long long l4_row_sum(int v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    long long s = (long long)v;
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)s, 0x141, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)(s >> 32), 0x141, 0xf, 0xf, false);
+        s += (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);     // row_half_mirror
+    }
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)s, 0x140, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)(s >> 32), 0x140, 0xf, 0xf, false);
+        s += (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);     // row_mirror
+    }
+    return s;
+}
+
+// Stage ROWS x 24 bytes at image (x0, y0) as LDS dwords dst[row * 6 + c]; the 16 lanes of a point cooperate (r = lane & 15).
+// Pixels outside the image are replicated from the border.
+template <int ROWS>
+__device__ __forceinline__ void l4_stage(const uint8_t *img, int w, int h, int x0, int y0, uint32_t *dst, int r, bool on) {
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    constexpr int N = ROWS * L4_DW, PER = (N + 15) / 16;
+    const bool fast = x0 >= 0 && y0 >= 0 && x0 + 4 * L4_DW <= w && y0 + ROWS <= h;
+    uint32_t v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = r + 16 * i;
+        v[i] = 0;
+        if (on && e < N) {
+            const int row = (e * 43) >> 8, c = e - L4_DW * row;       // e / 6 for e < 128
+            if (fast) v[i] = *(const u32u *)(img + (size_t)(y0 + row) * w + x0 + 4 * c);
+            else {
+                const uint8_t *rp = img + (size_t)min(max(y0 + row, 0), h - 1) * w;
+                const int xb = x0 + 4 * c;
+                v[i] = (uint32_t)rp[min(max(xb, 0), w - 1)] | ((uint32_t)rp[min(max(xb + 1, 0), w - 1)] << 8) |
+                       ((uint32_t)rp[min(max(xb + 2, 0), w - 1)] << 16) | ((uint32_t)rp[min(max(xb + 3, 0), w - 1)] << 24);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const int e = r + 16 * i; if (on && e < N) dst[e] = v[i]; }
+}
+
+// byte pair (b_k, b_k+1) of a byte string held in aligned dwords, as two 16-bit lanes
+template <int K> __device__ __forceinline__ int l4_pair(const uint32_t *a) {
+    constexpr int q = K >> 2, m = K & 3;
+    if (m == 0) return (int)__builtin_amdgcn_perm(0u, a[q], 0x0c010c00u);
+    if (m == 1) return (int)__builtin_amdgcn_perm(0u, a[q], 0x0c020c01u);
+    if (m == 2) return (int)__builtin_amdgcn_perm(0u, a[q], 0x0c030c02u);
+    return (int)__builtin_amdgcn_perm(a[q + 1], a[q], 0x0c040c03u);
+}
+template <int N, int K = 0> struct L4Pairs {
+    static __device__ __forceinline__ void run(const uint32_t *a, int *pr) { pr[K] = l4_pair<K>(a); L4Pairs<N, K + 1>::run(a, pr); }
+};
+template <int N> struct L4Pairs<N, N> { static __device__ __forceinline__ void run(const uint32_t *, int *) {} };
+
+__device__ __forceinline__ void l4_weights(float fa, float fb, int &wtop, int &wbot) {
+    const int qa = __float2int_rn(fa * 16384.0f), qb = __float2int_rn(fb * 16384.0f);
+    const int w00 = ((16384 - qa) * (16384 - qb) + 8192) >> 14;
+    const int w01 = (qa * (16384 - qb) + 8192) >> 14;
+    const int w10 = ((16384 - qa) * qb + 8192) >> 14;
+    const int w11 = 16384 - w00 - w01 - w10;                    // may be -1: kept signed in its 16-bit lane
+    wtop = (w00 & 0xffff) | (w01 << 16);
+    wbot = (w10 & 0xffff) | (w11 << 16);
+}
+
+// Block -> (stream, point group): the blocks b and b + 8 share an XCD (round-robin dispatch, speed only), so the point
+// groups of ONE stream are given ids that are congruent modulo 8: a stream's pyramid levels then travel through one L2.
+__global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, int stereo, int n_streams, int groups_per_stream) {
+    const int x = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int si = x + 8 * (qb / groups_per_stream), gi = qb - (qb / groups_per_stream) * groups_per_stream;
+    if (si >= n_streams) return;
+    const FeStreamDev &S = streams[si];
+    if (4 * gi >= S.n_pts) return;
+    if (!stereo && !S.do_temporal) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int pt = 4 * gi + g;
+    __shared__ uint32_t s_T[4][L4_TROWS * L4_DW + 2];
+    __shared__ uint32_t s_S[4][L4_SROWS * L4_DW + 4];
+    uint32_t *sT = s_T[g], *sS = s_S[g];
+
+    bool alive = pt < S.n_pts;
+    float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+    if (alive) {
+        if (!stereo) {
+            const mskf_point2f pin = S.in_pts[pt];
+            // predictFeatureTracking (:342-347): p2 = H p1, normalise, round to float
+            const double *Hm = S.Hpred;
+            const double px = (double)pin.x, py = (double)pin.y;
+            const double X = Hm[0] * px + Hm[1] * py + Hm[2] * 1.0;
+            const double Y = Hm[3] * px + Hm[4] * py + Hm[5] * 1.0;
+            const double Z = Hm[6] * px + Hm[7] * py + Hm[8] * 1.0;
+            ax = pin.x; ay = pin.y; bx = (float)(X / Z); by = (float)(Y / Z);
+        } else {
+            alive = (S.status[pt] & 1) != 0;
+            if (alive) { const mskf_point2f c0 = S.out0[pt], gsp = S.out1[pt]; ax = c0.x; ay = c0.y; bx = gsp.x; by = gsp.y; }
+        }
+    }
+    if (!__any(alive)) return;
+    const PyrDev &A = stereo ? S.curr0 : S.prev0;
+    const PyrDev &B = stereo ? S.curr1 : S.curr0;
+    int status = 1;
+    float ncx = 0.f, ncy = 0.f;
+    const bool winrow = r < LK_WIN;                       // lane 15 only feeds the row below window row 14
+    for (int l = MSKF_LEVELS - 1; l >= 0; --l) {
+        const uint8_t *imA = A.lvl[l];
+        const uint8_t *imB = B.lvl[l];
+        const int aw = A.w[l], ah = A.h[l], bw = B.w[l], bh = B.h[l];
+        const float sc = __int_as_float((127 - l) << 23);        // 2^-l exactly
+        const float pwx = ax * sc - (float)LK_HALF, pwy = ay * sc - (float)LK_HALF;
+        if (l == MSKF_LEVELS - 1) { ncx = bx * sc; ncy = by * sc; }
+        else { ncx = ncx * 2.0f; ncy = ncy * 2.0f; }
+        int ipx = (int)floorf(pwx), ipy = (int)floorf(pwy);
+        bool lvl_on = alive && !(ipx < -LK_WIN || ipx >= aw || ipy < -LK_WIN || ipy >= ah);
+        if (alive && !lvl_on && l == 0) status = 0;
+        if (!lvl_on) { ipx = 0; ipy = 0; }                   // idle slot: any in-range position
+        int wtop, wbot;
+        l4_weights(lvl_on ? pwx - (float)ipx : 0.f, lvl_on ? pwy - (float)ipy : 0.f, wtop, wbot);
+        // ---- stage the template source (18 x 24 B at the window's 4-aligned left edge) and the first search region
+        const int ax0 = (ipx - 1) & ~3, ay0 = ipy - 1, oxa = ipx - 1 - ax0;
+        float wx = ncx - (float)LK_HALF, wy = ncy - (float)LK_HALF;
+        int inx0 = (int)floorf(wx), iny0 = (int)floorf(wy);
+        const bool in_b0 = !(inx0 < -LK_WIN || inx0 >= bw || iny0 < -LK_WIN || iny0 >= bh);
+        if (!(lvl_on && in_b0)) { inx0 = 0; iny0 = 0; }
+        int bx0 = (inx0 - 2) & ~3, by0 = iny0 - 2;
+        __syncthreads();
+        l4_stage<L4_TROWS>(imA, aw, ah, ax0, ay0, sT, r, true);
+        l4_stage<L4_SROWS>(imB, bw, bh, bx0, by0, sS, r, true);
+        __syncthreads();
+        // ---- interpolated template: lane r holds source row r + 1, so V = T(row r+1) + B(row r+2) is template row r + 1;
+        //      rows 0 and 16 are the extra value E of lanes 0 and 15 (source rows 0 / 17 with the top / bottom weights)
+        int V[17], E[17];
+        {
+            uint32_t d[6], a[5];
+            int pr[17];
+            const uint32_t *rp = sT + (r + 1) * L4_DW;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = rp[i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], oxa);
+            L4Pairs<17>::run(a, pr);
+            int Bv[17];
+#pragma unroll
+            for (int c = 0; c < 17; ++c) { V[c] = l4_dot2(pr[c], wtop, 256); Bv[c] = l4_dot2(pr[c], wbot, 0); }
+            // extra row: source row 0 for lane 0 (top weights, added to its own B), source row 17 for lane 15 (bottom
+            // weights, added to its own T)
+            const uint32_t *ep = sT + (r == 0 ? 0 : 17) * L4_DW;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = ep[i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], oxa);
+            L4Pairs<17>::run(a, pr);
+            const int wsel = r == 0 ? wtop : wbot;
+#pragma unroll
+            for (int c = 0; c < 17; ++c) E[c] = l4_dot2(pr[c], wsel, r == 0 ? Bv[c] + 256 : V[c]) >> 9;
+#pragma unroll
+            for (int c = 0; c < 17; ++c) V[c] = (V[c] + l4_dpp0<L4_SHL1>(Bv[c])) >> 9;
+            // lane 15 is no window row: it hands template row 16 to lane 14 as "the row below"
+            if (r == 15) {
+#pragma unroll
+                for (int c = 0; c < 17; ++c) V[c] = E[c];
+            }
+        }
+        // ---- Scharr gradients of window row r: rows above / below from the neighbouring lanes
+        int Pp[8], Ixp[8], Iyp[8];       // packed pairs (column 2m, 2m + 1); column 15 is padding (zero gradient)
+        int A11 = 0, A12 = 0, A22 = 0;
+        {
+            int f[17], e[17];
+#pragma unroll
+            for (int c = 0; c < 17; ++c) {
+                const int up = __builtin_amdgcn_update_dpp(E[c], V[c], L4_SHR1, 0xf, 0xf, false);   // lane 0 keeps its E = template row 0
+                const int dn = l4_dpp0<L4_SHL1>(V[c]);
+                f[c] = up + dn; e[c] = dn - up;
+            }
+            int gx[16], gy[16], pv[16];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                const int sx = 3 * (f[i + 2] - f[i]) + 10 * (V[i + 2] - V[i]);
+                const int sy = 3 * (e[i] + e[i + 2]) + 10 * e[i + 1];
+                gx[i] = winrow ? (sx + 16) >> 5 : 0;
+                gy[i] = winrow ? (sy + 16) >> 5 : 0;
+                pv[i] = V[i + 1];
+            }
+            gx[15] = 0; gy[15] = 0; pv[15] = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                Ixp[m] = (int)__builtin_amdgcn_perm((uint32_t)gx[2 * m + 1], (uint32_t)gx[2 * m], 0x05040100u);
+                Iyp[m] = (int)__builtin_amdgcn_perm((uint32_t)gy[2 * m + 1], (uint32_t)gy[2 * m], 0x05040100u);
+                Pp[m] = (int)__builtin_amdgcn_perm((uint32_t)pv[2 * m + 1], (uint32_t)pv[2 * m], 0x05040100u);
+                A11 = l4_dot2(Ixp[m], Ixp[m], A11); A12 = l4_dot2(Ixp[m], Iyp[m], A12); A22 = l4_dot2(Iyp[m], Iyp[m], A22);
+            }
+        }
+        const long long A11s = l4_row_sum(A11), A12s = l4_row_sum(A12), A22s = l4_row_sum(A22);
+        const double a11 = lk_scaled_f64(A11s), a12 = lk_scaled_f64(A12s), a22 = lk_scaled_f64(A22s);   // (double)A * 2^-20
+        double D = a11 * a22 - a12 * a12;
+        const double dd = a11 - a22;
+        const double numer = a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12);      // minEig test without the division, see lk_point
+        bool run = lvl_on && !(numer < 0x1.70a3d70a3d70bp-5 || D < 1.1920928955078125e-07);
+        if (lvl_on && !run && l == 0) status = 0;
+        const bool solved = run;
+        D = 1.0 / D;
+        float pdx = 0.f, pdy = 0.f;
+        for (int it = 0; it < LK_ITERS; ++it) {
+            if (!__any(run)) break;
+            int inx = (int)floorf(wx), iny = (int)floorf(wy);
+            if (run && (inx < -LK_WIN || inx >= bw || iny < -LK_WIN || iny >= bh)) {
+                if (l == 0) status = 0;
+                run = false;
+            }
+            int ox = inx - bx0, oy = iny - by0;
+            const bool need = run && (ox < 0 || ox > L4_MAXOX || oy < 0 || oy > L4_MAXOY);
+            if (__any(need)) {
+                if (need) { bx0 = (inx - 2) & ~3; by0 = iny - 2; }
+                __syncthreads();
+                l4_stage<L4_SROWS>(imB, bw, bh, bx0, by0, sS, r, need);
+                __syncthreads();
+                ox = inx - bx0; oy = iny - by0;
+            }
+            if (!run) { ox = 0; oy = 0; }                      // idle slot: stay inside the staged region
+            int wt, wb;
+            l4_weights(wx - (float)inx, wy - (float)iny, wt, wb);
+            uint32_t d[5], a[4];
+            const uint32_t *rp = sS + (oy + r) * L4_DW + (ox >> 2);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = rp[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], ox & 3);
+            int pr[15];
+            L4Pairs<15>::run(a, pr);
+            int sv[16];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const int t = l4_dot2(pr[k], wt, 256), b = l4_dot2(pr[k], wb, 0);
+                sv[k] = (t + l4_dpp0<L4_SHL1>(b)) >> 9;
+            }
+            sv[15] = 0;
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const l4_v2s sp = __builtin_bit_cast(l4_v2s, (int)__builtin_amdgcn_perm((uint32_t)sv[2 * m + 1], (uint32_t)sv[2 * m], 0x05040100u));
+                const int df = __builtin_bit_cast(int, (l4_v2s)(sp - __builtin_bit_cast(l4_v2s, Pp[m])));
+                b1 = l4_dot2(df, Ixp[m], b1);            // masked pixels carry Ix = Iy = 0
+                b2 = l4_dot2(df, Iyp[m], b2);
+            }
+            const long long b1s = l4_row_sum(b1), b2s = l4_row_sum(b2);
+            const double db1 = lk_scaled_f64(b1s), db2 = lk_scaled_f64(b2s);
+            const float dx = (float)((a12 * db2 - a22 * db1) * D);
+            const float dy = (float)((a12 * db1 - a11 * db2) * D);
+            if (run) {
+                wx += dx; wy += dy;
+                if ((double)dx * (double)dx + (double)dy * (double)dy <= 1e-4) run = false;
+                else if (it > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                    wx -= dx * 0.5f; wy -= dy * 0.5f;
+                    run = false;
+                }
+                pdx = dx; pdy = dy;
+            }
+        }
+        if (solved) { ncx = wx + (float)LK_HALF; ncy = wy + (float)LK_HALF; }
+    }
+    if (alive && r == 0) {
+        if (!stereo) {
+            S.out0[pt] = mskf_point2f{ncx, ncy};
+            S.status[pt] = (uint8_t)(status ? 1 : 0);
+        } else {
+            S.out1[pt] = mskf_point2f{ncx, ncy};
+            S.status[pt] = (uint8_t)(1 | (status ? 2 : 0));
+        }
+    }
+}
+
 // Per-point geometry of a track call, one thread per point.
 //   phase 0 (between the tracks): bounds gate of the temporal result (:416-424), stereo initial guess
 //            undistort(cam0, R01) -> distort(cam1) (:542-548); status bit 0 = the point goes on to the stereo track
@@ -700,7 +1000,10 @@ __global__ __launch_bounds__(64) void k_pt_geom(const FeStreamDev *streams, int 
 
 extern "C" void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st) {
     if (max_pts <= 0) return;
-    hipLaunchKernelGGL(k_lk_points, dim3(max_pts, n_streams), dim3(64), 0, st, streams_dev, stereo);
+    static const bool v1 = []() { const char *e = getenv("MSKF_LK_V1"); return e && e[0] == '1'; }();
+    if (v1) { hipLaunchKernelGGL(k_lk_points, dim3(max_pts, n_streams), dim3(64), 0, st, streams_dev, stereo); return; }
+    const int gps = (max_pts + 3) / 4;
+    hipLaunchKernelGGL(k_lk_points4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), 0, st, streams_dev, stereo, n_streams, gps);
 }
 extern "C" void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st) {
     if (max_pts <= 0) return;
