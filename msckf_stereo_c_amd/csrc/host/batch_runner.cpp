@@ -42,7 +42,13 @@ void ForkJoin::run(int n, const std::function<void(int)> &fn) {
 }
 
 BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads) {
-    if (host_threads > 1) { pool_.reset(new ForkJoin(host_threads)); pool_ekf_.reset(new ForkJoin(host_threads)); }
+    // per-stream host phases of a group are independent: optional helper threads for the front-end / filter halves
+    // (MSKF_FE_HOST_THREADS / MSKF_EKF_HOST_THREADS override the common host_threads argument)
+    int ht_fe = host_threads, ht_ekf = host_threads;
+    if (const char *e = std::getenv("MSKF_FE_HOST_THREADS")) ht_fe = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("MSKF_EKF_HOST_THREADS")) ht_ekf = std::max(1, std::atoi(e));
+    if (ht_fe > 1) pool_.reset(new ForkJoin(ht_fe));
+    if (ht_ekf > 1) pool_ekf_.reset(new ForkJoin(ht_ekf));
     int rc = mskf_ctx_create(device, &ctx_);
     if (rc == MSKF_OK) {
         const char *pe = std::getenv("MSKF_EKF_PRIORITY");   // default on; MSKF_EKF_PRIORITY=0 disables

@@ -513,14 +513,29 @@ void ImageProcessor::addNewFeaturesHead() {
         if (code >= sieve.size()) continue;   // the reference indexes out of bounds here (Q7); defined: dropped
         sieve[code].push_back(std::make_pair(new_features[i], cand_responses_det_[i]));
     }
-    in_pts_.clear(); cand_responses_sieved_.clear();
-    for (auto &item : sieve) {
-        if ((int)item.size() > cfg_.grid_max_feature_num) {
-            small_stable_sort(item.begin(), item.end(),
-                              [](const std::pair<Point2f, double> &a, const std::pair<Point2f, double> &b) { return a.second > b.second; });
-            item.erase(item.begin() + cfg_.grid_max_feature_num, item.end());
+    // The reference stereo-matches every sieved candidate (:677-688) and then uses only those that land in a cell with
+    // a vacancy (:736-750).  A candidate's cell is its sieve cell (the matched cam0 point IS the candidate), and the
+    // vacancies are known here, after tracking: candidates of full cells cannot influence any output, so they are not
+    // sent to the device at all.  Their positions in the flattened candidate list still count: Q4 indexes the
+    // detection-order responses with that position, so every kept candidate carries its original index.
+    in_pts_.clear(); cand_responses_sieved_.clear(); cand_index_.clear();
+    int flat = 0;
+    for (size_t code = 0; code < sieve.size(); ++code) {
+        auto &item = sieve[code];
+        const int kept = std::min((int)item.size(), cfg_.grid_max_feature_num);
+        auto live = curr_features_ptr->find((int)code);
+        const bool vacant = live == curr_features_ptr->end() || (int)live->second.size() < cfg_.grid_min_feature_num;
+        if (vacant && kept > 0) {
+            if ((int)item.size() > cfg_.grid_max_feature_num)
+                small_stable_sort(item.begin(), item.end(),
+                                  [](const std::pair<Point2f, double> &a, const std::pair<Point2f, double> &b) { return a.second > b.second; });
+            for (int k = 0; k < kept; ++k) {
+                in_pts_.push_back(mskf_point2f{item[k].first.x, item[k].first.y});
+                cand_responses_sieved_.push_back(item[k].second);
+                cand_index_.push_back(flat + k);
+            }
         }
-        for (const auto &p : item) { in_pts_.push_back(mskf_point2f{p.first.x, p.first.y}); cand_responses_sieved_.push_back(p.second); }
+        flat += kept;
     }
 }
 
@@ -533,7 +548,7 @@ void ImageProcessor::addNewFeaturesTail() {
         if (!(status_[i] & 2)) continue;
         FeatureMetaData nf;
         nf.id = 0; nf.lifetime = 0;
-        nf.response = (float)(q4 ? cand_responses_det_[i] : cand_responses_sieved_[i]);   // Q4 (:698)
+        nf.response = (float)(q4 ? cand_responses_det_[cand_index_[i]] : cand_responses_sieved_[i]);   // Q4 (:698)
         nf.cam0_point = Point2f(out0_[i].x, out0_[i].y);
         nf.cam1_point = Point2f(out1_[i].x, out1_[i].y);
         nf.und0 = Point2f(und0_[i].x, und0_[i].y);

@@ -152,6 +152,7 @@ class ImageProcessor {
     hm::Mat3 cam0_R_p_c_, cam1_R_p_c_;            // integrateImuData result of this frame
     std::vector<double> cand_responses_det_;     // responses in detection order (Q4)
     std::vector<double> cand_responses_sieved_;  // responses in sieve order
+    std::vector<int> cand_index_;                // position of every candidate sent to the device in the reference's full candidate list
     std::vector<mskf_corner> cell_max_;
     GridFeatures grid_new_features_;                                     // per-frame scratch, storage reused
     std::vector<std::vector<std::pair<Point2f, double>>> sieve_;         // per-frame scratch, storage reused
