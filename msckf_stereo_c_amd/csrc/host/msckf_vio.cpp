@@ -96,6 +96,7 @@ void MsckfVio::resetCov() {
 bool MsckfVio::initialize() {
     if (!loadParameters()) return false;
     if (!stream_) { error_ = "MsckfVio: no device stream attached"; return false; }
+    resetCloneSlots();
     resetCov();
     if (have_yaml_) pose_outfile_.open("pose_out.txt");
     return error_.empty();
@@ -129,6 +130,7 @@ bool MsckfVio::resetCallback() {
     s.orientation = Quat(); s.position = Vector3(); s.velocity = Vector3(); s.gyro_bias = Vector3(); s.acc_bias = Vector3();
     s.orientation_null = Quat(); s.position_null = Vector3(); s.velocity_null = Vector3();
     state_server.cam_states.clear();
+    resetCloneSlots();
     resetCov();
     map_server.clear();
     imu_msg_buffer.clear();
@@ -276,6 +278,7 @@ void MsckfVio::stateAugmentation(double time) {
     cs.position = t_c_w;
     cs.orientation_null = cs.orientation;
     cs.position_null = cs.position;
+    cs.slot = allocCloneSlot();
 
     double *J = J_;
     have_J_ = true;
@@ -299,8 +302,10 @@ void MsckfVio::stateAugmentation(double time) {
 // thing (observation (0,0,0,0) for feature 0 at this state id), so when the producer told us where the
 // tail starts (setZeroTailHint) it is collapsed: first record processed normally, the remaining T-1
 // only bump tracked_feature_num exactly as the reference's loop would.  No hint -> plain loop.
+// The loop itself is the reference's, in message order: a record either finds its feature (observation of the newest
+// clone written, last write wins, tracked) or creates it.  The observation goes into the newest clone's column of the
+// observation table, the feature's mask gets the newest clone's bit (feature_store.h).
 void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
-    const StateIDType state_id = state_server.imu_state.id;
     const int curr_feature_num = (int)map_server.size();
     long long tracked = 0;
     size_t n_full = msg->features.size();
@@ -309,53 +314,60 @@ void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
         if (zero_tail_total_ > total) total = zero_tail_total_;          // truncated snapshot of a longer message
         if (zero_tail_start_ < total) n_full = std::min(n_full, zero_tail_start_ + 1);
     }
-    // The reference walks the message in order and looks every id up in map_server.  Same result with one ordered
-    // sweep: the records are visited in ascending id (equal ids keep their message order, which is what decides the
-    // surviving observation and the tracked count when the uncleared message carries an id twice, Q1) while a cursor
-    // advances through the sorted store; ids beyond the last stored one are new features and append.
-    order_.resize(n_full);
-    for (size_t k = 0; k < n_full; ++k) order_[k] = std::make_pair((FeatureIDType)msg->features[k].id, (uint32_t)k);
-    std::stable_sort(order_.begin(), order_.end(), [](const std::pair<FeatureIDType, uint32_t> &a, const std::pair<FeatureIDType, uint32_t> &b) { return a.first < b.first; });
-    size_t cur = 0;
-    for (size_t q = 0; q < n_full; ++q) {
-        const FeatureIDType fid = order_[q].first;
-        const FeatureMeasurement &f = msg->features[order_[q].second];
-        while (cur < map_server.size() && map_server.nth(cur).first < fid) ++cur;
-        if (cur < map_server.size() && map_server.nth(cur).first == fid) {
-            map_server.nth(cur).second.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
-            ++tracked;
-        } else {
-            Feature &nf = map_server[fid];        // append (or the rare ordered insert); cur now points at it
-            nf.id = fid;
-            nf.observations[state_id] = {f.u0, f.v0, f.u1, f.v1};
-        }
+    const CAMState &newest = state_server.cam_states.rbegin()->second;   // the clone stateAugmentation just added
+    const int cs = newest.slot;
+    const uint64_t bit = 1ULL << (state_server.cam_states.size() - 1);
+    for (size_t k = 0; k < n_full; ++k) {
+        const FeatureMeasurement &f = msg->features[k];
+        bool created = false;
+        const int s = map_server.find_or_add((FeatureIDType)f.id, created);
+        double *z = map_server.z(cs, s);
+        z[0] = f.u0; z[1] = f.v0; z[2] = f.u1; z[3] = f.v1;
+        map_server.mask(s) |= bit;
+        if (!created) ++tracked;
     }
     tracked += (long long)(total - n_full);
     tracking_rate = static_cast<double>(tracked) / static_cast<double>(curr_feature_num);   // Q18: 0/0 = NaN on the first frame
 }
 
-// feature.hpp:257-287
-bool MsckfVio::checkMotion(const Feature &f) const {
-    const CAMState &c0 = state_server.cam_states.find(f.observations.begin()->first)->second;
-    const CAMState &c1 = state_server.cam_states.find((--f.observations.end())->first)->second;
-    const hm::Mat3 R0 = kin::rotation_of(c0.orientation.q).transpose();
-    const auto &z = f.observations.begin()->second;
+// feature.hpp:257-287: first and last observation of the feature (bit positions of its mask = clone order)
+bool MsckfVio::checkMotion(int slot, uint64_t mask) const {
+    const int k0 = __builtin_ctzll(mask), k1 = 63 - __builtin_clzll(mask);
+    const mskf_clone_state &c0 = clones_[k0], &c1 = clones_[k1];
+    const hm::Mat3 R0 = kin::rotation_of(c0.q).transpose();
+    const double *z = map_server.z(order_slot_[k0], slot);
     Vector3 dir(z[0], z[1], 1.0);
     dir = dir / hm::norm(dir);
     dir = R0 * dir;
-    const Vector3 tr = c1.position - c0.position;
+    const Vector3 tr = Vector3(c1.p[0], c1.p[1], c1.p[2]) - Vector3(c0.p[0], c0.p[1], c0.p[2]);
     const double par = hm::dot(tr, dir);
     const Vector3 orth = tr - par * dir;
     return hm::norm(orth) > feat_translation_threshold_;
 }
 
+int MsckfVio::allocCloneSlot() {
+    const int s = free_clone_slots_.back();
+    free_clone_slots_.pop_back();
+    return s;
+}
+
+void MsckfVio::resetCloneSlots() {
+    // the window holds at most max_cam_state_size clones (pruning starts when it is full, :1079)
+    const int rows = std::min((int)MapServer::kMaxClones, std::max(cfg_.max_cam_state_size, 4) + 1);
+    map_server.set_clone_rows(rows);
+    free_clone_slots_.clear();
+    for (int s = rows - 1; s >= 0; --s) free_clone_slots_.push_back(s);
+}
+
+// clone states in window order (ascending state id) + the observation-table row of each
 void MsckfVio::packClones() {
-    clones_.clear();
+    clones_.clear(); order_slot_.clear();
     for (const auto &kv : state_server.cam_states) {
         mskf_clone_state c;
         for (int i = 0; i < 4; ++i) { c.q[i] = kv.second.orientation.q[i]; c.q_null[i] = kv.second.orientation_null.q[i]; }
         for (int i = 0; i < 3; ++i) { c.p[i] = kv.second.position[i]; c.p_null[i] = kv.second.position_null[i]; }
         clones_.push_back(c);
+        order_slot_.push_back(kv.second.slot);
     }
 }
 
@@ -381,40 +393,41 @@ void MsckfVio::finishArgs(mskf_ekf_update_args &upd, int dof_offset, int apply_c
     upd.rows_out = &rows_out_;
 }
 
-// removeLostFeatures, selection part (:937-984)
+// removeLostFeatures, selection part (:937-984).  Features are visited in ascending id (the reference's map order);
+// the observations of a feature come out in ascending state id = ascending bit position of its mask, and the bit
+// position IS the clone's index in the state vector.
 void MsckfVio::buildLostFeatureUpdate(mskf_ekf_update_args &upd) {
-    feats_.clear(); feat_ids_.clear(); obs_clone_.clear(); obs_z_.clear();
-    std::vector<FeatureIDType> invalid_ids;
-    const StateIDType cur = state_server.imu_state.id;
-    // clone id -> index in state order
-    std::map<StateIDType, int> clone_index;
-    { int k = 0; for (const auto &kv : state_server.cam_states) clone_index[kv.first] = k++; }
-    for (auto &kv : map_server) {
-        Feature &feature = kv.second;
-        if (feature.observations.find(cur) != feature.observations.end()) continue;
-        if (feature.observations.size() < 3) { invalid_ids.push_back(feature.id); continue; }
+    feats_.clear(); feat_slots_.clear(); erase_ranks_.clear(); obs_clone_.clear(); obs_z_.clear();
+    packClones();
+    const uint64_t cur_bit = 1ULL << (clones_.size() - 1);       // the clone of this frame
+    const size_t nf = map_server.size();
+    for (size_t rank = 0; rank < nf; ++rank) {
+        const int slot = map_server.slot_at(rank);
+        const uint64_t m = map_server.mask(slot);
+        if (m & cur_bit) continue;                                // still tracked
+        if (__builtin_popcountll(m) < 3) { erase_ranks_.push_back(rank); continue; }
         int needs_init = 0;
-        if (!feature.is_initialized) {
-            if (!checkMotion(feature)) { invalid_ids.push_back(feature.id); continue; }
+        if (!map_server.is_initialized(slot)) {
+            if (!checkMotion(slot, m)) { erase_ranks_.push_back(rank); continue; }
             needs_init = 1;   // Feature::initializePosition runs on the device; an invalid result drops the feature there
         }
         mskf_ekf_feature f;
         std::memset(&f, 0, sizeof(f));
         f.obs_start = (int)obs_clone_.size();
-        for (const auto &m : feature.observations) {
-            auto ci = clone_index.find(m.first);
-            if (ci == clone_index.end()) continue;   // feature.hpp:302-304
-            obs_clone_.push_back(ci->second);
-            for (int i = 0; i < 4; ++i) obs_z_.push_back(m.second[i]);
+        for (uint64_t b = m; b; b &= b - 1) {
+            const int k = __builtin_ctzll(b);
+            obs_clone_.push_back(k);
+            const double *z = map_server.z(order_slot_[k], slot);
+            obs_z_.insert(obs_z_.end(), z, z + 4);
         }
         f.n_obs = (int)obs_clone_.size() - f.obs_start;
         f.needs_init = needs_init; f.init_start = f.obs_start; f.n_init = f.n_obs;
-        for (int i = 0; i < 3; ++i) f.position[i] = feature.position[i];
+        const Vector3 &p = map_server.position(slot);
+        for (int i = 0; i < 3; ++i) f.position[i] = p[i];
         feats_.push_back(f);
-        feat_ids_.push_back(feature.id);
+        feat_slots_.push_back(slot);
+        erase_ranks_.push_back(rank);      // processed features leave the map after the update (:1016-1021), in phaseB
     }
-    map_server.erase_many(invalid_ids);
-    packClones();
     finishArgs(upd, -1, 1);   // Q12 dof = #obs - 1, Q13 row cap
 }
 
@@ -446,10 +459,12 @@ void MsckfVio::applyCorrection(const std::vector<double> &dx) {
 
 void MsckfVio::phaseB(mskf_ekf_update_args &upd) {
     // tail of removeLostFeatures (:1016-1021)
-    if (!feats_.empty()) {
-        if (rows_out_ > 0) { hostprof::Scope hp(hostprof::EKF_APPLY1); applyCorrection(delta_x_); }
+    if (!feats_.empty() && rows_out_ > 0) { hostprof::Scope hp(hostprof::EKF_APPLY1); applyCorrection(delta_x_); }
+    {
+        // the features that were too short-lived or failed the motion check (:944-960) and the ones just used
         hostprof::Scope hp(hostprof::EKF_ERASE_LOST);
-        map_server.erase_many(feat_ids_);
+        map_server.erase_ranks(erase_ranks_);
+        erase_ranks_.clear();
     }
     hostprof::Scope hp(hostprof::EKF_BUILD_PRUNE);
     buildPruneUpdate(upd);
@@ -481,60 +496,60 @@ void MsckfVio::findRedundantCamStates(std::vector<StateIDType> &rm) {
 
 // pruneCamStateBuffer, selection part (:1073-1153)
 void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
-    feats_.clear(); feat_ids_.clear(); feat_slots_.clear(); obs_clone_.clear(); obs_z_.clear();
+    feats_.clear(); feat_slots_.clear(); obs_clone_.clear(); obs_z_.clear();
     rm_cam_state_ids_.clear();
     prune_pending_ = false;
     std::memset(&upd, 0, sizeof(upd));
     if ((int)state_server.cam_states.size() < cfg_.max_cam_state_size) return;
     prune_pending_ = true;
     findRedundantCamStates(rm_cam_state_ids_);
-    std::map<StateIDType, int> clone_index;
-    { int k = 0; for (const auto &kv : state_server.cam_states) clone_index[kv.first] = k++; }
-    const StateIDType rm_lo = rm_cam_state_ids_.front(), rm_hi = rm_cam_state_ids_.back();   // sorted (findRedundantCamStates)
-    std::vector<StateIDType> inv;
-    for (size_t slot = 0; slot < map_server.size(); ++slot) {
-        Feature &feature = map_server.nth(slot).second;
-        // observation ids are ascending: a feature first seen after the newest removed clone (or last seen before the
-        // oldest) cannot involve either of them
-        if (feature.observations.empty() || feature.observations.front_key() > rm_hi || feature.observations.back_key() < rm_lo) continue;
-        inv.clear();
-        for (const auto &cid : rm_cam_state_ids_) if (feature.observations.find(cid) != feature.observations.end()) inv.push_back(cid);
-        if (inv.empty()) continue;
-        if (inv.size() == 1) { feature.observations.erase(inv[0]); continue; }
+    packClones();
+    // order indices (= mask bit positions) and table rows of the two clones being removed; rm ids are sorted
+    int ka = -1, kb = -1;
+    { int k = 0; for (const auto &kv : state_server.cam_states) { if (kv.first == rm_cam_state_ids_[0]) ka = k; if (kv.first == rm_cam_state_ids_[1]) kb = k; ++k; } }
+    rm_order_[0] = ka; rm_order_[1] = kb;
+    const uint64_t bit_a = 1ULL << ka, bit_b = 1ULL << kb;
+    const int row_a = order_slot_[ka], row_b = order_slot_[kb];
+    const size_t nf = map_server.size();
+    for (size_t rank = 0; rank < nf; ++rank) {
+        const int slot = map_server.slot_at(rank);
+        const uint64_t m = map_server.mask(slot);
+        // a feature observed by only one of the two loses that observation (:1096-1101), one observed by both but
+        // without enough motion loses both (:1104-1112): both happen when the clone bits are removed in phaseC
+        if ((m & bit_a) == 0 || (m & bit_b) == 0) continue;
         int needs_init = 0;
-        if (!feature.is_initialized) {
-            if (!checkMotion(feature)) {
-                for (const auto &cid : inv) feature.observations.erase(cid);
-                continue;
-            }
+        if (!map_server.is_initialized(slot)) {
+            if (!checkMotion(slot, m)) continue;
             needs_init = 1;
         }
         mskf_ekf_feature f;
         std::memset(&f, 0, sizeof(f));
         if (needs_init) {   // triangulation uses ALL observations of the feature (feature.hpp:298-320)
             f.init_start = (int)obs_clone_.size();
-            for (const auto &m : feature.observations) {
-                auto ci = clone_index.find(m.first);
-                if (ci == clone_index.end()) continue;
-                obs_clone_.push_back(ci->second);
-                for (int i = 0; i < 4; ++i) obs_z_.push_back(m.second[i]);
+            for (uint64_t b = m; b; b &= b - 1) {
+                const int k = __builtin_ctzll(b);
+                obs_clone_.push_back(k);
+                const double *z = map_server.z(order_slot_[k], slot);
+                obs_z_.insert(obs_z_.end(), z, z + 4);
             }
             f.n_init = (int)obs_clone_.size() - f.init_start;
         }
         f.obs_start = (int)obs_clone_.size();
-        for (const auto &cid : inv) {   // the Jacobian block uses only the clones being removed (:1143)
-            obs_clone_.push_back(clone_index[cid]);
-            const auto &z = feature.observations[cid];
-            for (int i = 0; i < 4; ++i) obs_z_.push_back(z[i]);
+        {   // the Jacobian block uses only the clones being removed (:1143)
+            obs_clone_.push_back(ka);
+            const double *za = map_server.z(row_a, slot);
+            obs_z_.insert(obs_z_.end(), za, za + 4);
+            obs_clone_.push_back(kb);
+            const double *zb = map_server.z(row_b, slot);
+            obs_z_.insert(obs_z_.end(), zb, zb + 4);
         }
-        f.n_obs = (int)inv.size();
+        f.n_obs = 2;
         f.needs_init = needs_init;
-        for (int i = 0; i < 3; ++i) f.position[i] = feature.position[i];
+        const Vector3 &p = map_server.position(slot);
+        for (int i = 0; i < 3; ++i) f.position[i] = p[i];
         feats_.push_back(f);
-        feat_ids_.push_back(feature.id);
         feat_slots_.push_back(slot);
     }
-    packClones();
     finishArgs(upd, 0, 0);   // Q12 dof = #involved, no row cap in the pruning path
 }
 
@@ -544,21 +559,21 @@ void MsckfVio::phaseC(bool defer_device) {
     if (prune_pending_) {
         hostprof::Scope hp(hostprof::EKF_TAIL_PRUNE);
         // tail of pruneCamStateBuffer (:1100-1181)
-        for (size_t j = 0; j < feats_.size(); ++j) {
-            Feature &feature = map_server.nth(feat_slots_[j]).second;     // store untouched since buildPruneUpdate
-            if (feats_[j].needs_init && (feat_status_[j] & 1)) {
-                feature.is_initialized = true;
-                feature.position = Vector3(feats_[j].position[0], feats_[j].position[1], feats_[j].position[2]);
-            }
-            for (const auto &cid : rm_cam_state_ids_) feature.observations.erase(cid);
-        }
+        for (size_t j = 0; j < feats_.size(); ++j)
+            if (feats_[j].needs_init && (feat_status_[j] & 1))
+                map_server.set_position(feat_slots_[j], Vector3(feats_[j].position[0], feats_[j].position[1], feats_[j].position[2]));
         if (!feats_.empty() && rows_out_ > 0) applyCorrection(delta_x_);
+        // every observation of the two clones goes (:1096-1101, :1104-1112, :1157-1159): drop their bit positions from
+        // all masks, higher position first so that the lower one stays valid
+        map_server.remove_clone_bit(rm_order_[1]);
+        map_server.remove_clone_bit(rm_order_[0]);
         // indices of both clones in the state order BEFORE either is erased (:1161-1181 removes them one by one)
-        int k = 0;
+        pending_rm_[0] = rm_order_[0]; pending_rm_[1] = rm_order_[1];
         for (const auto &cid : rm_cam_state_ids_) {
-            if (k < 2) pending_rm_[k++] = (int)std::distance(state_server.cam_states.begin(), state_server.cam_states.find(cid));
+            auto it = state_server.cam_states.find(cid);
+            free_clone_slots_.push_back(it->second.slot);
+            state_server.cam_states.erase(it);
         }
-        for (const auto &cid : rm_cam_state_ids_) state_server.cam_states.erase(cid);
         if (!defer_device) {
             mskf_stream *ss[1] = {stream_};
             int rc = mskf_ekf_remove_clones_batch(mskf_stream_ekf_ctx(stream_), 1, ss, pending_rm_);
@@ -578,6 +593,7 @@ void MsckfVio::phaseD(const double pos_var[3]) {
     if (sx < cfg_.position_std_threshold && sy < cfg_.position_std_threshold && sz < cfg_.position_std_threshold) return;
     ++online_reset_counter_;
     state_server.cam_states.clear();
+    resetCloneSlots();
     map_server.clear();
     resetCov();
 }
@@ -594,9 +610,10 @@ void MsckfVio::publish(double time_stamp) {
     if (keepTrajectory) {
         poses_.push_back(pose);
         path_.push_back(T_b_w.t);
-        for (const auto &item : map_server) {
-            if (!item.second.is_initialized) continue;
-            const Vector3 fp = T_imu_body_.R * item.second.position;
+        for (size_t rank = 0; rank < map_server.size(); ++rank) {
+            const int slot = map_server.slot_at(rank);
+            if (!map_server.is_initialized(slot)) continue;
+            const Vector3 fp = T_imu_body_.R * map_server.position(slot);
             points3d_.push_back(Point3f((float)fp[0], (float)fp[1], (float)fp[2]));
         }
     } else {

@@ -16,15 +16,12 @@
 #include <vector>
 #include "../../../include/mskf_hip.h"
 #include "cg_types.h"
-#include "flat_map.h"
+#include "feature_store.h"
 #include "yaml_lite.h"
 
 namespace cg {
 
 mskf_ekf_cfg ekf_cfg_from_yaml(const YAML::Node &cfg_msckfvio);
-
-typedef long long int StateIDType;
-typedef long long int FeatureIDType;
 
 struct Quat { double q[4] = {0, 0, 0, 1}; };   // JPL [x y z w]
 
@@ -46,16 +43,10 @@ struct CAMState {   // common/cam_state.h:25-55
     Vector3 position;
     Quat orientation_null;
     Vector3 position_null;
+    int slot = -1;      // row of the observation table that holds this clone's observations (feature_store.h)
 };
 typedef std::map<StateIDType, CAMState> CamStateServer;
-
-struct Feature {   // feature.hpp:31-163 (triangulation itself runs on the device)
-    FeatureIDType id = 0;
-    FlatMap<StateIDType, std::array<double, 4>> observations;   // feature.hpp:139 keeps a std::map; see flat_map.h
-    Vector3 position;
-    bool is_initialized = false;
-};
-typedef FlatMap<FeatureIDType, Feature> MapServer;
+// Feature / MapServer (feature.hpp:31-168): see feature_store.h — flat tables with the maps' semantics
 
 class MsckfVio {
   public:
@@ -127,8 +118,10 @@ class MsckfVio {
     void buildPruneUpdate(mskf_ekf_update_args &upd);
     void applyCorrection(const std::vector<double> &delta_x);
     void publish(double time_stamp);
-    bool checkMotion(const Feature &f) const;
+    bool checkMotion(int slot, uint64_t mask) const;
     void packClones();
+    int allocCloneSlot();
+    void resetCloneSlots();
     void finishArgs(mskf_ekf_update_args &upd, int dof_offset, int apply_cap);
     void fail(const char *what, int rc);
 
@@ -163,9 +156,10 @@ class MsckfVio {
     std::vector<mskf_imu_step> imu_steps_;
     std::vector<mskf_clone_state> clones_;
     std::vector<mskf_ekf_feature> feats_;
-    std::vector<FeatureIDType> feat_ids_;
-    std::vector<size_t> feat_slots_;                       // positions of feat_ids_ in map_server (pruning update)
-    std::vector<std::pair<FeatureIDType, uint32_t>> order_;     // addFeatureObservations scratch
+    std::vector<int> feat_slots_;                          // map_server slots of feats_
+    std::vector<size_t> erase_ranks_;                      // map_server ranks to erase after the lost-feature update (ascending)
+    std::vector<int> order_slot_;                          // observation-table row of the k-th oldest clone (packClones)
+    std::vector<int> free_clone_slots_;
     std::vector<int32_t> obs_clone_;
     std::vector<double> obs_z_;
     std::vector<double> delta_x_, gamma_;
@@ -176,6 +170,7 @@ class MsckfVio {
     bool defer_device_ = false, have_J_ = false;
     double J_[6 * 21];
     int32_t pending_rm_[2] = {-1, -1};
+    int rm_order_[2] = {-1, -1};                           // window positions of the two clones being pruned
     const CameraMeasurement *zero_tail_msg_ = nullptr;
     size_t zero_tail_start_ = 0, zero_tail_total_ = 0;
     std::ofstream pose_outfile_;
