@@ -16,6 +16,8 @@ void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
+void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
+int ekf_small_update_max_na(void);
 }
 
 namespace {
@@ -119,7 +121,7 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
     D.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
     D.qc[2] = s->ekf.noise_acc * s->ekf.noise_acc;
     D.qc[3] = s->ekf.noise_acc_bias * s->ekf.noise_acc_bias;
-    D.Hs = E.Hs; D.rs = E.rs; D.T = E.T; D.S = E.S; D.W = E.W; D.act = E.act; D.gate_S = E.gate_S; D.nmax = E.nmax;
+    D.Hs = E.Hs; D.rowmask = (unsigned long long *)E.rs; D.T = E.T; D.S = E.S; D.W = E.W; D.act = E.act; D.gate_S = E.gate_S; D.nmax = E.nmax;
     hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
     std::memcpy(D.R_c0_c1, T01.R.m, sizeof(D.R_c0_c1));
     for (int i = 0; i < 3; ++i) D.t_c0_c1[i] = T01.t[i];
@@ -418,7 +420,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     hipStream_t st = ctx->stream;
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
-    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0;
+    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0, max_na_bound = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
     std::vector<Lay> lay(n);
@@ -433,12 +435,18 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         if (a.n_feat && (!a.clones || !a.features || !a.obs_clone || !a.obs_z || !a.delta_x || !a.feat_status || !a.rows_out)) return MSKF_ERR_INVALID;
         Lay &L = lay[i];
         int m_total = 0;
+        unsigned long long clone_mask = 0ULL;          // clones any Jacobian block of this stream touches: bounds the active columns
         for (int j = 0; j < a.n_feat; ++j) {
             const mskf_ekf_feature &f = a.features[j];
             if (f.n_obs < 2 || f.n_obs > E.max_clones || f.obs_start < 0 || f.obs_start + f.n_obs > a.n_obs) return MSKF_ERR_INVALID;
             if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
             m_total += 4 * f.n_obs - 3;
             max_frows = std::max(max_frows, 4 * f.n_obs);
+            for (int o = 0; o < f.n_obs; ++o) {
+                const int c = a.obs_clone[f.obs_start + o];
+                if (c < 0 || c >= a.n_clones) return MSKF_ERR_INVALID;
+                clone_mask |= 1ULL << c;
+            }
             const double nj = 4.0 * f.n_obs - 3.0, M = f.n_obs, dd = E.d;
             fl_feat += 2.0 * nj * (4.0 * M) * (6.0 * M) + 2.0 * nj * dd * dd + 2.0 * nj * nj * dd;
         }
@@ -470,6 +478,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             if ((rc = dev_alloc(&E.rs, (size_t)cap, st)) != MSKF_OK) return rc;
             E.max_rows = cap;
         }
+        max_na_bound = std::max(max_na_bound, 6 * __builtin_popcountll(clone_mask));
         max_feat = std::max(max_feat, a.n_feat);
         max_m = std::max(max_m, m_total);
         max_d = std::max(max_d, E.d);
@@ -493,6 +502,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             fd[j].needs_init = f.needs_init; fd[j].init_start = f.init_start; fd[j].n_init = f.n_init;
             fd[j].row_off = row;
             fd[j].position[0] = f.position[0]; fd[j].position[1] = f.position[1]; fd[j].position[2] = f.position[2];
+            fd[j].colmask = 0ULL;
             row += 4 * f.n_obs - 3;
         }
         if (a.n_obs) {
@@ -524,30 +534,38 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);
         mskf_t_end(ctx, ts, n);
-        // QR compression as Gram + semidefinite Cholesky, then the Kalman update (ekf_linalg.hip)
-        enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
-        const double d3 = fl_upd / (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0);     // sum of d^3 over the launch
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
-        mskf_t_end(ctx, ts, (long long)fl_qr);
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
-        ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
-        mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
-        mskf_t_end(ctx, ts, (long long)(2.0 * d3));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_S2, max_d, st);
-        mskf_t_end(ctx, ts, (long long)(2.0 * d3));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
-        ekf_launch_chol(ctx->ekf_desc.d, n, 1, max_d, st);
-        mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
-        ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
-        mskf_t_end(ctx, ts, (long long)(2.0 * d3));
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
-        mskf_t_end(ctx, ts, (long long)(4.0 * d3));
+        if (max_na_bound <= ekf_small_update_max_na()) {
+            // every stream of the batch stacks blocks of at most four clones (the pruning update: the two clones being
+            // removed): compression, gain and downdate in one launch (k_ekf_small_update)
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
+            ekf_launch_small_update(ctx->ekf_desc.d, n, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(fl_qr + fl_upd));
+        } else {
+            // QR compression as Gram + semidefinite Cholesky, then the Kalman update (ekf_linalg.hip)
+            enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
+            const double d3 = fl_upd / (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0);     // sum of d^3 over the launch
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
+            mskf_t_end(ctx, ts, (long long)fl_qr);
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
+            ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(2.0 * d3));
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_S2, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(2.0 * d3));
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
+            ekf_launch_chol(ctx->ekf_desc.d, n, 1, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
+            ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(2.0 * d3));
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
+            mskf_t_end(ctx, ts, (long long)(4.0 * d3));
+        }
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));

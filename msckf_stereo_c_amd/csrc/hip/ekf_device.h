@@ -11,8 +11,9 @@
 struct EkfFeatDev {
     int obs_start, n_obs;
     int needs_init, init_start, n_init;
-    int row_off;              // first row of this feature's (4 n_obs - 3)-row block in Hs / rs
+    int row_off;              // first row of this feature's (4 n_obs - 3)-row block in Hs
     double position[3];
+    unsigned long long colmask;   // device: bit c set = the block carries clone c's six columns and is stacked (0 = not stacked)
 };
 
 // Everything the update kernels need for one VIO stream.
@@ -30,8 +31,11 @@ struct EkfStreamDev {
     EkfFeatDev *feats;                   // n_feat
     const int *obs_clone;                // n_obs
     const double *obs_z;                 // n_obs x 4
-    double *Hs;               // m_total x ld stacked (null-space projected) Jacobian, failed blocks zeroed
-    double *rs;               // m_total
+    // m_total x ld stacked (null-space projected) Jacobian.  A block is written only in the columns of the clones its
+    // feature observed (+ column d, the residual); what a row carries is its rowmask (clone bits, 0 = the row is not
+    // stacked: failed triangulation / gate, or behind the row cap).  Nothing else of a row is ever written or read.
+    double *Hs;
+    unsigned long long *rowmask;   // m_total, filled by k_ekf_cap
     // The dense update works on the active columns only (compact index i <-> column act[i]): a stacked Jacobian is
     // identically zero in the 21 IMU columns and in the columns of clones none of its features observed, and such
     // columns contribute nothing to S, K or the covariance downdate.

@@ -485,7 +485,6 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         EkfFeatDev &F = S.feats[j];
         const int M = F.n_obs, rows = 4 * M, n = rows - 3;
         double *Hrow0 = S.Hs + (size_t)F.row_off * ld;
-        double *r0 = S.rs + F.row_off;
         // ---- 1. position
         if (gt < 64) {
             bool valid = true;
@@ -501,9 +500,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         for (int c = gt; c < MAX_CLONES_DEV; c += GS) sObsOfClone[c] = -1;
         GSYNC();
         if (!sValid || M < 2) {
-            if (gt == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; }
-            for (int i = gt; i < n * ld; i += GS) Hrow0[i] = 0.0;
-            for (int i = gt; i < n; i += GS) r0[i] = 0.0;
+            if (gt == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; F.colmask = 0ULL; }
             continue;
         }
         // ---- 2. per-observation Jacobians (msckf_vio.cpp:610-677)
@@ -612,28 +609,20 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             sCoef[cc][0] = c1; sCoef[cc][1] = c2; sCoef[cc][2] = c3;
         }
         GSYNC();
-        // ---- 5. write the projected block: rows 3..4M-1 of Q^T [H_xj | r_j]
-        for (int i = 3 + (gt >> 6); i < rows; i += GS / 64) {       // one output row per wave pass, columns across lanes
+        // ---- 5. write the projected block: rows 3..4M-1 of Q^T [H_xj | r_j], only the 6 M columns of the observed
+        //         clones and the residual column (the rest of a row is never read: rowmask, k_ekf_cap)
+        for (int i = 3 + (gt >> 6); i < rows; i += GS / 64) {       // one output row per wave pass, compact columns across lanes
             const double v0 = sV[0][i], v1 = sV[1][i], v2 = sV[2][i];
             double *out = Hrow0 + (size_t)(i - 3) * ld;
             const int ob_i = i >> 2;
-            for (int c = gt & 63; c < d; c += 64) {
-                double v = 0.0;
-                if (c >= EKF_IMU_DIM) {
-                    const int cl = (c - EKF_IMU_DIM) / 6, c6 = (c - EKF_IMU_DIM) - 6 * cl;
-                    const int ob = sObsOfClone[cl];
-                    if (ob >= 0) {
-                        const int cc = 6 * ob + c6;
-                        const double base = (ob_i == ob) ? sHx[i][c6] : 0.0;
-                        v = base - sCoef[cc][0] * v0 - sCoef[cc][1] * v1 - sCoef[cc][2] * v2;
-                    }
-                }
-                out[c] = v;
+            for (int cc = gt & 63; cc < 6 * M; cc += 64) {
+                const int ob = cc / 6, c6 = cc - 6 * ob;
+                const double base = (ob_i == ob) ? sHx[i][c6] : 0.0;
+                out[EKF_IMU_DIM + 6 * sCloneOfObs[ob] + c6] = base - sCoef[cc][0] * v0 - sCoef[cc][1] * v1 - sCoef[cc][2] * v2;
             }
         }
         for (int i = 3 + gt; i < rows; i += GS) {
             const double rv = sr[i] - sCoef[6 * M][0] * sV[0][i] - sCoef[6 * M][1] * sV[1][i] - sCoef[6 * M][2] * sV[2][i];
-            r0[i - 3] = rv;
             sRo[i - 3] = rv;
             Hrow0[(size_t)(i - 3) * ld + d] = rv;   // column d of the stacked matrix carries the residual ([H | r])
         }
@@ -767,79 +756,87 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         }
         const int dof = M + S.dof_offset;
         const bool pass = pd_ok && dof >= 1 && dof < 100 && gamma < S.chi2[dof];
-        if (gt == 0) { S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma; }
-        if (!pass) {
-            GSYNC();
-            for (int i = gt; i < n * ld; i += GS) Hrow0[i] = 0.0;
-            for (int i = gt; i < n; i += GS) r0[i] = 0.0;
+        if (gt == 0) {
+            S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma;
+            unsigned long long cm = 0ULL;
+            if (pass) for (int o = 0; o < M; ++o) cm |= 1ULL << sCloneOfObs[o];
+            F.colmask = cm;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------ cap
-// msckf_vio.cpp:1002-1010: stack passing blocks in feature order, stop once rows > cap
+// msckf_vio.cpp:1002-1010: stack the passing blocks in feature order and stop once the stacked rows exceed the cap
+// (the block that crosses it is still stacked).  Parallel form: every thread owns a contiguous run of features, the
+// rows of the passing ones are prefix-summed across the workgroup, the first feature whose inclusive sum exceeds the
+// cap ends the stack.  Also produced here: the rowmask of every row (what k_ekf_gemm<GRAM> may read), the active
+// column list and the counters rows_out[0..2].
 __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    __shared__ int s_cap_from;
-    __shared__ int s_rows[1024], s_off[1024];
-    __shared__ unsigned char s_st[1024];
     const int nf = S.n_feat;
     if (nf <= 0) return;
-    // the scan is sequential by definition (stack until rows > cap); stage what it reads in LDS first
-    for (int base = 0; base < nf; base += 1024) {
-        const int cnt = min(1024, nf - base);
+    __shared__ int s_sum[WG], s_cross[WG];
+    __shared__ unsigned long long s_or[WG / 64];
+    __shared__ int s_cap_from;
+    const int tid = threadIdx.x;
+    const int per = (nf + WG - 1) / WG;
+    const int j0 = tid * per, j1 = min(nf, j0 + per);
+    int local = 0;
+    for (int j = j0; j < j1; ++j) if (S.feat_status[j] & 2) local += 4 * S.feats[j].n_obs - 3;
+    s_sum[tid] = local;
+    __syncthreads();
+    // inclusive scan of the per-thread sums (Hillis-Steele over WG entries)
+    for (int off = 1; off < WG; off <<= 1) {
+        const int v = tid >= off ? s_sum[tid - off] : 0;
         __syncthreads();
-        for (int j = threadIdx.x; j < cnt; j += WG) {
-            s_st[j] = S.feat_status[base + j];
-            s_rows[j] = 4 * S.feats[base + j].n_obs - 3;
-            s_off[j] = S.feats[base + j].row_off;
-        }
+        s_sum[tid] += v;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int stack = base == 0 ? 0 : S.rows_out[0];
-            int cap_from = base == 0 ? nf : s_cap_from;
-            int m_eff = base == 0 ? 0 : S.rows_out[1];
-            if (cap_from == nf) {
-                for (int j = 0; j < cnt; ++j) {
-                    if (s_st[j] & 2) { stack += s_rows[j]; m_eff = s_off[j] + s_rows[j]; }
-                    if (S.apply_row_cap && stack > S.max_stack_rows) { cap_from = base + j + 1; break; }
-                }
-            }
-            s_cap_from = cap_from;
-            S.rows_out[0] = stack;
-            S.rows_out[1] = m_eff;    // rows beyond the last stacked block are all zero: the Gram pass stops there
+    }
+    const int before = s_sum[tid] - local;
+    // first feature of this thread's run whose inclusive stacked-row count exceeds the cap
+    int cross = nf;
+    if (S.apply_row_cap) {
+        int run = before;
+        for (int j = j0; j < j1; ++j) {
+            if (S.feat_status[j] & 2) { run += 4 * S.feats[j].n_obs - 3; if (run > S.max_stack_rows) { cross = j; break; } }
         }
     }
+    s_cross[tid] = cross;
     __syncthreads();
-    // zero the blocks of features behind the cap (they passed the gate but are not stacked)
-    for (int j = s_cap_from; j < nf; ++j) {
-        if (!(S.feat_status[j] & 2)) continue;
-        const EkfFeatDev &F = S.feats[j];
-        const int n = 4 * F.n_obs - 3;
-        double *Hrow0 = S.Hs + (size_t)F.row_off * S.ld;
-        for (int i = threadIdx.x; i < n * S.ld; i += WG) Hrow0[i] = 0.0;
-        for (int i = threadIdx.x; i < n; i += WG) S.rs[F.row_off + i] = 0.0;
-        __syncthreads();
-        if (threadIdx.x == 0) S.feat_status[j] &= (uint8_t)~2;
+    if (tid == 0) {
+        int c = nf;
+        for (int t = 0; t < WG; ++t) if (s_cross[t] < c) c = s_cross[t];
+        s_cap_from = c < nf ? c + 1 : nf;       // features [cap_from, nf) are not stacked
     }
     __syncthreads();
-    // active columns: the six columns of every clone observed by a stacked feature, ascending
-    __shared__ int s_clone_on[MAX_CLONES_DEV];
-    for (int c = threadIdx.x; c < MAX_CLONES_DEV; c += WG) s_clone_on[c] = 0;
-    __syncthreads();
-    // stacked = passed the gate and in front of the cap.  The cap is applied by index here: thread 0 cleared the status
-    // bits of the capped features above, and another wave re-reading them could still be served the old L1 line.
     const int cap_from = s_cap_from;
-    for (int j = threadIdx.x; j < cap_from; j += WG) {
-        if (!(S.feat_status[j] & 2)) continue;
-        const EkfFeatDev &F = S.feats[j];
-        for (int o = 0; o < F.n_obs; ++o) s_clone_on[S.obs_clone[F.obs_start + o]] = 1;     // benign race: all writers store 1
+    // stacked rows, last stacked row, clone mask of the stack; capped features lose their block
+    int stack = 0, meff = 0;
+    unsigned long long orm = 0ULL;
+    for (int j = j0; j < j1; ++j) {
+        EkfFeatDev &F = S.feats[j];
+        const int n = 4 * F.n_obs - 3;
+        unsigned long long cm = F.colmask;
+        if (!(S.feat_status[j] & 2)) cm = 0ULL;
+        if (j >= cap_from && cm) { cm = 0ULL; F.colmask = 0ULL; S.feat_status[j] &= (uint8_t)~2; }
+        if (cm) { stack += n; meff = F.row_off + n; orm |= cm; }
+        for (int i = 0; i < n; ++i) S.rowmask[F.row_off + i] = cm;
     }
+    s_sum[tid] = stack; s_cross[tid] = meff;
+    for (int off = 32; off > 0; off >>= 1) orm |= __shfl_xor(orm, off);
+    if ((tid & 63) == 0) s_or[tid >> 6] = orm;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
+        int st = 0, me = 0;
+        for (int t = 0; t < WG; ++t) { st += s_sum[t]; if (s_cross[t] > me) me = s_cross[t]; }
+        unsigned long long m = 0ULL;
+        for (int w = 0; w < WG / 64; ++w) m |= s_or[w];
+        // active columns: the six columns of every clone observed by a stacked feature, ascending
         int na = 0;
         for (int c = 0; c < S.n_clones; ++c)
-            if (s_clone_on[c]) for (int k = 0; k < 6; ++k) S.act[na++] = EKF_IMU_DIM + 6 * c + k;
+            if ((m >> c) & 1ULL) for (int k = 0; k < 6; ++k) S.act[na++] = EKF_IMU_DIM + 6 * c + k;
+        S.rows_out[0] = st;
+        S.rows_out[1] = me;       // rows beyond the last stacked block carry nothing: the Gram pass stops there
         S.rows_out[2] = na;
     }
 }

@@ -100,10 +100,29 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         colA = (i0 + lo < na) ? act[i0 + lo] : d;       // compact index na is the residual column d of [H | r]
         colB = (j0 + lo < na) ? act[j0 + lo] : d;
     }
+    // GRAM: what a stacked row carries is its rowmask (bit c = the six columns of clone c, any bit = the residual column);
+    // everything else of the row was never written and is not read
+    const int cloneA = MODE == GM_GRAM ? (colA < d ? (colA - EKF_IMU_DIM) / 6 : -1) : 0;
+    const int cloneB = MODE == GM_GRAM ? (colB < d ? (colB - EKF_IMU_DIM) / 6 : -1) : 0;
+    const unsigned long long *__restrict__ rowmask = S.rowmask;
     double ra[4], rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            if (MODE == GM_GRAM) {
+                // both operands are (column = lo, row = hi + 8 e) of [H | r]
+                const int gk = k0 + hi + 8 * e;
+                double v = 0.0, w = 0.0;
+                if (gk < K) {
+                    const unsigned long long rm = rowmask[gk];
+                    const bool onA = cloneA < 0 ? rm != 0ULL : ((rm >> cloneA) & 1ULL) != 0ULL;
+                    const bool onB = cloneB < 0 ? rm != 0ULL : ((rm >> cloneB) & 1ULL) != 0ULL;
+                    if (onA && i0 + lo < M) v = A[(size_t)gk * ld + colA];
+                    if (onB && j0 + lo < N) w = B[(size_t)gk * ld + colB];
+                }
+                ra[e] = v; rb[e] = w;
+                continue;
+            }
             // A: TA -> (i = lo, k = hi + 8e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + 8e) reads A[i*ld + k]
             const int ii = TR::TA ? lo : hi + 8 * e, kk = TR::TA ? hi + 8 * e : lo;
             const int gi = i0 + ii, gk = k0 + kk;
@@ -375,6 +394,167 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     }
 }
 
+// ------------------------------------------------------------------------------------ small update, fused
+// The whole measurement update of a stream in ONE workgroup when the stack touches few clones (na <= SU_MAX_NA active
+// columns): the pruning update (msckf_vio.cpp:1073-1184) stacks hundreds of 2-observation features but only the two
+// clones being removed, i.e. na = 12.  The general path spends seven launches (Gram, factor, T, S, factor, solve,
+// downdate) on 13 x 13 and 12 x 12 matrices there; here the compression, the gain and the covariance downdate run
+// back to back out of LDS.  Same algebra as the general path: G = [H_act|r]^T [H_act|r] + lambda I = L L^T,
+// T = L^T[0:na,0:na] P[act,:], S = T[:,act] L[0:na,0:na] + sigma^2 I = L2 L2^T, Y = L2^-1 [T | Q^T r],
+// delta_x = Y^T w, P -= Y^T Y (symmetric by construction).  All sums run in a fixed order (no atomics).
+#define SU_MAX_NA 24
+#define SU_CH 64          // stacked rows per Gram chunk
+__global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    if (S.n_feat <= 0) return;
+    const int d = S.d, ld = S.ld, na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1];
+    const int tid = threadIdx.x;
+    if (na <= 0 || na > SU_MAX_NA) {            // nothing stacked (or a caller error): no correction, P unchanged
+        for (int c = tid; c < d; c += 256) S.delta_x[c] = 0.0;
+        return;
+    }
+    extern __shared__ double s_dyn[];
+    double *sT = s_dyn;                          // na x (d + 1): T, then Y
+    double *sG = sT + (size_t)na * (d + 1);      // n1 x n1: Gram matrix, then its factor L (lower)
+    double *sS = sG + n1 * n1;                   // na x na: S, then its factor L2 (lower)
+    double *sC = sS + na * na;                   // SU_CH x n1 chunk of [H_act | r]
+    __shared__ int s_col[SU_MAX_NA + 1], s_clone[SU_MAX_NA + 1];
+    __shared__ double s_lam;
+    if (tid < n1) {
+        const int col = tid < na ? S.act[tid] : d;
+        s_col[tid] = col;
+        s_clone[tid] = tid < na ? (col - EKF_IMU_DIM) / 6 : -1;
+    }
+    __syncthreads();
+    // ---- 1. Gram matrix, pairs (i >= j) over the threads, rows in order
+    const int np = n1 * (n1 + 1) / 2;
+    int pi[2], pj[2];
+    double acc[2] = {0.0, 0.0};
+    for (int q = 0; q < 2; ++q) {
+        const int p = tid + 256 * q;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= p) ++i;
+        pi[q] = i; pj[q] = p - i * (i + 1) / 2;
+    }
+    for (int k0 = 0; k0 < K; k0 += SU_CH) {
+        __syncthreads();
+        for (int e = tid; e < SU_CH * n1; e += 256) {
+            const int r = e / n1, c = e - r * n1, gk = k0 + r;
+            double v = 0.0;
+            if (gk < K) {
+                const unsigned long long rm = S.rowmask[gk];
+                const bool on = s_clone[c] < 0 ? rm != 0ULL : ((rm >> s_clone[c]) & 1ULL) != 0ULL;
+                if (on) v = S.Hs[(size_t)gk * ld + s_col[c]];
+            }
+            sC[e] = v;
+        }
+        __syncthreads();
+        for (int q = 0; q < 2; ++q) {
+            if (tid + 256 * q >= np) continue;
+            double a = acc[q];
+            for (int r = 0; r < SU_CH; ++r) a += sC[r * n1 + pi[q]] * sC[r * n1 + pj[q]];
+            acc[q] = a;
+        }
+    }
+    for (int q = 0; q < 2; ++q)
+        if (tid + 256 * q < np) { sG[pi[q] * n1 + pj[q]] = acc[q]; sG[pj[q] * n1 + pi[q]] = acc[q]; }
+    __syncthreads();
+    // ---- 2. G + lambda I = L L^T (lambda as in k_ekf_chol_lds), the Q^T r row rides along as row na
+    if (tid == 0) { double mx = 0; for (int i = 0; i < na; ++i) mx = fmax(mx, sG[i * n1 + i]); s_lam = mx * (double)d * 1e-14; }
+    __syncthreads();
+    if (tid < na) sG[tid * n1 + tid] += s_lam;
+    __syncthreads();
+    for (int k = 0; k < na; ++k) {
+        const double pv = sG[k * n1 + k];
+        const double inv = pv > 0.0 ? 1.0 / sqrt(pv) : 0.0;
+        __syncthreads();
+        if (tid >= k && tid < n1) sG[tid * n1 + k] = (tid == k) ? (pv > 0.0 ? sqrt(pv) : 0.0) : sG[tid * n1 + k] * inv;
+        __syncthreads();
+        for (int e = tid; e < (n1 - k - 1) * (n1 - k - 1); e += 256) {
+            const int i = k + 1 + e / (n1 - k - 1), j = k + 1 + e % (n1 - k - 1);
+            if (j <= i) sG[i * n1 + j] -= sG[i * n1 + k] * sG[j * n1 + k];
+        }
+        __syncthreads();
+    }
+    // ---- 3. T = R P[act, :] with R = L^T (upper): T[i][c] = sum_{k >= i} L[k][i] P[act[k]][c];  T[i][d] = (Q^T r)_i = L[na][i]
+    const double *P = S.P;
+    for (int c = tid; c < d; c += 256) {
+        double pc[SU_MAX_NA];
+#pragma unroll
+        for (int k = 0; k < SU_MAX_NA; ++k) pc[k] = k < na ? P[(size_t)s_col[k] * ld + c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < SU_MAX_NA; ++i) {
+            if (i < na) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = i; k < SU_MAX_NA; ++k) if (k < na) t += sG[k * n1 + i] * pc[k];
+                sT[i * (d + 1) + c] = t;
+            }
+        }
+    }
+    if (tid < na) sT[tid * (d + 1) + d] = sG[na * n1 + tid];
+    __syncthreads();
+    // ---- 4. S = T[:, act] R^T + sigma^2 I (lower, mirrored): S[i][j] = sum_{k >= j} T[i][act[k]] L[k][j]
+    for (int e = tid; e < na * na; e += 256) {
+        const int i = e / na, j = e - i * na;
+        if (j > i) continue;
+        double t = 0.0;
+        for (int k = j; k < na; ++k) t += sT[i * (d + 1) + s_col[k]] * sG[k * n1 + j];
+        if (i == j) t += S.sigma2;
+        sS[i * na + j] = t; sS[j * na + i] = t;
+    }
+    __syncthreads();
+    // ---- 5. S = L2 L2^T
+    for (int k = 0; k < na; ++k) {
+        const double pv = sS[k * na + k];
+        const double inv = pv > 0.0 ? 1.0 / sqrt(pv) : 0.0;
+        __syncthreads();
+        if (tid >= k && tid < na) sS[tid * na + k] = (tid == k) ? (pv > 0.0 ? sqrt(pv) : 0.0) : sS[tid * na + k] * inv;
+        __syncthreads();
+        for (int e = tid; e < (na - k - 1) * (na - k - 1); e += 256) {
+            const int i = k + 1 + e / (na - k - 1), j = k + 1 + e % (na - k - 1);
+            if (j <= i) sS[i * na + j] -= sS[i * na + k] * sS[j * na + k];
+        }
+        __syncthreads();
+    }
+    // ---- 6. Y = L2^-1 [T | Q^T r], one thread per column
+    for (int c = tid; c <= d; c += 256) {
+        double y[SU_MAX_NA];
+#pragma unroll
+        for (int i = 0; i < SU_MAX_NA; ++i) {
+            y[i] = 0.0;
+            if (i >= na) continue;
+            double t = sT[i * (d + 1) + c];
+#pragma unroll
+            for (int k = 0; k < i; ++k) t -= sS[i * na + k] * y[k];
+            const double l = sS[i * na + i];
+            y[i] = l != 0.0 ? t / l : 0.0;
+            sT[i * (d + 1) + c] = y[i];
+        }
+    }
+    __syncthreads();
+    // ---- 7. delta_x = Y^T w (msckf_vio.cpp:860), P <- P - Y^T Y (:897-904): thread = column j, rows i >= j, mirrored
+    double *Pw = S.P;
+    for (int j = tid; j < d; j += 256) {
+        double yj[SU_MAX_NA];
+        double dx = 0.0;
+#pragma unroll
+        for (int k = 0; k < SU_MAX_NA; ++k) {
+            yj[k] = k < na ? sT[k * (d + 1) + j] : 0.0;
+            if (k < na) dx += yj[k] * sT[k * (d + 1) + d];
+        }
+        S.delta_x[j] = dx;
+        for (int i = j; i < d; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < SU_MAX_NA; ++k) if (k < na) t += sT[k * (d + 1) + i] * yj[k];
+            const double v = Pw[(size_t)i * ld + j] - t;
+            Pw[(size_t)i * ld + j] = v;
+            if (i != j) Pw[(size_t)j * ld + i] = v;
+        }
+    }
+}
+
 extern "C" {
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st) {
     const int t = (max_mn + GT - 1) / GT;
@@ -399,6 +579,13 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
     const int pan_rs = (nt + 15) / 16 * 16;
     hipLaunchKernelGGL(k_ekf_chol, dim3(1, n), dim3(CHOLG_THREADS), (size_t)LNB * pan_rs * sizeof(double), st, d, which, pan_rs);
 }
+void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
+    const size_t lds = ((size_t)SU_MAX_NA * (max_d + 1) + (SU_MAX_NA + 1) * (SU_MAX_NA + 1) + SU_MAX_NA * SU_MAX_NA + SU_CH * (SU_MAX_NA + 1)) * sizeof(double);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_small_update), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
+    hipLaunchKernelGGL(k_ekf_small_update, dim3(1, n), dim3(256), lds, st, d);
+}
+int ekf_small_update_max_na(void) { return SU_MAX_NA; }
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
     // the solve runs over the active rows only: n <= max_d - 21 (the IMU columns are never active).  A full 64-clone
