@@ -12,6 +12,7 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, int max_clones, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
+void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
@@ -420,9 +421,10 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
     hipStream_t st = ctx->stream;
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
-    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0, max_na_bound = 0;
+    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0, max_na_bound = 0, max_tri = 0;
+    bool all_pairs = true;     // every feature of the batch has exactly two Jacobian observations of ONE clone pair per stream
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
-    struct Lay { size_t clones, feats, obs_clone, obs_z; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
+    struct Lay { size_t clones, feats, obs_clone, obs_z, tri; int n_tri; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
     std::vector<Lay> lay(n);
     size_t in_bytes = 0, out_bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -436,8 +438,11 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         Lay &L = lay[i];
         int m_total = 0;
         unsigned long long clone_mask = 0ULL;          // clones any Jacobian block of this stream touches: bounds the active columns
+        int n_tri = 0;
         for (int j = 0; j < a.n_feat; ++j) {
             const mskf_ekf_feature &f = a.features[j];
+            n_tri += f.needs_init ? 1 : 0;
+            if (f.n_obs != 2) all_pairs = false;
             if (f.n_obs < 2 || f.n_obs > E.max_clones || f.obs_start < 0 || f.obs_start + f.n_obs > a.n_obs) return MSKF_ERR_INVALID;
             if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
             m_total += 4 * f.n_obs - 3;
@@ -461,7 +466,8 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         L.feats = align_up(L.clones + sizeof(mskf_clone_state) * (size_t)a.n_clones, 16);
         L.obs_clone = align_up(L.feats + sizeof(EkfFeatDev) * (size_t)a.n_feat, 16);
         L.obs_z = align_up(L.obs_clone + sizeof(int) * (size_t)a.n_obs, 16);
-        in_bytes = align_up(L.obs_z + sizeof(double) * 4 * (size_t)a.n_obs, 64);
+        L.tri = align_up(L.obs_z + sizeof(double) * 4 * (size_t)a.n_obs, 16);
+        in_bytes = align_up(L.tri + sizeof(int) * (size_t)n_tri, 64);
         L.o_dx = out_bytes;
         L.o_gamma = align_up(L.o_dx + sizeof(double) * (size_t)E.ld, 16);
         L.o_pos = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
@@ -479,6 +485,9 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             E.max_rows = cap;
         }
         max_na_bound = std::max(max_na_bound, 6 * __builtin_popcountll(clone_mask));
+        if (a.n_feat > 0 && __builtin_popcountll(clone_mask) != 2) all_pairs = false;
+        L.n_tri = n_tri;
+        max_tri = std::max(max_tri, n_tri);
         max_feat = std::max(max_feat, a.n_feat);
         max_m = std::max(max_m, m_total);
         max_d = std::max(max_d, E.d);
@@ -495,6 +504,8 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         const Lay &L = lay[i];
         if (a.n_clones) std::memcpy(hin + L.clones, a.clones, sizeof(mskf_clone_state) * (size_t)a.n_clones);
         EkfFeatDev *fd = (EkfFeatDev *)(hin + L.feats);
+        int *tri = (int *)(hin + L.tri);
+        int n_tri_w = 0;
         int row = 0;
         for (int j = 0; j < a.n_feat; ++j) {
             const mskf_ekf_feature &f = a.features[j];
@@ -504,6 +515,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             fd[j].position[0] = f.position[0]; fd[j].position[1] = f.position[1]; fd[j].position[2] = f.position[2];
             fd[j].colmask = 0ULL;
             row += 4 * f.n_obs - 3;
+            if (f.needs_init) tri[n_tri_w++] = j;
         }
         if (a.n_obs) {
             std::memcpy(hin + L.obs_clone, a.obs_clone, sizeof(int) * (size_t)a.n_obs);
@@ -519,6 +531,8 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         D.feats = (EkfFeatDev *)(din + L.feats);
         D.obs_clone = (const int *)(din + L.obs_clone);
         D.obs_z = (const double *)(din + L.obs_z);
+        D.tri_idx = (const int *)(din + L.tri);
+        D.n_tri = L.n_tri;
         D.delta_x = (double *)(dout + L.o_dx);
         D.gamma = (double *)(dout + L.o_gamma);
         D.pos_out = (double *)(dout + L.o_pos);
@@ -529,7 +543,8 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         MSKF_HIPCHK(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
-        ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, (max_d - 21) / 6, st);
+        if (all_pairs) ekf_launch_pair_features(ctx->ekf_desc.d, n, max_feat, max_tri, st);      // the pruning update
+        else ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, (max_d - 21) / 6, st);
         mskf_t_end(ctx, ts, (long long)fl_feat);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);

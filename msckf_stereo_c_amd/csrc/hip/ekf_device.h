@@ -49,6 +49,8 @@ struct EkfStreamDev {
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
     double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
+    const int *tri_idx;       // features that need triangulation (pair path: k_ekf_triangulate), n_tri of them
+    int n_tri;
     int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)

@@ -765,6 +765,230 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
     }
 }
 
+// ------------------------------------------------------------------------------------ pair features (pruning update)
+// The pruning update (msckf_vio.cpp:1073-1153) hands over hundreds of features per stream that all have exactly TWO
+// Jacobian observations: the two clones being removed.  A workgroup (or even a wavefront) per feature is almost all
+// latency there, so this path gives every feature ONE THREAD: triangulation of the not yet initialised ones first
+// (k_ekf_triangulate, one wavefront per such feature, the same Levenberg-Marquardt routine), then k_ekf_pair_blocks with
+// the feature's 8 x 13 block [H_x | r] and its reflectors in a private LDS slab.  Same algebra as k_ekf_feature_blocks:
+// per-observation Jacobians with the observability projection, three Householder reflectors of H_f, rows 3..7 of
+// Q^T [H_x | r] written in the twelve columns of the two clones + the residual column, gate on
+// gamma = r_o^T (H_o P_cc H_o^T + sigma^2 I)^-1 r_o against chi2[2 + dof_offset].
+__global__ __launch_bounds__(64) void k_ekf_triangulate(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    __shared__ TriScratch sTri;
+    for (int t = blockIdx.x; t < S.n_tri; t += gridDim.x) {
+        const int j = S.tri_idx[t];
+        EkfFeatDev &F = S.feats[j];
+        double pos[3] = {F.position[0], F.position[1], F.position[2]};
+        __syncthreads();
+        const bool valid = triangulate_wave(S, F, sTri, pos);
+        if (threadIdx.x == 0) {
+            F.position[0] = pos[0]; F.position[1] = pos[1]; F.position[2] = pos[2];
+            S.feat_status[j] = valid ? 1 : 0;
+        }
+    }
+}
+
+#define PAIR_SLAB 153          // doubles per thread: X 8 x 13 (104) + H_f 8 x 3 (24) + V 3 x 8 (24) + 1 (odd stride: no bank conflicts)
+__global__ __launch_bounds__(64) void k_ekf_pair_blocks(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    const int d = S.d, ld = S.ld;
+    extern __shared__ double s_pair[];
+    __shared__ double sPcc[12 * 12];
+    __shared__ double sRw[2][2][9], sTc1[2][3], sRn[2][9];     // per clone of the pair: R_w_c0, R_w_c1, t_c1_w, R(q_null)
+    __shared__ int sPair[2];
+    double *X = s_pair + (size_t)threadIdx.x * PAIR_SLAB;       // [8][13]: H_x of obs 0 in columns 0..5, obs 1 in 6..11, r in 12
+    double *Hf = X + 104;                                        // [8][3]
+    double *V = Hf + 24;                                         // [3][8]
+    for (int base = blockIdx.x * 64; base < S.n_feat; base += gridDim.x * 64) {
+        const int j = base + threadIdx.x;
+        const bool have = j < S.n_feat;
+        // the clone pair of the first feature of this batch; P_cc and the clone rotations are shared by every feature with that pair
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const EkfFeatDev &F0 = S.feats[base];
+            sPair[0] = S.obs_clone[F0.obs_start]; sPair[1] = S.obs_clone[F0.obs_start + 1];
+        }
+        __syncthreads();
+        const int pa = sPair[0], pb = sPair[1];
+        for (int e = threadIdx.x; e < 144; e += 64) {
+            const int u = e / 12, v = e - 12 * u;
+            const int cu = EKF_IMU_DIM + 6 * (u < 6 ? pa : pb) + (u % 6), cv = EKF_IMU_DIM + 6 * (v < 6 ? pa : pb) + (v % 6);
+            sPcc[e] = S.P[(size_t)cu * ld + cv];
+        }
+        if (threadIdx.x < 2) {
+            const mskf_clone_state &cam = S.clones[threadIdx.x == 0 ? pa : pb];
+            double R0[9], R1[9], tmp[3];
+            quat_to_rot(cam.q, R0);
+            mat3_mul(S.R_c0_c1, R0, R1);
+            mat3t_vec(R1, S.t_c0_c1, tmp);
+            for (int i = 0; i < 9; ++i) { sRw[threadIdx.x][0][i] = R0[i]; sRw[threadIdx.x][1][i] = R1[i]; }
+            for (int i = 0; i < 3; ++i) sTc1[threadIdx.x][i] = cam.p[i] - tmp[i];
+            quat_to_rot(cam.q_null, R0);
+            for (int i = 0; i < 9; ++i) sRn[threadIdx.x][i] = R0[i];
+        }
+        __syncthreads();
+        if (!have) continue;
+        EkfFeatDev &F = S.feats[j];
+        const int c0 = S.obs_clone[F.obs_start], c1 = S.obs_clone[F.obs_start + 1];
+        const bool valid = F.needs_init ? (S.feat_status[j] & 1) != 0 : true;
+        const double pos[3] = {F.position[0], F.position[1], F.position[2]};
+        S.pos_out[3 * j] = pos[0]; S.pos_out[3 * j + 1] = pos[1]; S.pos_out[3 * j + 2] = pos[2];
+        if (!valid || F.n_obs != 2 || c0 != pa || c1 != pb) {      // (a foreign pair cannot happen: the host checks the batch)
+            S.feat_status[j] = 0; S.gamma[j] = -1.0; F.colmask = 0ULL;
+            continue;
+        }
+        // ---- per-observation Jacobians (msckf_vio.cpp:610-677)
+        for (int i = 0; i < 104; ++i) X[i] = 0.0;
+        const double g[3] = {S.gravity[0], S.gravity[1], S.gravity[2]};
+#pragma unroll 1
+        for (int ob = 0; ob < 2; ++ob) {
+            const mskf_clone_state &cam = S.clones[ob == 0 ? pa : pb];
+            const double *R_w_c0 = sRw[ob][0], *R_w_c1 = sRw[ob][1];
+            const double dp0[3] = {pos[0] - cam.p[0], pos[1] - cam.p[1], pos[2] - cam.p[2]};
+            const double dp1[3] = {pos[0] - sTc1[ob][0], pos[1] - sTc1[ob][1], pos[2] - sTc1[ob][2]};
+            double p_c0[3], p_c1[3];
+            mat3_vec(R_w_c0, dp0, p_c0);
+            mat3_vec(R_w_c1, dp1, p_c1);
+            const double dz[4][3] = {{1 / p_c0[2], 0, -p_c0[0] / (p_c0[2] * p_c0[2])},
+                                     {0, 1 / p_c0[2], -p_c0[1] / (p_c0[2] * p_c0[2])},
+                                     {1 / p_c1[2], 0, -p_c1[0] / (p_c1[2] * p_c1[2])},
+                                     {0, 1 / p_c1[2], -p_c1[1] / (p_c1[2] * p_c1[2])}};
+            const double sk[9] = {0, -p_c0[2], p_c0[1], p_c0[2], 0, -p_c0[0], -p_c0[1], p_c0[0], 0};
+            double Rsk[9];
+            mat3_mul(S.R_c0_c1, sk, Rsk);
+            double *Xb = X + (4 * ob) * 13 + 6 * ob;          // this observation's 4 x 6 block inside X (row stride 13)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double l0 = rr < 2 ? sk[c] : Rsk[c], l1 = rr < 2 ? sk[3 + c] : Rsk[3 + c], l2 = rr < 2 ? sk[6 + c] : Rsk[6 + c];
+                    const double m0 = rr < 2 ? R_w_c0[c] : R_w_c1[c], m1 = rr < 2 ? R_w_c0[3 + c] : R_w_c1[3 + c], m2 = rr < 2 ? R_w_c0[6 + c] : R_w_c1[6 + c];
+                    Xb[rr * 13 + c] = dz[rr][0] * l0 + dz[rr][1] * l1 + dz[rr][2] * l2;
+                    Xb[rr * 13 + 3 + c] = -(dz[rr][0] * m0 + dz[rr][1] * m1 + dz[rr][2] * m2);
+                }
+            }
+            double u[6];
+            mat3_vec(sRn[ob], g, u);
+            const double dn[3] = {pos[0] - cam.p_null[0], pos[1] - cam.p_null[1], pos[2] - cam.p_null[2]};
+            u[3] = dn[1] * g[2] - dn[2] * g[1]; u[4] = dn[2] * g[0] - dn[0] * g[2]; u[5] = dn[0] * g[1] - dn[1] * g[0];
+            double uu = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) uu += u[k] * u[k];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                double Au = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Au += Xb[rr * 13 + k] * u[k];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double h = Xb[rr * 13 + c] - Au * (1.0 / uu) * u[c];
+                    Xb[rr * 13 + c] = h;
+                    if (c >= 3) Hf[(4 * ob + rr) * 3 + (c - 3)] = -h;
+                }
+            }
+            const double *z = S.obs_z + 4 * (F.obs_start + ob);
+            X[(4 * ob + 0) * 13 + 12] = z[0] - p_c0[0] / p_c0[2];
+            X[(4 * ob + 1) * 13 + 12] = z[1] - p_c0[1] / p_c0[2];
+            X[(4 * ob + 2) * 13 + 12] = z[2] - p_c1[0] / p_c1[2];
+            X[(4 * ob + 3) * 13 + 12] = z[3] - p_c1[1] / p_c1[2];
+        }
+        // ---- three Householder reflectors of H_f, applied to H_f's remaining columns and to [H_x | r] (:757-766)
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            double nrm2 = 0;
+            for (int i = k; i < 8; ++i) nrm2 += Hf[i * 3 + k] * Hf[i * 3 + k];
+            const double nrm = sqrt(nrm2);
+            const double x0 = Hf[k * 3 + k];
+            const double alpha = x0 > 0 ? -nrm : nrm;
+            double vn = 0;
+            for (int i = 0; i < 8; ++i) {
+                const double v = (i < k) ? 0.0 : (i == k ? x0 - alpha : Hf[i * 3 + k]);
+                V[k * 8 + i] = v;
+                vn += v * v;
+            }
+            const double beta = (nrm == 0.0 || vn == 0.0) ? 0.0 : 2.0 / vn;
+            for (int c = k + 1; c < 3; ++c) {
+                double sdot = 0;
+                for (int i = k; i < 8; ++i) sdot += V[k * 8 + i] * Hf[i * 3 + c];
+                sdot *= beta;
+                for (int i = k; i < 8; ++i) Hf[i * 3 + c] -= sdot * V[k * 8 + i];
+            }
+#pragma unroll 1
+            for (int c = 0; c < 13; ++c) {
+                double sdot = 0;
+                for (int i = k; i < 8; ++i) sdot += V[k * 8 + i] * X[i * 13 + c];
+                sdot *= beta;
+                for (int i = k; i < 8; ++i) X[i * 13 + c] -= sdot * V[k * 8 + i];
+            }
+        }
+        // ---- gate: S_g = H_o P_cc H_o^T + sigma^2 I on rows 3..7, gamma = r_o^T S_g^-1 r_o (:909-935)
+        // H_o P_cc (5 x 12) goes into the dead part of the slab: rows 0..2 of X and H_f
+        double Sg[5][5];
+        {
+#pragma unroll 1
+            for (int i = 0; i < 5; ++i) {
+                double *hp = i < 3 ? X + 12 * i : Hf + 12 * (i - 3);
+#pragma unroll 1
+                for (int v = 0; v < 12; ++v) {
+                    double t = 0;
+                    for (int u2 = 0; u2 < 12; ++u2) t += X[(3 + i) * 13 + u2] * sPcc[u2 * 12 + v];
+                    hp[v] = t;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double *hp = i < 3 ? X + 12 * i : Hf + 12 * (i - 3);
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) {
+                    if (jj > i) continue;
+                    double t = 0;
+#pragma unroll 1
+                    for (int v = 0; v < 12; ++v) t += hp[v] * X[(3 + jj) * 13 + v];
+                    Sg[i][jj] = t + (i == jj ? S.sigma2 : 0.0);
+                }
+            }
+        }
+        bool pd_ok = true;
+        double y[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) y[i] = X[(3 + i) * 13 + 12];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const double dk = Sg[k][k];
+            pd_ok = pd_ok && (dk > 0);
+            const double inv = 1.0 / sqrt(dk > 0 ? dk : 1.0);
+#pragma unroll
+            for (int i = k; i < 5; ++i) Sg[i][k] *= inv;
+            y[k] *= inv;
+#pragma unroll
+            for (int a = k + 1; a < 5; ++a) {
+#pragma unroll
+                for (int b = k + 1; b <= a; ++b) Sg[a][b] -= Sg[a][k] * Sg[b][k];
+                y[a] -= Sg[a][k] * y[k];
+            }
+        }
+        double gamma = 1e300;
+        if (pd_ok) { gamma = 0; for (int i = 0; i < 5; ++i) gamma += y[i] * y[i]; }
+        const int dof = 2 + S.dof_offset;
+        const bool pass = pd_ok && dof >= 1 && dof < 100 && gamma < S.chi2[dof];
+        // ---- the projected block: rows 3..7, the twelve columns of the pair + the residual column
+        double *Hrow0 = S.Hs + (size_t)F.row_off * ld;
+        for (int i = 0; i < 5; ++i) {
+            double *out = Hrow0 + (size_t)i * ld;
+            for (int c = 0; c < 6; ++c) {
+                out[EKF_IMU_DIM + 6 * pa + c] = X[(3 + i) * 13 + c];
+                out[EKF_IMU_DIM + 6 * pb + c] = X[(3 + i) * 13 + 6 + c];
+            }
+            out[d] = X[(3 + i) * 13 + 12];
+        }
+        S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0));
+        S.gamma[j] = gamma;
+        F.colmask = pass ? ((1ULL << pa) | (1ULL << pb)) : 0ULL;
+    }
+}
+
 // ------------------------------------------------------------------------------------ cap
 // msckf_vio.cpp:1002-1010: stack the passing blocks in feature order and stop once the stacked rows exceed the cap
 // (the block that crosses it is still stacked).  Parallel form: every thread owns a contiguous run of features, the
@@ -873,6 +1097,19 @@ void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_row
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
     if (max_rows <= 4 * 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false>), dim3(slots, n), dim3(WG), lds, st, d, lds_rows, 0);
     else hipLaunchKernelGGL((k_ekf_feature_blocks<MAX_CLONES_DEV, false>), dim3(slots, n), dim3(WG), lds, st, d, lds_rows, 0);
+}
+// pruning update: every feature of every stream has exactly two Jacobian observations (the host checked)
+void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st) {
+    if (max_tri > 0) {
+        const int slots = max_tri < 256 ? max_tri : 256;
+        hipLaunchKernelGGL(k_ekf_triangulate, dim3(slots, n), dim3(64), 0, st, d);
+    }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, []() {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_pair_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * PAIR_SLAB * 8);
+    });
+    const int blocks = (max_feat + 63) / 64;
+    hipLaunchKernelGGL(k_ekf_pair_blocks, dim3(blocks, n), dim3(64), (size_t)64 * PAIR_SLAB * sizeof(double), st, d);
 }
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_posvar, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n, out);

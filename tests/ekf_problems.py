@@ -16,7 +16,8 @@ def small_quat(rng, scale):
     return q / np.linalg.norm(q)
 
 
-def make_problem(calib, seed=0, n_clones=10, n_feat=12, min_obs=3, noise=0.002, null_perturb=1e-3, p_scale=1e-3):
+def make_problem(calib, seed=0, n_clones=10, n_feat=12, min_obs=3, noise=0.002, null_perturb=1e-3, p_scale=1e-3, pair=None):
+    """pair = (ka, kb): every feature is observed by exactly these two clones (the pruning update's shape)."""
     rng = np.random.default_rng(seed)
     T01 = np.array(calib.T_cam1_cam0).reshape(4, 4)
     R01, t01 = T01[:3, :3], T01[:3, 3]
@@ -33,7 +34,7 @@ def make_problem(calib, seed=0, n_clones=10, n_feat=12, min_obs=3, noise=0.002, 
         pw = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(3.0, 8.0)])
         m = int(rng.integers(min_obs, n_clones + 1))
         start = int(rng.integers(0, n_clones - m + 1))
-        for ci in range(start, start + m):
+        for ci in (range(start, start + m) if pair is None else pair):
             R = quat_to_rot(clones[ci, 0:4])
             pc0 = R @ (pw - clones[ci, 4:7])
             pc1 = R01 @ pc0 + t01

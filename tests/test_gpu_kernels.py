@@ -213,6 +213,38 @@ def test_ekf_update_matches_oracle(gpu_ctx, oracle, n_clones, n_feat, seed, dof_
     s.close()
 
 
+@pytest.mark.parametrize("n_clones,n_feat,pair,seed", [(30, 400, (3, 4), 31), (12, 70, (0, 1), 32), (20, 5, (17, 18), 33)])
+def test_ekf_pruning_update_pair_path(gpu_ctx, oracle, n_clones, n_feat, pair, seed):
+    """The pruning update's shape (msckf_vio.cpp:1073-1153): hundreds of features, each observed by exactly the two
+    clones being removed, dof = 2, no row cap.  On the device that is the thread-per-feature kernel k_ekf_pair_blocks
+    and the fused k_ekf_small_update (12 active columns); gates, gains and covariance against the oracle's generic
+    featureJacobian / measurementUpdate."""
+    s, calib = _stream(gpu_ctx, oracle, 376, 240, max_cam_state_size=n_clones)
+    cfg = default_ekf_cfg(max_cam_state_size=n_clones)
+    pr = ekf_problems.make_problem(calib, seed=seed, n_clones=n_clones, n_feat=n_feat, pair=pair, noise=0.004)
+    ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"],
+                                    pr["obs_clone"], pr["obs_z"], 0)
+    s.ekf_set_cov(pr["P"])
+    got = s.ekf_update(pr["gravity"], pr["clones"], pr["positions"], pr["obs_start"], pr["obs_clone"], pr["obs_z"], 0, False)
+    assert np.allclose(got["gamma"], ref["gamma"], rtol=1e-7)
+    assert np.array_equal((got["status"] >> 1) & 1, ref["passed"])
+    assert 0 < ref["passed"].sum() and got["rows"] == ref["rows"] == 5 * ref["passed"].sum()
+    scale = np.abs(ref["delta_x"]).max()
+    assert np.allclose(got["delta_x"], ref["delta_x"], rtol=1e-6, atol=1e-9 * max(scale, 1e-3))
+    Pg = s.ekf_get_cov()
+    assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 1e-8
+    assert np.array_equal(Pg, Pg.T)
+    # the same through triangulation on the device (k_ekf_triangulate): positions from the two stereo views only
+    s.ekf_set_cov(pr["P"])
+    pos_ref, valid_ref = oracle.triangulate(calib, pr["clones"], pr["obs_start"], pr["obs_clone"], pr["obs_z"])
+    got2 = s.ekf_update(pr["gravity"], pr["clones"], None, pr["obs_start"], pr["obs_clone"], pr["obs_z"], 0, False,
+                        needs_init=np.ones(n_feat, np.int32))
+    assert np.array_equal(got2["status"] & 1, valid_ref)
+    v = valid_ref.astype(bool)
+    assert np.allclose(got2["positions"][v], pos_ref[v], rtol=1e-6, atol=1e-8)
+    s.close()
+
+
 def test_triangulation_matches_oracle(gpu_ctx, oracle):
     n_clones = 12
     s, calib = _stream(gpu_ctx, oracle, 376, 240, max_cam_state_size=n_clones)
