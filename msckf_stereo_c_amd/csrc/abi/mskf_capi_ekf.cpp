@@ -555,6 +555,10 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
             ekf_launch_small_update(ctx->ekf_desc.d, n, max_d, st);
             mskf_t_end(ctx, ts, (long long)(fl_qr + fl_upd));
+            enum { GM_PUPD = 3 };
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
+            mskf_t_end(ctx, ts, 0);
         } else {
             // QR compression as Gram + semidefinite Cholesky, then the Kalman update (ekf_linalg.hip)
             enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };

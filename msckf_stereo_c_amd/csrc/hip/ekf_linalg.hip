@@ -66,12 +66,13 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         // the K range split over the 8 thread rows and reduced through LDS
         const int c0 = (tile - tiles_m * tiles_n) * GT;
         if (c0 >= d) return;
+        const double *Y = S.T;
         __shared__ double s_part[8][GT + 1];
         const int cl = threadIdx.x & 31, ks = threadIdx.x >> 5;
         const int c = c0 + cl;
         double s2 = 0;
         if (c < d)
-            for (int k = ks; k < na; k += 8) s2 += S.T[(size_t)k * ld + c] * S.T[(size_t)k * ld + d];
+            for (int k = ks; k < na; k += 8) s2 += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
         s_part[ks][cl] = s2;
         __syncthreads();
         if (ks == 0 && c < d) {
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     int k_begin = 0;
     if (TR::KMIN_I) k_begin = (i0 / GK) * GK;
     if (TR::KMIN_J) k_begin = (j0 / GK) * GK;
+    const int k_end = K;
     // gathered source columns of this thread's fixed (i = lo / j = lo) operand lanes
     int colA = i0 + lo, colB = j0 + lo;
     if (MODE == GM_GRAM) {
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         }
     };
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    if (k_begin < K) fetch(k_begin);
-    for (int k0 = k_begin; k0 < K; k0 += GK) {
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += GK) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
             sB[hi + 8 * e][lo] = rb[e];
         }
         __syncthreads();
-        if (k0 + GK < K) fetch(k0 + GK);
+        if (k0 + GK < k_end) fetch(k0 + GK);
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             const int kk = 4 * s + (lane >> 4);
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
 // T = L^T[0:na,0:na] P[act,:], S = T[:,act] L[0:na,0:na] + sigma^2 I = L2 L2^T, Y = L2^-1 [T | Q^T r],
 // delta_x = Y^T w, P -= Y^T Y (symmetric by construction).  All sums run in a fixed order (no atomics).
 #define SU_MAX_NA 24
-#define SU_CH 64          // stacked rows per Gram chunk
+#define SU_CH 128         // stacked rows per Gram chunk
 __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
@@ -426,12 +428,17 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         s_clone[tid] = tid < na ? (col - EKF_IMU_DIM) / 6 : -1;
     }
     __syncthreads();
-    // ---- 1. Gram matrix, pairs (i >= j) over the threads, rows in order
+    // ---- 1. Gram matrix: pairs (i >= j) over the threads; with few pairs (the pruning update: 91) the threads also split
+    //         the rows of a chunk into `groups` interleaved sets, summed in a fixed order at the end
     const int np = n1 * (n1 + 1) / 2;
-    int pi[2], pj[2];
+    const int groups = np <= 128 ? 256 / np : 1;
+    int pi[2], pj[2], pg[2];
     double acc[2] = {0.0, 0.0};
     for (int q = 0; q < 2; ++q) {
-        const int p = tid + 256 * q;
+        int p = tid + 256 * q, grp = 0;
+        if (groups > 1) { grp = q == 0 ? tid / np : groups; p = tid - grp * np; }
+        pg[q] = (groups > 1) ? (grp < groups ? grp : -1) : (p < np ? 0 : -1);
+        if (pg[q] < 0) p = 0;
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= p) ++i;
         pi[q] = i; pj[q] = p - i * (i + 1) / 2;
@@ -450,14 +457,27 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
         __syncthreads();
         for (int q = 0; q < 2; ++q) {
-            if (tid + 256 * q >= np) continue;
+            if (pg[q] < 0) continue;
             double a = acc[q];
-            for (int r = 0; r < SU_CH; ++r) a += sC[r * n1 + pi[q]] * sC[r * n1 + pj[q]];
+            for (int r = pg[q]; r < SU_CH; r += groups) a += sC[r * n1 + pi[q]] * sC[r * n1 + pj[q]];
             acc[q] = a;
         }
     }
-    for (int q = 0; q < 2; ++q)
-        if (tid + 256 * q < np) { sG[pi[q] * n1 + pj[q]] = acc[q]; sG[pj[q] * n1 + pi[q]] = acc[q]; }
+    __syncthreads();
+    if (groups > 1) {
+        // sC is free now: partial sums [group][pair], reduced by group 0's threads in group order
+        if (pg[0] >= 0) sC[pg[0] * np + (pi[0] * (pi[0] + 1) / 2 + pj[0])] = acc[0];
+        __syncthreads();
+        if (pg[0] == 0) {
+            const int p = pi[0] * (pi[0] + 1) / 2 + pj[0];
+            double t = 0.0;
+            for (int g2 = 0; g2 < groups; ++g2) t += sC[g2 * np + p];
+            sG[pi[0] * n1 + pj[0]] = t; sG[pj[0] * n1 + pi[0]] = t;
+        }
+    } else {
+        for (int q = 0; q < 2; ++q)
+            if (pg[q] >= 0) { sG[pi[q] * n1 + pj[q]] = acc[q]; sG[pj[q] * n1 + pi[q]] = acc[q]; }
+    }
     __syncthreads();
     // ---- 2. G + lambda I = L L^T (lambda as in k_ekf_chol_lds), the Q^T r row rides along as row na
     if (tid == 0) { double mx = 0; for (int i = 0; i < na; ++i) mx = fmax(mx, sG[i * n1 + i]); s_lam = mx * (double)d * 1e-14; }
@@ -533,25 +553,11 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
     }
     __syncthreads();
-    // ---- 7. delta_x = Y^T w (msckf_vio.cpp:860), P <- P - Y^T Y (:897-904): thread = column j, rows i >= j, mirrored
-    double *Pw = S.P;
-    for (int j = tid; j < d; j += 256) {
-        double yj[SU_MAX_NA];
-        double dx = 0.0;
-#pragma unroll
-        for (int k = 0; k < SU_MAX_NA; ++k) {
-            yj[k] = k < na ? sT[k * (d + 1) + j] : 0.0;
-            if (k < na) dx += yj[k] * sT[k * (d + 1) + d];
-        }
-        S.delta_x[j] = dx;
-        for (int i = j; i < d; ++i) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < SU_MAX_NA; ++k) if (k < na) t += sT[k * (d + 1) + i] * yj[k];
-            const double v = Pw[(size_t)i * ld + j] - t;
-            Pw[(size_t)i * ld + j] = v;
-            if (i != j) Pw[(size_t)j * ld + i] = v;
-        }
+    // ---- 7. Y goes to the stream's T buffer (ld-wide rows): delta_x = Y^T w (msckf_vio.cpp:860) and P <- P - Y^T Y
+    //         (:897-904) are the tile-parallel GM_PUPD launch that follows
+    for (int e = tid; e < na * (d + 1); e += 256) {
+        const int k = e / (d + 1), c = e - k * (d + 1);
+        S.T[(size_t)k * ld + c] = sT[e];
     }
 }
 
