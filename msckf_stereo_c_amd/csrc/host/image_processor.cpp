@@ -56,16 +56,14 @@ mskf_fe_cfg fe_cfg_from_yaml(const YAML::Node &y) {
 }
 
 ImageProcessor::ImageProcessor(YAML::Node cfg_cam_imu)
-    : feature_msg_ptr_(new CameraMeasurement), cfg_cam_imu_(cfg_cam_imu), have_yaml_(true),
-      prev_features_ptr(new GridFeatures()), curr_features_ptr(new GridFeatures()) {
+    : feature_msg_ptr_(new CameraMeasurement), cfg_cam_imu_(cfg_cam_imu), have_yaml_(true) {
     std::memset(&calib_, 0, sizeof(calib_));
     std::memset(&cfg_, 0, sizeof(cfg_));
     std::memset(&processor_config, 0, sizeof(processor_config));
 }
 
 ImageProcessor::ImageProcessor(const mskf_calib &calib, const mskf_fe_cfg &cfg)
-    : feature_msg_ptr_(new CameraMeasurement), calib_(calib), cfg_(cfg),
-      prev_features_ptr(new GridFeatures()), curr_features_ptr(new GridFeatures()) {
+    : feature_msg_ptr_(new CameraMeasurement), calib_(calib), cfg_(cfg) {
     std::memset(&processor_config, 0, sizeof(processor_config));
 }
 
@@ -133,6 +131,9 @@ void ImageProcessor::phaseBegin(double time_stamp, int width, int height) {
         grid_width = width / cfg_.grid_col;
         det_cell_h = (height + cfg_.det_rows - 1) / cfg_.det_rows;
         det_cell_w = (width + cfg_.det_cols - 1) / cfg_.det_cols;
+        // largest grid code a point inside the image can get (Q7: rows / columns past the nominal grid exist when the
+        // image size is not a multiple of the grid)
+        n_codes_ = std::max(((height - 1) / grid_height) * cfg_.grid_col + (width - 1) / grid_width + 1, cfg_.grid_row * cfg_.grid_col);
     }
 }
 
@@ -248,26 +249,18 @@ void ImageProcessor::phasePrepare1(mskf_fe_track_args &args) {
         std::vector<Point2f> det;
         detectFeatures(det, cand_responses_det_);
         in_pts_.resize(det.size());
-        for (size_t i = 0; i < det.size(); ++i) in_pts_[i] = mskf_point2f{det[i].x, det[i].y};
+        cand_index_.resize(det.size());
+        for (size_t i = 0; i < det.size(); ++i) { in_pts_[i] = mskf_point2f{det[i].x, det[i].y}; cand_index_[i] = (int)i; }
         fill_args(args, (int)in_pts_.size(), 0, in_pts_, out0_, out1_, und0_, und1_, status_);
         stage_ = 1;
         return;
     }
-    // trackFeatures head (:352-410)
+    // trackFeatures head (:352-410): the previous grid in iteration order is exactly what prev_ holds
     hostprof::Scope hp(hostprof::FE_PREPARE);
     hm::Mat3 cam0_R_p_c, cam1_R_p_c;
     integrateImuData(cam0_R_p_c, cam1_R_p_c);
     cam0_R_p_c_ = cam0_R_p_c; cam1_R_p_c_ = cam1_R_p_c;
-    const bool ransac = !(cfg_.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC);
-    t_ids_.clear(); t_lifetime_.clear(); in_pts_.clear(); t_und0_.clear(); t_und1_.clear();
-    for (const auto &item : *prev_features_ptr)
-        for (const auto &pf : item.second) {
-            t_ids_.push_back(pf.id);
-            t_lifetime_.push_back(pf.lifetime);
-            in_pts_.push_back(mskf_point2f{pf.cam0_point.x, pf.cam0_point.y});
-            if (ransac) { t_und0_.push_back(pf.und0); t_und1_.push_back(pf.und1); }
-        }
-    fill_args(args, (int)in_pts_.size(), 1, in_pts_, out0_, out1_, und0_, und1_, status_);
+    fill_args(args, (int)prev_.size(), 1, prev_.cam0, out0_, out1_, und0_, und1_, status_);
     computeHpred(cam0_R_p_c, args.Hpred);
     stage_ = 2;
 }
@@ -283,47 +276,52 @@ static void small_stable_sort(It b, It e, Cmp cmp) {
         for (It j = i; j != b && cmp(*j, *(j - 1)); --j) std::iter_swap(j, j - 1);
 }
 
-// empty every cell list but keep the storage (and the keys) of the map
-void ImageProcessor::resetGrid(GridFeatures &g) const {
-    for (auto &kv : g) kv.second.clear();
-    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) g[code];
-}
-
-// :270-316
-void ImageProcessor::initializeFirstFrameTail() {
-    GridFeatures &grid_new_features = grid_new_features_;
-    resetGrid(grid_new_features);
+// Matched candidates (status bit 1) grouped by grid code, the best `vacancy` of every cell by response (stable: Q19) get
+// the next ids in code order (:700-750; first frame :270-316 with every cell empty).  Candidates arrive in ascending code
+// order already (the sieve emits them cell by cell, detections of the first frame are binned here).
+void ImageProcessor::selectNewFeatures(bool first_frame) {
+    const bool q4 = (cfg_.compat_flags & MSKF_COMPAT_Q4_RESPONSE_INDEX) != 0;
+    const int n_cells = cfg_.grid_row * cfg_.grid_col;
+    new_.clear();
+    // (code, response, index) of the matched candidates
+    struct Cand { int code; float response; int idx; };
+    std::vector<Cand> cands;
+    cands.reserve(status_.size());
     for (size_t i = 0; i < status_.size(); ++i) {
         if (!(status_[i] & 2)) continue;
-        FeatureMetaData nf;
-        nf.id = 0; nf.lifetime = 0;
-        nf.response = (float)cand_responses_det_[i];
-        nf.cam0_point = Point2f(out0_[i].x, out0_[i].y);
-        nf.cam1_point = Point2f(out1_[i].x, out1_[i].y);
-        nf.und0 = Point2f(und0_[i].x, und0_[i].y);
-        nf.und1 = Point2f(und1_[i].x, und1_[i].y);
-        int row = static_cast<int>(nf.cam0_point.y / grid_height);
-        int col = static_cast<int>(nf.cam0_point.x / grid_width);
-        grid_new_features[row * cfg_.grid_col + col].push_back(nf);
+        const double resp = first_frame ? cand_responses_det_[i] : (q4 ? cand_responses_det_[cand_index_[i]] : cand_responses_sieved_[i]);   // Q4 (:698)
+        cands.push_back(Cand{gridCode(out0_[i]), (float)resp, (int)i});
     }
-    for (auto &item : grid_new_features)   // Q19: stable sort is the defined behaviour
-        small_stable_sort(item.second.begin(), item.second.end(),
-                          [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
-    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) {
-        std::vector<FeatureMetaData> &features_this_grid = (*curr_features_ptr)[code];
-        std::vector<FeatureMetaData> &new_features_this_grid = grid_new_features[code];
-        for (int k = 0; k < cfg_.grid_min_feature_num && k < (int)new_features_this_grid.size(); ++k) {
-            features_this_grid.push_back(new_features_this_grid[k]);
-            features_this_grid.back().id = next_feature_id++;
-            features_this_grid.back().lifetime = 1;
+    // ascending code, then descending response; stable, so equal responses keep their candidate order
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.code != b.code ? a.code < b.code : a.response > b.response; });
+    for (size_t k = 0; k < cands.size();) {
+        const int code = cands[k].code;
+        size_t e = k;
+        while (e < cands.size() && cands[e].code == code) ++e;
+        if (code >= 0 && code < n_cells) {        // only the nominal cells are filled (:736)
+            const int have = first_frame ? 0 : cell_count_[code];
+            const int vacancy = cfg_.grid_min_feature_num - have;
+            for (int q = 0; q < vacancy && k + q < e; ++q) {
+                const int i = cands[k + q].idx;
+                new_.push(next_feature_id++, 1, code, cands[k + q].response, out0_[i], out1_[i], und0_[i], und1_[i]);
+            }
         }
+        k = e;
     }
+}
+
+void ImageProcessor::initializeFirstFrameTail() {
+    tracked_.clear();
+    cell_count_.assign(n_codes_, 0);
+    selectNewFeatures(true);
 }
 
 // :416-513
 void ImageProcessor::trackFeaturesTail() {
-    before_tracking = (int)t_ids_.size();
-    if (t_ids_.empty()) return;   // :383
+    tracked_.clear();
+    cell_count_.assign(n_codes_, 0);
+    before_tracking = (int)prev_.size();
+    if (prev_.size() == 0) return;   // :383
     after_tracking = 0; after_matching = 0; after_ransac = 0;
     // Q5: the reference has both twoPointRansac calls commented out (:482-500); with the switch cleared they run on the
     // matched cam0 and cam1 temporal pairs and a feature must be an inlier of both
@@ -335,7 +333,7 @@ void ImageProcessor::trackFeaturesTail() {
         for (size_t i = 0; i < status_.size(); ++i) {
             if ((status_[i] & 3) != 3) continue;
             idx.push_back(i);
-            p0.push_back(t_und0_[i]); p1.push_back(t_und1_[i]);
+            p0.push_back(Point2f(prev_.und0[i].x, prev_.und0[i].y)); p1.push_back(Point2f(prev_.und1[i].x, prev_.und1[i].y));
             c0v.push_back(Point2f(und0_[i].x, und0_[i].y)); c1v.push_back(Point2f(und1_[i].x, und1_[i].y));
         }
         std::vector<int> in0, in1;
@@ -350,19 +348,11 @@ void ImageProcessor::trackFeaturesTail() {
         if (!(status_[i] & 2)) continue;
         ++after_matching;
         if (ransac && !keep[i]) continue;
-        const Point2f c0(out0_[i].x, out0_[i].y);
-        int row = static_cast<int>(c0.y / grid_height);
-        int col = static_cast<int>(c0.x / grid_width);
-        int code = row * cfg_.grid_col + col;   // Q7: col may equal grid_col
-        (*curr_features_ptr)[code].push_back(FeatureMetaData());
-        FeatureMetaData &g = (*curr_features_ptr)[code].back();
-        g.id = t_ids_[i];
-        g.response = 0.f;
-        g.lifetime = t_lifetime_[i] + 1;
-        g.cam0_point = c0;
-        g.cam1_point = Point2f(out1_[i].x, out1_[i].y);
-        g.und0 = Point2f(und0_[i].x, und0_[i].y);
-        g.und1 = Point2f(und1_[i].x, und1_[i].y);
+        int code = gridCode(out0_[i]);   // Q7: col may equal grid_col
+        if (code < 0) code = 0;
+        if (code >= n_codes_) { n_codes_ = code + 1; cell_count_.resize(n_codes_, 0); }
+        tracked_.push(prev_.id[i], prev_.lifetime[i] + 1, code, 0.f, out0_[i], out1_[i], und0_[i], und1_[i]);
+        ++cell_count_[code];
         ++after_ransac;
     }
 }
@@ -493,44 +483,43 @@ void two_point_ransac(const std::vector<Point2f> &pts1_undistorted, const std::v
 void ImageProcessor::addNewFeaturesHead() {
     {
         hostprof::Scope hp(hostprof::FE_OCCUPANCY);
-        for (const auto &features : *curr_features_ptr)
-            for (const auto &feature : features.second) {
-                const int y = static_cast<int>(feature.cam0_point.y);
-                const int x = static_cast<int>(feature.cam0_point.x);
-                setGridPosition((float)x, (float)y);
-            }
+        for (size_t k = 0; k < tracked_.size(); ++k) {
+            const int y = static_cast<int>(tracked_.cam0[k].y);
+            const int x = static_cast<int>(tracked_.cam0[k].x);
+            setGridPosition((float)x, (float)y);
+        }
     }
     std::vector<Point2f> new_features;
     { hostprof::Scope hp(hostprof::FE_DETECT); detectFeatures(new_features, cand_responses_det_); }
     hostprof::Scope hp_sieve(hostprof::FE_SIEVE);
-    std::vector<std::vector<std::pair<Point2f, double>>> &sieve = sieve_;
-    sieve.resize((size_t)cfg_.grid_row * cfg_.grid_col);
-    for (auto &cell : sieve) cell.clear();
+    // The reference sieves every detection into its grid cell, keeps the grid_max best of a cell (:664-675), stereo-matches
+    // all of them (:677-688) and then uses only those of cells with a vacancy (:736-750).  A candidate's cell is its sieve
+    // cell (the matched cam0 point IS the candidate) and the vacancies are known here, after tracking: candidates of
+    // full cells cannot influence any output, so only their NUMBER is kept.  It still counts: Q4 indexes the
+    // detection-order responses with the candidate's position in the reference's full candidate list, so every
+    // candidate that is sent to the device carries that position.
+    const int n_cells = cfg_.grid_row * cfg_.grid_col;
+    sieve_.resize((size_t)n_cells);
+    sieve_count_.assign((size_t)n_cells, 0);
+    for (auto &cell : sieve_) cell.clear();
     for (size_t i = 0; i < new_features.size(); ++i) {
-        int row = static_cast<int>(new_features[i].y / grid_height);
-        int col = static_cast<int>(new_features[i].x / grid_width);
-        size_t code = (size_t)(row * cfg_.grid_col + col);
-        if (code >= sieve.size()) continue;   // the reference indexes out of bounds here (Q7); defined: dropped
-        sieve[code].push_back(std::make_pair(new_features[i], cand_responses_det_[i]));
+        const mskf_point2f p{new_features[i].x, new_features[i].y};
+        const int code = gridCode(p);
+        if (code < 0 || code >= n_cells) continue;   // the reference indexes out of bounds here (Q7); defined: dropped
+        ++sieve_count_[code];
+        if (cell_count_[code] < cfg_.grid_min_feature_num) sieve_[code].push_back(std::make_pair(p, cand_responses_det_[i]));
     }
-    // The reference stereo-matches every sieved candidate (:677-688) and then uses only those that land in a cell with
-    // a vacancy (:736-750).  A candidate's cell is its sieve cell (the matched cam0 point IS the candidate), and the
-    // vacancies are known here, after tracking: candidates of full cells cannot influence any output, so they are not
-    // sent to the device at all.  Their positions in the flattened candidate list still count: Q4 indexes the
-    // detection-order responses with that position, so every kept candidate carries its original index.
     in_pts_.clear(); cand_responses_sieved_.clear(); cand_index_.clear();
     int flat = 0;
-    for (size_t code = 0; code < sieve.size(); ++code) {
-        auto &item = sieve[code];
-        const int kept = std::min((int)item.size(), cfg_.grid_max_feature_num);
-        auto live = curr_features_ptr->find((int)code);
-        const bool vacant = live == curr_features_ptr->end() || (int)live->second.size() < cfg_.grid_min_feature_num;
-        if (vacant && kept > 0) {
+    for (int code = 0; code < n_cells; ++code) {
+        const int kept = std::min(sieve_count_[code], cfg_.grid_max_feature_num);
+        auto &item = sieve_[code];
+        if (!item.empty()) {
             if ((int)item.size() > cfg_.grid_max_feature_num)
                 small_stable_sort(item.begin(), item.end(),
-                                  [](const std::pair<Point2f, double> &a, const std::pair<Point2f, double> &b) { return a.second > b.second; });
+                                  [](const std::pair<mskf_point2f, double> &a, const std::pair<mskf_point2f, double> &b) { return a.second > b.second; });
             for (int k = 0; k < kept; ++k) {
-                in_pts_.push_back(mskf_point2f{item[k].first.x, item[k].first.y});
+                in_pts_.push_back(item[k].first);
                 cand_responses_sieved_.push_back(item[k].second);
                 cand_index_.push_back(flat + k);
             }
@@ -540,47 +529,34 @@ void ImageProcessor::addNewFeaturesHead() {
 }
 
 // :690-750
-void ImageProcessor::addNewFeaturesTail() {
-    const bool q4 = (cfg_.compat_flags & MSKF_COMPAT_Q4_RESPONSE_INDEX) != 0;
-    GridFeatures &grid_new_features = grid_new_features_;
-    resetGrid(grid_new_features);
-    for (size_t i = 0; i < status_.size(); ++i) {
-        if (!(status_[i] & 2)) continue;
-        FeatureMetaData nf;
-        nf.id = 0; nf.lifetime = 0;
-        nf.response = (float)(q4 ? cand_responses_det_[cand_index_[i]] : cand_responses_sieved_[i]);   // Q4 (:698)
-        nf.cam0_point = Point2f(out0_[i].x, out0_[i].y);
-        nf.cam1_point = Point2f(out1_[i].x, out1_[i].y);
-        nf.und0 = Point2f(und0_[i].x, und0_[i].y);
-        nf.und1 = Point2f(und1_[i].x, und1_[i].y);
-        int row = static_cast<int>(nf.cam0_point.y / grid_height);
-        int col = static_cast<int>(nf.cam0_point.x / grid_width);
-        grid_new_features[row * cfg_.grid_col + col].push_back(nf);
-    }
-    for (auto &item : grid_new_features)
-        small_stable_sort(item.second.begin(), item.second.end(),
-                          [](const FeatureMetaData &a, const FeatureMetaData &b) { return cmpResponse(a.response, b.response); });
-    for (int code = 0; code < cfg_.grid_row * cfg_.grid_col; ++code) {
-        std::vector<FeatureMetaData> &features_this_grid = (*curr_features_ptr)[code];
-        std::vector<FeatureMetaData> &new_features_this_grid = grid_new_features[code];
-        if ((int)features_this_grid.size() >= cfg_.grid_min_feature_num) continue;
-        int vacancy_num = cfg_.grid_min_feature_num - (int)features_this_grid.size();
-        for (int k = 0; k < vacancy_num && k < (int)new_features_this_grid.size(); ++k) {
-            features_this_grid.push_back(new_features_this_grid[k]);
-            features_this_grid.back().id = next_feature_id++;
-            features_this_grid.back().lifetime = 1;
-        }
-    }
-}
+void ImageProcessor::addNewFeaturesTail() { selectNewFeatures(false); }
 
-// :758-768
-void ImageProcessor::pruneGridFeatures() {
-    for (auto &item : *curr_features_ptr) {
-        auto &grid_features = item.second;
-        if ((int)grid_features.size() <= cfg_.grid_max_feature_num) continue;
-        small_stable_sort(grid_features.begin(), grid_features.end(),
-                          [](const FeatureMetaData &a, const FeatureMetaData &b) { return a.lifetime > b.lifetime; });
-        grid_features.erase(grid_features.begin() + cfg_.grid_max_feature_num, grid_features.end());
+// This frame's grid in the reference's iteration order: ascending code; inside a cell the tracked features in track
+// order, then the new ones in rank order; cells over grid_max keep their grid_max longest-lived features
+// (pruneGridFeatures, :758-768; stable).  tracked_ is in track order, new_ in code order.
+void ImageProcessor::assembleGrid() {
+    curr_.clear();
+    cell_start_.assign((size_t)n_codes_ + 1, 0);
+    for (size_t k = 0; k < tracked_.size(); ++k) ++cell_start_[tracked_.code[k] + 1];
+    for (int c = 0; c < n_codes_; ++c) cell_start_[c + 1] += cell_start_[c];
+    order_.resize(tracked_.size());
+    {
+        std::vector<int> &fill = sieve_count_;      // scratch
+        fill.assign((size_t)n_codes_, 0);
+        for (size_t k = 0; k < tracked_.size(); ++k) { const int c = tracked_.code[k]; order_[cell_start_[c] + fill[c]++] = (int)k; }
+    }
+    size_t nn = 0;
+    struct Slot { int lifetime; int from_new; int idx; };
+    std::vector<Slot> cell;
+    for (int c = 0; c < n_codes_; ++c) {
+        cell.clear();
+        for (int q = cell_start_[c]; q < cell_start_[c + 1]; ++q) cell.push_back(Slot{tracked_.lifetime[order_[q]], 0, order_[q]});
+        while (nn < new_.size() && new_.code[nn] == c) { cell.push_back(Slot{new_.lifetime[nn], 1, (int)nn}); ++nn; }
+        if ((int)cell.size() > cfg_.grid_max_feature_num) {
+            small_stable_sort(cell.begin(), cell.end(), [](const Slot &a, const Slot &b) { return a.lifetime > b.lifetime; });
+            cell.resize((size_t)cfg_.grid_max_feature_num);
+        }
+        for (const Slot &sl : cell) curr_.push_from(sl.from_new ? new_ : tracked_, (size_t)sl.idx);
     }
 }
 
@@ -589,7 +565,7 @@ void ImageProcessor::phaseAfter1(mskf_fe_track_args &args2) {
     if (stage_ == 1) {
         initializeFirstFrameTail();
         is_first_img = false;
-        stage_ = 0;
+        stage_ = 4;
         return;
     }
     { hostprof::Scope hp(hostprof::FE_TRACK_TAIL); trackFeaturesTail(); }
@@ -601,40 +577,43 @@ void ImageProcessor::phaseAfter1(mskf_fe_track_args &args2) {
 void ImageProcessor::phaseAfter2(bool is_draw) {
     if (stage_ == 3) {
         { hostprof::Scope hp(hostprof::FE_NEW_TAIL); addNewFeaturesTail(); }
-        { hostprof::Scope hp(hostprof::FE_PRUNE); pruneGridFeatures(); }
-        stage_ = 0;
+        { hostprof::Scope hp(hostprof::FE_PRUNE); assembleGrid(); }
+    } else if (stage_ == 4) {
+        assembleGrid();      // first frame: the new features are the grid (no pruning in initializeFirstFrame, grid_min <= grid_max)
+    } else {
+        curr_.clear();
     }
+    stage_ = 0;
     if (is_draw) {   // :163-184
-        prev_ids_.clear();
-        for (const auto &g : *prev_features_ptr) for (const auto &f : g.second) prev_ids_.push_back(f.id);
+        prev_ids_.assign(prev_.id.begin(), prev_.id.end());
         prev_cam0_points_.clear(); prev_cam1_points_.clear(); curr_cam0_points_.clear(); curr_cam1_points_.clear();
-        for (const auto &g : *prev_features_ptr) for (const auto &f : g.second) { prev_cam0_points_[f.id] = f.cam0_point; prev_cam1_points_[f.id] = f.cam1_point; }
-        for (const auto &g : *curr_features_ptr) for (const auto &f : g.second) { curr_cam0_points_[f.id] = f.cam0_point; curr_cam1_points_[f.id] = f.cam1_point; }
+        for (size_t k = 0; k < prev_.size(); ++k) { prev_cam0_points_[prev_.id[k]] = Point2f(prev_.cam0[k].x, prev_.cam0[k].y); prev_cam1_points_[prev_.id[k]] = Point2f(prev_.cam1[k].x, prev_.cam1[k].y); }
+        for (size_t k = 0; k < curr_.size(); ++k) { curr_cam0_points_[curr_.id[k]] = Point2f(curr_.cam0[k].x, curr_.cam0[k].y); curr_cam1_points_[curr_.id[k]] = Point2f(curr_.cam1[k].x, curr_.cam1[k].y); }
     }
     hostprof::Scope hp_pub(hostprof::FE_PUBLISH);
     publish();
     // :192-200
     if (!(cfg_.compat_flags & MSKF_COMPAT_Q2_PREV_ALIAS)) cam0_prev_time = cam0_curr_time;
-    std::swap(prev_features_ptr, curr_features_ptr);     // prev <- the grid just published; the old prev is recycled
+    std::swap(prev_, curr_);     // prev <- the grid just published
     mskf_fe_swap(stream_);
-    resetGrid(*curr_features_ptr);
 }
 
 // :1137-1182
 void ImageProcessor::publish() {
     feature_msg_ptr_->time_stamp = cam0_curr_time;
-    if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) feature_msg_ptr_->features.clear();
-    size_t i = 0;
-    for (const auto &g : *curr_features_ptr)
-        for (const auto &f : g.second) {
-            feature_msg_ptr_->features.push_back(FeatureMeasurement{0, 0, 0, 0, 0});   // Q1: never cleared
-            FeatureMeasurement &m = feature_msg_ptr_->features[i];
-            m.id = (unsigned int)f.id;
-            m.u0 = f.und0.x; m.v0 = f.und0.y; m.u1 = f.und1.x; m.v1 = f.und1.y;
-            ++i;
-        }
-    if (i > max_published_) max_published_ = i;
-    if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) max_published_ = i;
+    std::vector<FeatureMeasurement> &msg = feature_msg_ptr_->features;
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) msg.clear();
+    const size_t n = curr_.size();
+    // Q1: the reference push_backs one value-initialised record per feature and then writes records 0 .. n-1: the
+    // message grows by n every frame and is never cleared
+    msg.resize(msg.size() + n, FeatureMeasurement{0, 0, 0, 0, 0});
+    for (size_t i = 0; i < n; ++i) {
+        FeatureMeasurement &m = msg[i];
+        m.id = (unsigned int)curr_.id[i];
+        m.u0 = curr_.und0[i].x; m.v0 = curr_.und0[i].y; m.u1 = curr_.und1[i].x; m.v1 = curr_.und1[i].y;
+    }
+    if (n > max_published_) max_published_ = n;
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) max_published_ = n;
     last_tracking_info = TrackingInfo{cam0_curr_time, before_tracking, after_tracking, after_matching, after_ransac};
     if (debug_.is_open())
         debug_ << std::fixed << std::setprecision(9) << cam0_curr_time << ": " << before_tracking << ", " << after_tracking << ", "
@@ -643,10 +622,11 @@ void ImageProcessor::publish() {
 
 void ImageProcessor::dumpCurrent(std::vector<FeatureIDType> &ids, std::vector<int> &lifetime, std::vector<Point2f> &cam0,
                                  std::vector<Point2f> &cam1) const {
-    // after phaseAfter2 the published grid is prev_features_ptr
-    ids.clear(); lifetime.clear(); cam0.clear(); cam1.clear();
-    for (const auto &g : *prev_features_ptr)
-        for (const auto &f : g.second) { ids.push_back(f.id); lifetime.push_back(f.lifetime); cam0.push_back(f.cam0_point); cam1.push_back(f.cam1_point); }
+    // after phaseAfter2 the published grid is prev_
+    ids.assign(prev_.id.begin(), prev_.id.end());
+    lifetime.assign(prev_.lifetime.begin(), prev_.lifetime.end());
+    cam0.clear(); cam1.clear();
+    for (size_t k = 0; k < prev_.size(); ++k) { cam0.push_back(Point2f(prev_.cam0[k].x, prev_.cam0[k].y)); cam1.push_back(Point2f(prev_.cam1[k].x, prev_.cam1[k].y)); }
 }
 
 }  // namespace cg

@@ -87,15 +87,23 @@ class ImageProcessor {
     const std::string &error() const { return error_; }
 
   private:
-    struct FeatureMetaData {
-        FeatureIDType id;
-        float response;
-        int lifetime;
-        cg::Point2f cam0_point;
-        cg::Point2f cam1_point;
-        cg::Point2f und0, und1;   // undistorted normalised coordinates (what publish() sends)
+    // The reference keeps the live features in GridFeatures = std::map<int code, std::vector<FeatureMetaData>>
+    // (image_processor.h:100-113): iteration = ascending grid code, insertion order inside a cell.  Here the same
+    // sequence is ONE set of flat arrays in that iteration order (a frame's grid is rebuilt by a stable counting sort
+    // over the codes): no per-cell containers, the previous frame's pixels go to the device as they lie.
+    struct FeatureArrays {
+        std::vector<FeatureIDType> id;
+        std::vector<int> lifetime, code;
+        std::vector<float> response;
+        std::vector<mskf_point2f> cam0, cam1, und0, und1;   // pixels; undistorted normalised coordinates (what publish() sends)
+        size_t size() const { return id.size(); }
+        void clear() { id.clear(); lifetime.clear(); code.clear(); response.clear(); cam0.clear(); cam1.clear(); und0.clear(); und1.clear(); }
+        void push(FeatureIDType i, int life, int c, float resp, mskf_point2f a, mskf_point2f b, mskf_point2f ua, mskf_point2f ub) {
+            id.push_back(i); lifetime.push_back(life); code.push_back(c); response.push_back(resp);
+            cam0.push_back(a); cam1.push_back(b); und0.push_back(ua); und1.push_back(ub);
+        }
+        void push_from(const FeatureArrays &o, size_t k) { push(o.id[k], o.lifetime[k], o.code[k], o.response[k], o.cam0[k], o.cam1[k], o.und0[k], o.und1[k]); }
     };
-    typedef std::map<int, std::vector<FeatureMetaData>> GridFeatures;
 
     bool loadParameters();
     void detectFeatures(std::vector<Point2f> &pts, std::vector<double> &responses);  // CornerDetector::detect_features
@@ -116,8 +124,11 @@ class ImageProcessor {
     void trackFeaturesTail();
     void addNewFeaturesHead();
     void addNewFeaturesTail();
-    void pruneGridFeatures();
-    void resetGrid(GridFeatures &g) const;
+    void selectNewFeatures(bool first_frame);   // per-cell response sort + vacancy fill + ids (:690-750 / :270-316)
+    void assembleGrid();                         // grid of this frame in iteration order + pruneGridFeatures (:758-768)
+    int gridCode(const mskf_point2f &p) const {  // :452-454 (Q7: the column may equal grid_col)
+        return static_cast<int>(p.y / grid_height) * cfg_.grid_col + static_cast<int>(p.x / grid_width);
+    }
     void publish();
     void fail(const char *what, int rc);
 
@@ -140,22 +151,22 @@ class ImageProcessor {
     int grid_height = 0, grid_width = 0;
     int det_cell_w = 0, det_cell_h = 0;
     std::vector<uint8_t> occupancy_;
-    std::shared_ptr<GridFeatures> prev_features_ptr, curr_features_ptr;
+    FeatureArrays prev_, curr_, tracked_, new_;      // published grid of the last frame / of this frame; this frame's survivors (track order); new features (code order)
+    std::vector<int> cell_count_, cell_start_;       // tracked features per grid code of this frame; counting-sort offsets
+    int n_codes_ = 0;                                 // grid codes that can occur: 0 .. n_codes_ - 1
     int before_tracking = 0, after_tracking = 0, after_matching = 0, after_ransac = 0;
 
     // per-frame scratch shared between phases
     std::vector<mskf_point2f> in_pts_, out0_, out1_, und0_, und1_;
     std::vector<uint8_t> status_;
-    std::vector<FeatureIDType> t_ids_;
-    std::vector<int> t_lifetime_;
-    std::vector<cg::Point2f> t_und0_, t_und1_;    // undistorted previous points of the tracked features (RANSAC input)
     hm::Mat3 cam0_R_p_c_, cam1_R_p_c_;            // integrateImuData result of this frame
     std::vector<double> cand_responses_det_;     // responses in detection order (Q4)
     std::vector<double> cand_responses_sieved_;  // responses in sieve order
     std::vector<int> cand_index_;                // position of every candidate sent to the device in the reference's full candidate list
     std::vector<mskf_corner> cell_max_;
-    GridFeatures grid_new_features_;                                     // per-frame scratch, storage reused
-    std::vector<std::vector<std::pair<Point2f, double>>> sieve_;         // per-frame scratch, storage reused
+    std::vector<std::vector<std::pair<mskf_point2f, double>>> sieve_;   // candidates of the cells with a vacancy (per-frame scratch)
+    std::vector<int> sieve_count_;                                       // candidates per grid cell (all cells)
+    std::vector<int> order_;                                             // scratch: sort permutation
     size_t max_published_ = 0;
     int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
     std::ofstream debug_;
