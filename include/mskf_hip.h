@@ -157,6 +157,8 @@ typedef struct mskf_ekf_update_args {
     uint8_t *feat_status;           /* out per feature: bit0 triangulation valid, bit1 gating passed (stacked) */
     double *gamma;                  /* out per feature (may be NULL): Mahalanobis gate value */
     int32_t *rows_out;              /* out: number of stacked rows (0 => no update applied) */
+    int32_t *diag_out;              /* out, optional (may be NULL), 2 ints: [0] 1 if the compression ran as Householder TSQR, 0 for
+                                       Gram + Cholesky; [1] pivots of the Gram factor below 100 lambda (-1: not computed) */
 } mskf_ekf_update_args;
 
 /* What processModel (msckf_vio.cpp:409-469) needs to propagate the covariance over one IMU sample.
@@ -188,6 +190,8 @@ int mskf_ekf_remove_clone(mskf_stream *s, int clone_index);
 /* Remove up to two clones per stream in one launch: idx[2*i], idx[2*i+1] are clone indices in the CURRENT
  * state order (distinct; -1 = none).  Equivalent to mskf_ekf_remove_clone calls (msckf_vio.cpp:1161-1181). */
 int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *idx);
+/* Diagnostics for tests: raw work buffers of the stream's last update (0 Hs, 1 rowmask, 2 S, 3 T, 4 W, 5 act). */
+int mskf_ekf_debug_read(mskf_stream *s, int which, void *out, size_t capacity, int *ld_out);
 int mskf_ekf_get_dim(mskf_stream *s, int *d);
 int mskf_ekf_get_cov(mskf_stream *s, double *P, int capacity /* doubles */);
 int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d);

@@ -35,7 +35,8 @@ class EkfUpdateArgs(C.Structure):
     _fields_ = [("n_clones", C.c_int32), ("n_feat", C.c_int32), ("n_obs", C.c_int32), ("dof_offset", C.c_int32),
                 ("apply_row_cap", C.c_int32), ("_pad", C.c_int32), ("gravity", C.c_double * 3),
                 ("clones", C.c_void_p), ("features", C.c_void_p), ("obs_clone", C.c_void_p), ("obs_z", C.c_void_p),
-                ("delta_x", C.c_void_p), ("feat_status", C.c_void_p), ("gamma", C.c_void_p), ("rows_out", C.c_void_p)]
+                ("delta_x", C.c_void_p), ("feat_status", C.c_void_p), ("gamma", C.c_void_p), ("rows_out", C.c_void_p),
+                ("diag_out", C.c_void_p)]
 
 
 EXPORTS = [
@@ -45,7 +46,7 @@ EXPORTS = [
     "mskf_fe_get_level", "mskf_ekf_reset", "mskf_ekf_propagate", "mskf_ekf_augment", "mskf_ekf_update",
     "mskf_ekf_update_batch", "mskf_ekf_remove_clone", "mskf_ekf_remove_clones_batch", "mskf_ekf_predict_batch", "mskf_ekf_propagate_imu",
     "mskf_ekf_get_pos_var", "mskf_ekf_get_pos_var_batch", "mskf_ctx_set_timing", "mskf_ctx_get_timing", "mskf_stream_ctx",
-    "mskf_ekf_get_dim", "mskf_ekf_get_cov", "mskf_ekf_set_cov",
+    "mskf_ekf_get_dim", "mskf_ekf_get_cov", "mskf_ekf_set_cov", "mskf_ekf_debug_read",
 ]
 
 
@@ -246,12 +247,14 @@ class Stream:
         status = np.zeros(max(n_feat, 1), np.uint8)
         gamma = np.zeros(max(n_feat, 1))
         rows = np.zeros(1, np.int32)
+        diag = np.zeros(2, np.int32)
         a = EkfUpdateArgs()
         a.n_clones, a.n_feat, a.n_obs = n_clones, n_feat, len(obs_clone)
         a.dof_offset, a.apply_row_cap = dof_offset, int(apply_row_cap)
         a.gravity[:] = list(np.asarray(gravity, dtype=np.float64))
         a.clones, a.features, a.obs_clone, a.obs_z = clones.ctypes.data, feats.ctypes.data, obs_clone.ctypes.data, obs_z.ctypes.data
         a.delta_x, a.feat_status, a.gamma, a.rows_out = dx.ctypes.data, status.ctypes.data, gamma.ctypes.data, rows.ctypes.data
+        a.diag_out = diag.ctypes.data
         _chk(self.L.mskf_ekf_update(self.h, C.byref(a)))
         return dict(delta_x=dx, status=status[:n_feat], gamma=gamma[:n_feat], rows=int(rows[0]),
-                    positions=feats["position"].copy())
+                    positions=feats["position"].copy(), used_qr=int(diag[0]), tiny_pivots=int(diag[1]))

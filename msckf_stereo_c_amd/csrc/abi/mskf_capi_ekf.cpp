@@ -18,6 +18,7 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
+void ekf_launch_qr(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 int ekf_small_update_max_na(void);
 }
 
@@ -115,6 +116,7 @@ static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
     D.P = E.P; D.d = E.d; D.ld = E.ld;
     D.sigma2 = s->ekf.noise_feature * s->ekf.noise_feature;   // msckf_vio.cpp:74,81
     D.max_stack_rows = s->ekf.max_stack_rows;
+    D.qr_mode = s->ekf.compression_mode;
     D.chi2 = E.chi2;
     D.remove_index = D.remove_index2 = -1;
     // continuous_noise_cov diagonal blocks: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:70-80, 174-178)
@@ -569,6 +571,11 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
             ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
             ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
             mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+            // Householder TSQR instead, for the streams that need it (no more rows than columns, near-zero pivots beyond
+            // the gauge, or compression_mode = 2): the others leave the launch at once
+            ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
+            ekf_launch_qr(ctx->ekf_desc.d, n, max_d, st);
+            mskf_t_end(ctx, ts, 0);
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
@@ -599,16 +606,44 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         if (!a.n_feat) {
             if (a.delta_x) std::memset(a.delta_x, 0, sizeof(double) * (size_t)d);
             if (a.rows_out) *a.rows_out = 0;
+            if (a.diag_out) { a.diag_out[0] = 0; a.diag_out[1] = -1; }
             continue;
         }
         std::memcpy(a.delta_x, hout + L.o_dx, sizeof(double) * (size_t)d);
         if (a.gamma) std::memcpy(a.gamma, hout + L.o_gamma, sizeof(double) * (size_t)a.n_feat);
         *a.rows_out = ((const int *)(hout + L.o_rows))[0];
+        if (a.diag_out) { const int dg = ((const int *)(hout + L.o_rows))[3]; a.diag_out[0] = dg & 1; a.diag_out[1] = dg >> 8; }
         std::memcpy(a.feat_status, hout + L.o_status, (size_t)a.n_feat);
         const double *po = (const double *)(hout + L.o_pos);
         for (int j = 0; j < a.n_feat; ++j)
             for (int k = 0; k < 3; ++k) a.features[j].position[k] = po[3 * j + k];
     }
+    return MSKF_OK;
+}
+
+// Test / diagnostic access to the work buffers of the last update of a stream (not used by the product path):
+// which = 0 Hs (max_rows x ld), 1 rowmask (max_rows, 8-byte), 2 S (ld x ld), 3 T (ld x ld), 4 W (ld x ld), 5 act (ld ints).
+// Copies min(capacity, size) bytes; *ld_out = row stride in doubles.
+extern "C" int mskf_ekf_debug_read(mskf_stream *s, int which, void *out, size_t capacity, int *ld_out) {
+    if (!s || !out) return MSKF_ERR_INVALID;
+    EkfStreamState &E = s->ekf_state;
+    MSKF_HIPCHK(hipSetDevice(s->ctx_ekf->device));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx_ekf->stream));
+    const void *src = nullptr;
+    size_t bytes = 0;
+    const size_t pl = sizeof(double) * (size_t)E.ld * E.ld;
+    switch (which) {
+        case 0: src = E.Hs; bytes = sizeof(double) * (size_t)E.max_rows * E.ld; break;
+        case 1: src = E.rs; bytes = sizeof(double) * (size_t)E.max_rows; break;
+        case 2: src = E.S; bytes = pl; break;
+        case 3: src = E.T; bytes = pl; break;
+        case 4: src = E.W; bytes = pl; break;
+        case 5: src = E.act; bytes = sizeof(int) * (size_t)E.ld; break;
+        default: return MSKF_ERR_INVALID;
+    }
+    if (!src) return MSKF_ERR_INVALID;
+    if (ld_out) *ld_out = E.ld;
+    MSKF_HIPCHK(hipMemcpy(out, src, std::min(bytes, capacity), hipMemcpyDeviceToHost));
     return MSKF_OK;
 }
 

@@ -49,9 +49,12 @@ struct EkfStreamDev {
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
     double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
+    int qr_mode;              // mskf_ekf_cfg.compression_mode: 0 auto (Gram + Cholesky, Householder TSQR when flagged), 1 Gram only, 2 TSQR always
     const int *tri_idx;       // features that need triangulation (pair path: k_ekf_triangulate), n_tri of them
     int n_tri;
-    int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns
+    int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns,
+                              // [3] compression diagnostics: bit 0 = Householder TSQR used, bit 1 = the lambda prior of the Gram path
+                              //     would bias P by more than QR_BIAS_LIMIT, bits 8.. = pivots of the Gram factor below 100 lambda
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)
     const mskf_imu_step *imu_steps;   // or: n_steps compact IMU records, Phi/Q formed on the device

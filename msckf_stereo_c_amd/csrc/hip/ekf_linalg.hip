@@ -28,6 +28,14 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Gram + regularised Cholesky adds a prior lambda I to the stacked information H^T H / sigma^2: the posterior covariance
+// moves by about lambda max(P_aa) / sigma^2 relative.  Above this limit (or when the stack has no more rows than active
+// columns) the compression runs as Householder TSQR instead (k_ekf_qr), which has no such term.
+#define QR_BIAS_LIMIT 1e-8
+// auto mode, stack with no more rows than active columns (the reference compresses nothing there, msckf_vio.cpp:818-821):
+// the Gram pass and its factorisation are skipped, k_ekf_qr triangularises the few rows directly
+__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]); }
+
 enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
 
 // Per-mode compile-time shape of op(A) op(B): TA: op(A)(i,k) = A[k*ld+i] (else A[i*ld+k]); B is always B[k*ld+j].
@@ -49,6 +57,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     using TR = GemmTraits<MODE>;
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
+    if (MODE == GM_GRAM && ekf_skip_gram(S)) return;
     const int d = S.d, ld = S.ld;
     const int na = S.rows_out[2];                  // active columns (compact index i <-> column act[i])
     const int *__restrict__ act = S.act;
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
 __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *streams, int which, int pan_rs) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
+    if (which == 0 && ekf_skip_gram(S)) { if (threadIdx.x == 0) S.rows_out[3] = 0; return; }
     const int n = S.rows_out[2];                          // active columns
     const int nt = n + (which == 0 ? 1 : 0);              // + the extra Q^T r row of the Gram factorisation
     const int lda = S.ld;
@@ -212,6 +222,25 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     __syncthreads();
     chol_blocked_lds<CHOLG_THREADS / 64>(A, [lda](int i, int j) { return i * lda + j; }, n, nt, 0.0, sPanT, pan_rs, s_cb);
     if (which == 0) {
+        // pivots (L_kk^2) that end within 100 lambda of the regularisation floor: what k_ekf_qr decides on
+        int tiny = 0;
+        for (int i = tid; i < n; i += CHOLG_THREADS) { const double l = A[(size_t)i * lda + i]; tiny += (l * l < 100.0 * s_tol) ? 1 : 0; }
+        for (int o = 32; o > 0; o >>= 1) tiny += __shfl_xor(tiny, o);
+        __shared__ int s_tiny[CHOLG_THREADS / 64];
+        if ((tid & 63) == 0) s_tiny[tid >> 6] = tiny;
+        __syncthreads();
+        // predicted relative bias of the posterior covariance from the lambda prior: lambda max(P_aa) / sigma^2
+        double pm = 0;
+        for (int i = tid; i < n; i += CHOLG_THREADS) pm = fmax(pm, S.P[(size_t)S.act[i] * lda + S.act[i]]);
+        for (int o = 32; o > 0; o >>= 1) pm = fmax(pm, __shfl_xor(pm, o));
+        __syncthreads();
+        if ((tid & 63) == 0) s_mx[tid >> 6] = pm;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0; for (int i = 0; i < CHOLG_THREADS / 64; ++i) t += s_tiny[i];
+            double p = 0; for (int i = 0; i < CHOLG_THREADS / 64; ++i) p = fmax(p, s_mx[i]);
+            S.rows_out[3] = (t << 8) | ((s_tol * p > QR_BIAS_LIMIT * S.sigma2) ? 2 : 0);
+        }
         // column d of T <- (Q^T r) = the extra row of L, so the TRSM carries w = L2^-1 Q^T r along
         for (int k = tid; k < n; k += CHOLG_THREADS) S.T[(size_t)k * lda + S.d] = A[(size_t)n * lda + k];
     }
@@ -242,6 +271,7 @@ __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
+    if (which == 0 && ekf_skip_gram(S)) { if (threadIdx.x == 0) S.rows_out[3] = 0; return; }
     double *A = which == 0 ? S.S : S.W;
     const int off = 0, lda = S.ld;                 // compact storage: index i <-> column act[i]
     const int n = S.rows_out[2];                   // active columns
@@ -294,6 +324,27 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     }
     const double tol = 0.0;      // a pivot <= 0 (cannot happen for G + lambda I or for S >= sigma^2 I) zeroes its column
     chol_blocked_lds<CHOL_WAVES>(sM, [](int i, int j) { return pk(i, j); }, n, nt, tol, sPanT, CHOL_PAN_RS, s_cb);
+    if (which == 0) {
+        // pivots (L_kk^2) that end within 100 lambda of the regularisation floor: what k_ekf_qr decides on
+        int tiny = 0;
+        for (int i = tid; i < n; i += CHOL_THREADS) { const double l = sM[pk(i, i)]; tiny += (l * l < 100.0 * s_tol) ? 1 : 0; }
+        for (int o = 32; o > 0; o >>= 1) tiny += __shfl_xor(tiny, o);
+        __shared__ int s_tiny[CHOL_WAVES];
+        if (lane == 0) s_tiny[wave] = tiny;
+        __syncthreads();
+        // predicted relative bias of the posterior covariance from the lambda prior: lambda max(P_aa) / sigma^2
+        double pm = 0;
+        for (int i = tid; i < n; i += CHOL_THREADS) pm = fmax(pm, S.P[(size_t)S.act[i] * lda + S.act[i]]);
+        for (int o = 32; o > 0; o >>= 1) pm = fmax(pm, __shfl_xor(pm, o));
+        __syncthreads();
+        if (lane == 0) s_mx[wave] = pm;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0; for (int i = 0; i < CHOL_WAVES; ++i) t += s_tiny[i];
+            double p = 0; for (int i = 0; i < CHOL_WAVES; ++i) p = fmax(p, s_mx[i]);
+            S.rows_out[3] = (t << 8) | ((s_tol * p > QR_BIAS_LIMIT * S.sigma2) ? 2 : 0);
+        }
+    }
     // store back
     for (int i = wave; i < nt; i += CHOL_WAVES) {
         double *dst = A + (size_t)(off + i) * lda + off;
@@ -310,6 +361,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
 // ------------------------------------------------------------------------------------ TRSM
 // Y = L^-1 B in place, L = lower Cholesky factor in S.W (na x na), B = S.T (na x (d+1)).  One workgroup per
 // 32-column strip; the strip (na x 32 doubles) stays in LDS for the whole solve, L is staged 16 rows at a time.
+#define QR_MAX_N1 (6 * 64 + 1)     // active columns of a 64-clone window + the residual
 #define TS_COLS 32
 #define TS_RB 16
 __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
@@ -394,6 +446,99 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
         const int i = e >> 5, cc = e & 31;
         if (c0 + cc < ncols) B[(size_t)i * ld + c0 + cc] = sY[e];
     }
+}
+
+// ------------------------------------------------------------------------------------ Householder TSQR
+// The reference compresses the stacked Jacobian with a Householder QR (SPQR / Eigen HouseholderQR, msckf_vio.cpp:795-817).
+// The default here is the Gram matrix + a regularised Cholesky (one MFMA pass, fully parallel), which squares the
+// condition number of H and adds the prior lambda I.  The Kalman update itself is regularised by P, so what that costs is
+// bounded by lambda max(P_aa) / sigma^2 whatever cond(H) is (measured: tests/test_gpu_kernels.py, condition sweep); the
+// factorisation evaluates that bound and this path takes over when it exceeds QR_BIAS_LIMIT, when the stack has no more
+// rows than active columns (the reference's m <= d case: nothing is compressed there, :818-821; H^T H would be singular
+// by construction), or always with compression_mode = 2.
+// Row-block TSQR: the upper-triangular R of [H_act | r] (n1 = na + 1 columns, the residual rides along as the last one)
+// stays resident (LDS, packed by rows, when it fits: na <= 174; the stream's W buffer otherwise); the stacked rows are
+// streamed through LDS sixteen at a time and annihilated column by column against R's diagonal with Householder
+// reflectors of length 17.  One 256-thread workgroup per stream: thread j owns column j of the block during a step.
+#define QR_BR 16
+template <class RAt>
+__device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, const int *s_col, const int *s_clone, RAt Rat, double *sB) {
+    const int tid = threadIdx.x, nth = blockDim.x, ld = S.ld;
+    for (int k0 = 0; k0 < K; k0 += QR_BR) {
+        __syncthreads();
+        for (int e = tid; e < QR_BR * n1; e += nth) {
+            const int r = e / n1, c = e - r * n1, gk = k0 + r;
+            double v = 0.0;
+            if (gk < K) {
+                const unsigned long long rm = S.rowmask[gk];
+                const bool on = s_clone[c] < 0 ? rm != 0ULL : ((rm >> s_clone[c]) & 1ULL) != 0ULL;
+                if (on) v = S.Hs[(size_t)gk * ld + s_col[c]];
+            }
+            sB[e] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < n1; ++k) {
+            double bk[QR_BR];
+            double ss = 0.0;
+#pragma unroll
+            for (int i = 0; i < QR_BR; ++i) { bk[i] = sB[i * n1 + k]; ss += bk[i] * bk[i]; }
+            // Nothing (left) in this column of the block: structurally zero, or what earlier reflectors of this block left
+            // of it.  Rounding residue shrinks by ~1e-16 per generation of 16 reflectors; once its square leaves the
+            // normal range 2 / (v0^2 + ss) overflows, and far above that it is already meaningless: below 1e-40 of
+            // R_kk^2 (or 1e-200 absolute) the column counts as annihilated.  Uniform: every thread reads the same values.
+            const double x0 = Rat(k, k);
+            if (ss < 1e-200 || ss < 1e-40 * (x0 * x0)) continue;
+            const double nrm = sqrt(x0 * x0 + ss);
+            const double alpha = x0 > 0.0 ? -nrm : nrm;
+            const double v0 = x0 - alpha;
+            const double beta = 2.0 / (v0 * v0 + ss);
+            for (int j = k + 1 + tid; j < n1; j += nth) {
+                double dot = v0 * Rat(k, j);
+#pragma unroll
+                for (int i = 0; i < QR_BR; ++i) dot += bk[i] * sB[i * n1 + j];
+                const double t = beta * dot;
+                Rat(k, j) -= t * v0;
+#pragma unroll
+                for (int i = 0; i < QR_BR; ++i) sB[i * n1 + j] -= t * bk[i];
+            }
+            __syncthreads();
+            if (tid == 0) Rat(k, k) = alpha;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_ekf_qr(const EkfStreamDev *streams, int r_in_lds) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    if (S.n_feat <= 0) return;
+    const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], m = S.rows_out[0], d = S.d, ld = S.ld;
+    const int diag = S.rows_out[3];
+    const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && na > 0 && (m <= na || (diag & 2)));
+    if (!need || na <= 0) return;
+    extern __shared__ double s_dyn[];
+    __shared__ int s_col[QR_MAX_N1], s_clone[QR_MAX_N1];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < n1; c += 256) {
+        const int col = c < na ? S.act[c] : d;
+        s_col[c] = col;
+        s_clone[c] = c < na ? (col - EKF_IMU_DIM) / 6 : -1;
+    }
+    double *sB = s_dyn;                                  // QR_BR x n1
+    double *Rl = s_dyn + QR_BR * n1;                     // packed upper by rows (r_in_lds)
+    double *Rg = S.W;                                    // or the stream's W buffer, ld-wide rows
+    if (r_in_lds) { for (int e = tid; e < n1 * (n1 + 1) / 2; e += 256) Rl[e] = 0.0; }
+    else { for (int e = tid; e < n1 * ld; e += 256) Rg[e] = 0.0; }
+    __syncthreads();
+    if (r_in_lds) tsqr16(S, n1, K, s_col, s_clone, [=](int k, int j) -> double & { return Rl[k * n1 - k * (k - 1) / 2 + (j - k)]; }, sB);
+    else tsqr16(S, n1, K, s_col, s_clone, [=](int k, int j) -> double & { return Rg[(size_t)k * ld + j]; }, sB);
+    // hand over in the layout the update expects: S.S = L = R^T (lower, ld-wide rows), column d of T = Q^T r
+    auto Rv = [&](int k, int j) { return r_in_lds ? Rl[k * n1 - k * (k - 1) / 2 + (j - k)] : Rg[(size_t)k * ld + j]; };
+    for (int e = tid; e < na * na; e += 256) {
+        const int i = e / na, j = e - i * na;
+        if (j <= i) S.S[(size_t)i * ld + j] = Rv(j, i);
+    }
+    for (int k = tid; k < na; k += 256) S.T[(size_t)k * ld + d] = Rv(k, na);
+    if (tid == 0) S.rows_out[3] = diag | 1;
 }
 
 // ------------------------------------------------------------------------------------ small update, fused
@@ -496,6 +641,33 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
         __syncthreads();
     }
+    // ---- 2b. the same decision as k_ekf_qr: near-zero pivots beyond the gauge, no more rows than columns, or forced ->
+    //          Householder TSQR of the stacked rows, R in sG (full rows), then L = R^T back in place
+    {
+        __shared__ int s_tiny, s_bias;
+        if (tid == 0) {
+            int t = 0;
+            double pm = 0;
+            for (int i = 0; i < na; ++i) {
+                const double l = sG[i * n1 + i];
+                t += (l * l < 100.0 * s_lam) ? 1 : 0;
+                pm = fmax(pm, S.P[(size_t)s_col[i] * ld + s_col[i]]);
+            }
+            s_tiny = t;
+            s_bias = (s_lam * pm > QR_BIAS_LIMIT * S.sigma2) ? 1 : 0;
+        }
+        __syncthreads();
+        const int tiny = s_tiny;
+        const bool need_qr = S.qr_mode == 2 || (S.qr_mode == 0 && (S.rows_out[0] <= na || s_bias));
+        if (need_qr) {
+            for (int e = tid; e < n1 * n1; e += 256) sG[e] = 0.0;
+            __syncthreads();
+            tsqr16(S, n1, K, s_col, s_clone, [=](int k, int j) -> double & { return sG[k * n1 + j]; }, sC);
+            for (int e = tid; e < n1 * n1; e += 256) { const int i = e / n1, j = e - i * n1; if (j < i) sG[e] = sG[j * n1 + i]; }
+            __syncthreads();
+        }
+        if (tid == 0) S.rows_out[3] = (tiny << 8) | (s_bias ? 2 : 0) | (need_qr ? 1 : 0);
+    }
     // ---- 3. T = R P[act, :] with R = L^T (upper): T[i][c] = sum_{k >= i} L[k][i] P[act[k]][c];  T[i][d] = (Q^T r)_i = L[na][i]
     const double *P = S.P;
     for (int c = tid; c < d; c += 256) {
@@ -592,6 +764,14 @@ void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_
     hipLaunchKernelGGL(k_ekf_small_update, dim3(1, n), dim3(256), lds, st, d);
 }
 int ekf_small_update_max_na(void) { return SU_MAX_NA; }
+void ekf_launch_qr(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
+    const int n1 = max_d - EKF_IMU_DIM + 1;
+    const size_t blk = (size_t)QR_BR * n1 * sizeof(double), packed = (size_t)n1 * (n1 + 1) / 2 * sizeof(double);
+    const int r_in_lds = blk + packed <= 150 * 1024 ? 1 : 0;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_qr), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    hipLaunchKernelGGL(k_ekf_qr, dim3(1, n), dim3(256), blk + (r_in_lds ? packed : 0), st, d, r_in_lds);
+}
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
     // the solve runs over the active rows only: n <= max_d - 21 (the IMU columns are never active).  A full 64-clone

@@ -38,7 +38,7 @@ class EkfCfg(C.Structure):
         ("init_velocity", C.c_double * 3),
         ("cov_velocity", C.c_double), ("cov_gyro_bias", C.c_double), ("cov_acc_bias", C.c_double),
         ("cov_ext_rot", C.c_double), ("cov_ext_trans", C.c_double),
-        ("max_stack_rows", C.c_int32), ("_pad", C.c_int32),
+        ("max_stack_rows", C.c_int32), ("compression_mode", C.c_int32),
     ]
 
 
@@ -72,8 +72,8 @@ def default_fe_cfg(grid_row=4, grid_col=5, grid_min=3, grid_max=4, compat=COMPAT
     return c
 
 
-def default_ekf_cfg(max_cam_state_size=20):
-    """config/app_msckfvio.yaml values of the reference."""
+def default_ekf_cfg(max_cam_state_size=20, compression_mode=0):
+    """config/app_msckfvio.yaml values of the reference.  compression_mode: 0 auto, 1 Gram + Cholesky only, 2 Householder TSQR."""
     c = EkfCfg()
     c.frame_rate = 20.0
     c.max_cam_state_size = max_cam_state_size
@@ -86,4 +86,5 @@ def default_ekf_cfg(max_cam_state_size=20):
     c.cov_velocity, c.cov_gyro_bias, c.cov_acc_bias = 0.25, 0.01, 0.01
     c.cov_ext_rot, c.cov_ext_trans = 3.0462e-4, 2.5e-5
     c.max_stack_rows = 1500
+    c.compression_mode = compression_mode
     return c

@@ -297,6 +297,83 @@ def test_ekf_update_ill_conditioned(gpu_ctx, oracle, n_clones, n_feat):
     s.close()
 
 
+def _update_vs_oracle(gpu_ctx, oracle, n_clones, n_feat, seed, mode, dof_offset=-1, cap=True, **kw):
+    calib = oracle.euroc_calib(376, 240)
+    cfg = default_ekf_cfg(max_cam_state_size=max(n_clones, 4), compression_mode=mode)
+    s = capi.Stream(gpu_ctx, calib, default_fe_cfg(), cfg)
+    pr = ekf_problems.make_problem(calib, seed=seed, n_clones=n_clones, n_feat=n_feat, **kw)
+    ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"],
+                                    pr["obs_clone"], pr["obs_z"], dof_offset)
+    s.ekf_set_cov(pr["P"])
+    got = s.ekf_update(pr["gravity"], pr["clones"], pr["positions"], pr["obs_start"], pr["obs_clone"], pr["obs_z"], dof_offset, cap)
+    Pg = s.ekf_get_cov()
+    s.close()
+    st = (got["status"] >> 1) & 1
+    used = sorted(set(int(c) for j in range(n_feat) if st[j] for c in pr["obs_clone"][pr["obs_start"][j]:pr["obs_start"][j + 1]]))
+    return dict(got=got, ref=ref, errP=np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max(),
+                errdx=np.abs(got["delta_x"] - ref["delta_x"]).max() / max(np.abs(ref["delta_x"]).max(), 1e-300),
+                na=6 * len(used), sym=np.array_equal(Pg, Pg.T))
+
+
+@pytest.mark.parametrize("n_clones,n_feat,seed,kw", [
+    (6, 5, 1, {}), (20, 30, 2, {}), (30, 60, 3, {}),                                   # full-rank stacks, the 1500-row cap
+    (29, 4, 129, dict(min_obs=3)), (13, 4, 113, dict(min_obs=3)), (10, 2, 110, dict(min_obs=3)),   # few features over many clones
+    (13, 2, 1301, dict(min_obs=3)), (24, 2, 2402, dict(min_obs=3)),                    # fewer rows than active columns
+    (50, 40, 21, dict(min_obs=20)), (64, 30, 23, dict(min_obs=20)),                    # R does not fit LDS: kept in the W buffer
+    (30, 400, 31, dict(pair=(3, 4), noise=0.004)), (12, 2, 5, dict(pair=(0, 1))),      # pruning shape: inside k_ekf_small_update
+])
+def test_ekf_update_householder_tsqr(gpu_ctx, oracle, n_clones, n_feat, seed, kw):
+    """compression_mode = 2: the QR compression of msckf_vio.cpp:795-817 as Householder row-block TSQR (k_ekf_qr /
+    the TSQR branch of k_ekf_small_update) instead of Gram + Cholesky.  The oracle compresses with Householder QR too, so
+    the two agree to rounding: 1e-9 is the bar, ~1e-15 is what comes out."""
+    pair = "pair" in kw
+    r = _update_vs_oracle(gpu_ctx, oracle, n_clones, n_feat, seed, 2, 0 if pair else -1, not pair, **kw)
+    assert r["got"]["used_qr"] == 1
+    assert r["got"]["rows"] == r["ref"]["rows"] > 0
+    assert r["errP"] < 1e-9 and r["errdx"] < 1e-9 and r["sym"]
+    assert r["errP"] < 1e-12                                   # (what Householder against Householder actually gives)
+
+
+def test_ekf_update_rows_not_more_than_columns_skips_gram(gpu_ctx, oracle):
+    """The reference's m <= d case (msckf_vio.cpp:818-821: no compression when the stack has no more rows than
+    columns): in auto mode the Gram pass and its factorisation are skipped (H^T H would be singular by construction) and
+    the few rows are triangularised directly; with more rows than columns the default Gram path runs."""
+    few = _update_vs_oracle(gpu_ctx, oracle, 13, 2, 1301, 0, min_obs=3)
+    assert few["got"]["rows"] <= few["na"] and few["got"]["used_qr"] == 1
+    assert few["errP"] < 1e-12 and few["errdx"] < 1e-9
+    many = _update_vs_oracle(gpu_ctx, oracle, 13, 8, 1301, 0, min_obs=3)
+    assert many["got"]["rows"] > many["na"] and many["got"]["used_qr"] == 0
+    assert many["errP"] < 2e-9
+
+
+def test_ekf_compression_condition_sweep(gpu_ctx, oracle):
+    """Gram + regularised Cholesky squares cond(H) and adds the prior lambda I; how far can the stack be pushed before
+    that shows?  The generator is driven towards ill conditioning (camera motion between clones shrunk to 1e-4, cond(H)
+    beyond 1e9) and towards large Jacobian entries (features at a few centimetres).  Findings pinned here:
+      * Householder TSQR stays at rounding level against the oracle's Householder QR everywhere;
+      * the Gram path's error does NOT grow with cond(H): the update is regularised by P, the loss is the lambda prior,
+        lambda max(P_aa) / sigma^2, and it grows with the SIZE of H (close features), as the device-side bound predicts;
+      * auto mode switches to TSQR wherever the Gram path would exceed 1e-7, and stays below 1e-7 everywhere."""
+    rows = []
+    for baseline_scale, depth_scale in [(1.0, 1.0), (1e-1, 1.0), (1e-2, 1.0), (1e-3, 1.0), (1e-4, 1.0),
+                                        (1.0, 0.3), (1.0, 0.1), (1.0, 0.03), (1.0, 0.01), (1e-2, 0.03)]:
+        kw = dict(min_obs=3, baseline_scale=baseline_scale, depth_scale=depth_scale, noise=0.002)
+        gram = _update_vs_oracle(gpu_ctx, oracle, 20, 12, 77, 1, **kw)
+        tsqr = _update_vs_oracle(gpu_ctx, oracle, 20, 12, 77, 2, **kw)
+        auto = _update_vs_oracle(gpu_ctx, oracle, 20, 12, 77, 0, **kw)
+        rows.append((baseline_scale, depth_scale, gram["errP"], tsqr["errP"], auto["errP"], auto["got"]["used_qr"], gram["got"]["rows"]))
+        print("baseline x%-6g depth x%-5g rows %4d  |dP|/|P|: gram %.2e  tsqr %.2e  auto %.2e (tsqr used: %d)" % (
+            baseline_scale, depth_scale, gram["got"]["rows"], gram["errP"], tsqr["errP"], auto["errP"], auto["got"]["used_qr"]))
+    for b, dsc, eg, et, ea, used, nrows in rows:
+        if nrows == 0:
+            continue
+        assert et < 1e-9, (b, dsc, et)
+        assert ea < 1e-7, (b, dsc, ea)
+        if eg > 1e-7:
+            assert used == 1, (b, dsc, eg)
+    assert max(r[2] for r in rows if r[1] == 1.0 and r[6] > 0) < 1e-8        # conditioning alone never hurts the Gram path
+
+
 @pytest.mark.parametrize("n_clones,n_feat,seed", [(50, 40, 21), (60, 30, 22), (64, 30, 23)])
 def test_ekf_update_many_clones(gpu_ctx, oracle, n_clones, n_feat, seed):
     """d = 321 / 381 / 405 (the largest window mskf_stream_create accepts): global-memory Cholesky fallback, gating
