@@ -31,7 +31,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Gram + regularised Cholesky adds a prior lambda I to the stacked information H^T H / sigma^2: the posterior covariance
 // moves by about lambda max(P_aa) / sigma^2 relative.  Above this limit (or when the stack has no more rows than active
 // columns) the compression runs as Householder TSQR instead (k_ekf_qr), which has no such term.
-#define QR_BIAS_LIMIT 1e-8
+#define QR_BIAS_LIMIT 1e-6
 // auto mode, stack with no more rows than active columns (the reference compresses nothing there, msckf_vio.cpp:818-821):
 // the Gram pass and its factorisation are skipped, k_ekf_qr triangularises the few rows directly
 __device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]); }

@@ -353,10 +353,11 @@ def test_ekf_compression_condition_sweep(gpu_ctx, oracle):
       * Householder TSQR stays at rounding level against the oracle's Householder QR everywhere;
       * the Gram path's error does NOT grow with cond(H): the update is regularised by P, the loss is the lambda prior,
         lambda max(P_aa) / sigma^2, and it grows with the SIZE of H (close features), as the device-side bound predicts;
-      * auto mode switches to TSQR wherever the Gram path would exceed 1e-7, and stays below 1e-7 everywhere."""
+      * auto mode switches to TSQR where the device-side bound predicts more than 1e-6 (QR_BIAS_LIMIT): it is on TSQR
+        wherever the Gram path would exceed 1e-5 and stays below 1e-6 everywhere."""
     rows = []
     for baseline_scale, depth_scale in [(1.0, 1.0), (1e-1, 1.0), (1e-2, 1.0), (1e-3, 1.0), (1e-4, 1.0),
-                                        (1.0, 0.3), (1.0, 0.1), (1.0, 0.03), (1.0, 0.01), (1e-2, 0.03)]:
+                                        (1.0, 0.3), (1.0, 0.1), (1.0, 0.03), (1.0, 0.01), (1.0, 0.004), (1e-2, 0.03)]:
         kw = dict(min_obs=3, baseline_scale=baseline_scale, depth_scale=depth_scale, noise=0.002)
         gram = _update_vs_oracle(gpu_ctx, oracle, 20, 12, 77, 1, **kw)
         tsqr = _update_vs_oracle(gpu_ctx, oracle, 20, 12, 77, 2, **kw)
@@ -368,8 +369,8 @@ def test_ekf_compression_condition_sweep(gpu_ctx, oracle):
         if nrows == 0:
             continue
         assert et < 1e-9, (b, dsc, et)
-        assert ea < 1e-7, (b, dsc, ea)
-        if eg > 1e-7:
+        assert ea < 1e-6, (b, dsc, ea)
+        if eg > 1e-5:
             assert used == 1, (b, dsc, eg)
     assert max(r[2] for r in rows if r[1] == 1.0 and r[6] > 0) < 1e-8        # conditioning alone never hurts the Gram path
 
