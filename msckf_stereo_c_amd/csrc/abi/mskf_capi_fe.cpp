@@ -245,7 +245,7 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
     size_t cell_bytes = 0;
     {
         for (int i = 0; i < n; ++i) { if (!streams[i] || streams[i]->ctx != ctx) return MSKF_ERR_INVALID; cell_bytes += sizeof(unsigned long long) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
-        if (cell_bytes > ctx->cell_arena.cap) { MSKF_HIPCHK(hipStreamSynchronize(st)); rc = ctx->cell_arena.ensure(cell_bytes); if (rc != MSKF_OK) return rc; }
+        if (cell_bytes > ctx->cell_arena.cap) { MSKF_HIPCHK(hipStreamSynchronize(st)); rc = ctx->cell_arena.ensure(cell_bytes); if (rc != MSKF_OK) return rc; ctx->cell_keys_dirty = true; }
         ++ctx->push_gen;
         size_t off = 0;
         for (int i = 0; i < n; ++i) { streams[i]->cell_off = off; streams[i]->push_gen = ctx->push_gen; off += sizeof(unsigned long long) * (size_t)streams[i]->fe.det_rows * streams[i]->fe.det_cols; }
@@ -271,7 +271,8 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
         s->has_curr = true;
         max_w = std::max(max_w, s->w); max_h = std::max(max_h, s->h);
     }
-    // pyramid levels 1..3 of both cameras, one launch per level over all streams
+    // pyramid levels 1..3 of both cameras; level 1 is fused with the detector (one pass over level 0), levels 2 and 3 are
+    // one launch each over all streams
     int max_dw[MSKF_LEVELS] = {0}, max_dh[MSKF_LEVELS] = {0};
     for (int l = 1; l < MSKF_LEVELS; ++l)
         for (int i = 0; i < n; ++i) {
@@ -287,27 +288,30 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
             max_dw[l] = std::max(max_dw[l], s->lw[l]); max_dh[l] = std::max(max_dh[l], s->lh[l]);
         }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(PyrJob) * (size_t)n * 2 * (MSKF_LEVELS - 1), hipMemcpyHostToDevice, st));
-    for (int l = 1; l < MSKF_LEVELS; ++l) {
+    for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    {
+        // per-cell maxima carry the push generation in their top byte: a newer push wins every atomicMax, so the key
+        // array is cleared only when it is fresh or the 8-bit generation wraps
+        const unsigned int gen = (unsigned int)((ctx->push_gen - 1) % 255ULL) + 1U;
+        if (ctx->cell_keys_dirty || gen == 1U) {
+            MSKF_HIPCHK(hipMemsetAsync(ctx->cell_arena.d, 0, ctx->cell_arena.cap, st));
+            ctx->cell_keys_dirty = false;
+        }
+        long long px0 = 0, px1 = 0;
+        for (int i = 0; i < n; ++i) { px0 += (long long)streams[i]->w * streams[i]->h; px1 += 2LL * streams[i]->lw[1] * streams[i]->lh[1]; }
+        const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
+        fe_launch_pyr_detect(ctx->jobs.d, ctx->desc[0].d, n, max_w, max_h, gen, st);
+        mskf_t_end(ctx, ts, px0 + px1 * 0);      // units: level-0 pixels of cam0 scored (the level-1 outputs ride along)
+    }
+    for (int l = 2; l < MSKF_LEVELS; ++l) {
         long long px = 0;
         for (int i = 0; i < n; ++i) px += 2LL * streams[i]->lw[l] * streams[i]->lh[l];
         const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
         fe_launch_pyr_down(ctx->jobs.d + (size_t)(l - 1) * 2 * n, 2 * n, max_dw[l], max_dh[l], st);
         mskf_t_end(ctx, ts, px);
     }
-    // detector per-cell maxima on cam0 level 0
-    for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-    {
-        long long px = 0;
-        for (int i = 0; i < n; ++i) px += (long long)streams[i]->w * streams[i]->h;
-        MSKF_HIPCHK(hipMemsetAsync(ctx->cell_arena.d, 0, cell_bytes, st));   // keys are merged with atomicMax
-        const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
-        fe_launch_detect(ctx->desc[0].d, n, max_w, max_h, st);
-        mskf_t_end(ctx, ts, px);
-    }
-    {
-        MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
-    }
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
     MSKF_HIPCHK(hipGetLastError());
     return MSKF_OK;
 }
@@ -342,14 +346,18 @@ extern "C" int mskf_fe_push_stereo_device(mskf_stream *s, const uint8_t *d_cam0,
     return mskf_fe_push_stereo_batch(s->ctx, 1, ss, a, b, 1);
 }
 
-// keys -> corners: score << 32 | ~order, order = row-major position inside the cell (0 = no corner)
+// keys -> corners: gen (8) | score (24) | ~order (32), order = row-major position inside the cell; a key of another
+// generation (an older push, or 0) means no corner in this one
+static inline unsigned int stream_gen(const mskf_stream *s) { return (unsigned int)((s->push_gen - 1) % 255ULL) + 1U; }
+static inline long long score_of_key(unsigned long long k, unsigned int gen) { return (k >> 56) == gen ? (long long)((k >> 32) & 0xFFFFFFULL) : 0LL; }
 static inline void corner_of_key(const mskf_stream *s, int cell, unsigned long long k, mskf_corner &o) {
     o.cell = cell;
-    if (k == 0ULL) { o.x = 0.f; o.y = 0.f; o.score = 0; return; }
+    const long long sc = score_of_key(k, stream_gen(s));
+    if (sc == 0) { o.x = 0.f; o.y = 0.f; o.score = 0; return; }
     const int cols = s->fe.det_cols, cw = s->det_cw, ch = s->det_ch;
     const unsigned int order = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFULL);
     const int cy = cell / cols, cx = cell - cy * cols;
-    o.score = (int)(k >> 32);
+    o.score = (int)sc;
     o.y = (float)(cy * ch + (int)(order / (unsigned)cw));
     o.x = (float)(cx * cw + (int)(order % (unsigned)cw));
 }
@@ -380,10 +388,11 @@ extern "C" int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_c
     const int rc = cell_keys_ready(s);
     if (rc != MSKF_OK) return rc;
     const unsigned long long *keys = (const unsigned long long *)(s->ctx->cell_arena.h + s->cell_off);
+    const unsigned int gen = stream_gen(s);
     int m = 0;
     for (int cell = 0; cell < n; ++cell) {
         const unsigned long long k = keys[cell];
-        if ((long long)(k >> 32) <= (long long)min_score) continue;       // also skips empty cells (key 0)
+        if (score_of_key(k, gen) <= (long long)min_score) continue;       // also skips empty cells (no key of this generation)
         if (m >= capacity) return MSKF_ERR_CAPACITY;
         corner_of_key(s, cell, k, out[m++]);
     }

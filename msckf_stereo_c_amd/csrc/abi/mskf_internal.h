@@ -16,7 +16,7 @@ void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_
 // more waiting host threads than it has cores to spin on) parks the thread on an interrupt-driven event instead of
 // spinning in hipStreamSynchronize, leaving the core to the other groups' host phases.
 int mskf_wait(mskf_ctx *c);
-void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, hipStream_t st);
+void fe_launch_pyr_detect(const PyrJob *jobs_dev, const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st);
 void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st);
 void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st);
 }
@@ -68,6 +68,7 @@ struct mskf_ctx {
     PinnedDev<char> cell_arena;       // per-cell maximum keys of every stream of the last push batch (one D2H copy)
     PinnedDev<char> trk_in, trk_out;  // input points / results of every stream of a track batch (one copy each way)
     unsigned long long push_gen = 0;
+    bool cell_keys_dirty = true;      // the key array holds bytes no generation tag explains (fresh allocation): clear before use
     PinnedDev<PyrJob> jobs;
     PinnedDev<EkfStreamDev> ekf_desc;
     PinnedDev<char> upd_in, upd_out;     // inputs / results of every stream of an update batch (one copy each way)

@@ -1,7 +1,8 @@
 // fe_kernels.hip — hand-written gfx950 kernels of the stereo KLT front-end.
 //
-//  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242)
-//  k_detect_cells : cg::CornerDetector      (:132,259,657) — per-cell integer Shi-Tomasi maximum (32x32 px tiles)
+//  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242), levels 2 and 3
+//  k_pyr_detect   : level 1 of both pyramids fused with cg::CornerDetector (:132,259,657) — per-cell integer Shi-Tomasi
+//                   maximum — on cam0: one pass over level 0
 //  k_lk_points    : cg::optical_flow_multi_level (:410 temporal, :569 stereo) fused with the
 //                   prediction (:321-350), the image-bounds gates (:416-424, :575-583), the stereo
 //                   initial guess (:542-548), undistortion and the epipolar gate (:587-617).
@@ -9,7 +10,7 @@
 // Arithmetic contract: every decision-bearing quantity is integer or a fixed
 // sequence of IEEE-754 double operations; this file must be compiled with -ffp-contract=off.
 // Work shapes: one 64-lane wavefront per tracked point (a 15x15 window = 225 pixels, <= 4 per
-// lane), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
+// lane), one workgroup per 128x32 level-0 region (level-1 tile + four 32x32 detector sub-tiles), one per 64x16 pyramid output tile; the
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
 #include "fe_device.h"
@@ -80,14 +81,25 @@ extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_d
     hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, st, jobs_dev);
 }
 
-// ------------------------------------------------------------------------------------------ detector
+// ------------------------------------------------------------------------------------------ detector (fused with level 1)
 #define DET_BORDER 8
-#define DTW 32                 // tile of output pixels per workgroup
+#define DTW 32                 // detector sub-tile: 32 x 32 output pixels
 #define DTH 32
-#define DSW 48                 // staged bytes per row: image x in [tx0-8, tx0+40)
-#define DSH 42                 // staged rows:          image y in [ty0-5, ty0+37)
-#define DPW 40                 // gradient-product plane: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
-#define DET_SLOTS 64           // per-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
+#define DPW 40                 // gradient-product plane of a sub-tile: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
+#define DET_SLOTS 64           // per-sub-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
+#define PDF_W (2 * PD_TW)      // level-0 region of a workgroup: 128 x 32 pixels = one 64 x 16 level-1 tile = four detector sub-tiles
+#define PDF_H (2 * PD_TH)
+#define PDF_SW (PDF_W + 16)    // staged bytes per row: image x in [x0 - 8, x0 + 136)
+#define PDF_SH (PDF_H + 10)    // staged rows:          image y in [y0 - 5, y0 + 37)
+
+// Per-cell maxima are merged as 64-bit keys  gen (8 bits) | score (24 bits) | ~order (32 bits):
+//   score  = integer Shi-Tomasi score (< 2^24: two sums of 64 squared differences of bytes),
+//   order  = row-major position inside the cell, complemented, so ties go to the first pixel in scan order,
+//   gen    = push generation of the context (1..255): a newer push always wins the atomicMax, so the key array is
+//            never cleared between frames (only when the generation wraps or the array is reallocated).
+__device__ __forceinline__ unsigned long long det_key(unsigned int gen, int score, unsigned int order) {
+    return ((unsigned long long)gen << 56) | ((unsigned long long)(unsigned int)score << 32) | (0xFFFFFFFFu - order);
+}
 
 // floor(sqrt(v)) for 0 <= v < 2^48, exact: the hardware estimate is corrected with integer compares.
 __device__ __forceinline__ unsigned int isqrt48(unsigned long long v, double vd) {
@@ -97,80 +109,48 @@ __device__ __forceinline__ unsigned int isqrt48(unsigned long long v, double vd)
     return r;
 }
 
-// cg::CornerDetector per-cell maxima.  One workgroup scores a 32x32 pixel tile: the u8 footprint is staged in
-// LDS once (border pixels replicated), the three gradient products dx*dx, dx*dy, dy*dy are formed once per
-// pixel, the 8x8 box sums are separable with sliding windows (horizontal runs of 8, vertical runs of 4), the
-// integer Shi-Tomasi score (a + c) - isqrt((a - c)^2 + 4 b^2) is exact, and per-cell maxima are merged as
-// 64-bit keys  score << 32 | ~order  (order = row-major position inside the cell, so ties go to the first
-// pixel in scan order) through LDS atomics and one global atomicMax per touched cell.  The key array must be
-// zero before the launch; mskf_fe_get_cell_maxima turns keys into mskf_corner records.
-__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams, int tiles_x) {
-    const FeStreamDev &S = streams[blockIdx.y];
+struct DetLds {
+    int P[3][DPW * DPW];
+    int H[3][DPW * DTW];
+    unsigned long long key[DET_SLOTS];
+    int cx[DTW], cy[DTH];
+};
+
+// cg::CornerDetector per-cell maxima of one 32 x 32 sub-tile at image (tx0, ty0).  t8 points at the staged byte of image
+// (ty0 - 5, tx0 - 8), rows `stride` bytes apart, border pixels replicated.  The three gradient products dx*dx, dx*dy, dy*dy
+// are formed once per pixel, the 8x8 box sums are separable with sliding windows (horizontal runs of 8, vertical runs of
+// 4), the integer Shi-Tomasi score (a + c) - isqrt((a - c)^2 + 4 b^2) is exact.  All 256 threads of the workgroup call this.
+__device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t *t8, int stride, int tx0, int ty0, unsigned int gen, DetLds &L) {
     const int W = S.curr0.w[0], H = S.curr0.h[0];
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int tx0 = txi * DTW, ty0 = tyi * DTH;
-    if (tx0 >= W || ty0 >= H) return;
-    const uint8_t *img = S.curr0.lvl[0];
     const int cw = S.cell_w, ch = S.cell_h;
     const int tid = threadIdx.x;
-
-    __shared__ uint32_t s_tile[DSW / 4 * DSH];
-    __shared__ int s_P[3][DPW * DPW];
-    __shared__ int s_H[3][DPW * DTW];
-    __shared__ unsigned long long s_key[DET_SLOTS];
-    __shared__ int s_cx[DTW], s_cy[DTH];
-
-    // ---- stage the footprint
-    const int sx0 = tx0 - 8, sy0 = ty0 - 5;
-    const bool fast = sx0 >= 0 && sy0 >= 0 && sx0 + DSW <= W && sy0 + DSH <= H;
-    if (fast) {
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        for (int i = tid; i < DSW / 4 * DSH; i += 256) {
-            const int r = i / (DSW / 4), c = i - r * (DSW / 4);
-            s_tile[i] = *(const u32u *)(img + (size_t)(sy0 + r) * W + sx0 + 4 * c);
-        }
-    } else {
-        uint8_t *t8 = (uint8_t *)s_tile;
-        for (int i = tid; i < DSW * DSH; i += 256) {
-            const int r = i / DSW, c = i - r * DSW;
-            const int gx = min(max(sx0 + c, 0), W - 1), gy = min(max(sy0 + r, 0), H - 1);
-            t8[i] = img[(size_t)gy * W + gx];
-        }
-    }
-    if (tid < DTW) s_cx[tid] = (tx0 + tid) / cw;
-    else if (tid < DTW + DTH) s_cy[tid - DTW] = (ty0 + tid - DTW) / ch;
-    if (tid < DET_SLOTS) s_key[tid] = 0ULL;
-    __syncthreads();
-
+    if (tid < DTW) L.cx[tid] = (tx0 + tid) / cw;
+    else if (tid < DTW + DTH) L.cy[tid - DTW] = (ty0 + tid - DTW) / ch;
+    if (tid < DET_SLOTS) L.key[tid] = 0ULL;
     // ---- gradient products at image (ty0-4+r, tx0-4+c): staged position (r+1, c+4)
-    {
-        const uint8_t *t8 = (const uint8_t *)s_tile;
-        for (int i = tid; i < DPW * DPW; i += 256) {
-            const int r = i / DPW, c = i - r * DPW;
-            const uint8_t *t = t8 + (r + 1) * DSW + (c + 4);
-            const int dx = (int)t[1] - (int)t[-1];
-            const int dy = (int)t[DSW] - (int)t[-DSW];
-            s_P[0][i] = dx * dx; s_P[1][i] = dx * dy; s_P[2][i] = dy * dy;
-        }
+    for (int i = tid; i < DPW * DPW; i += 256) {
+        const int r = i / DPW, c = i - r * DPW;
+        const uint8_t *t = t8 + (r + 1) * stride + (c + 4);
+        const int dx = (int)t[1] - (int)t[-1];
+        const int dy = (int)t[stride] - (int)t[-stride];
+        L.P[0][i] = dx * dx; L.P[1][i] = dx * dy; L.P[2][i] = dy * dy;
     }
     __syncthreads();
-
     // ---- horizontal 8-sums: item = (plane, row, run of 8 outputs)
     for (int it = tid; it < 3 * DPW * (DTW / 8); it += 256) {
         const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
         const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
-        const int *src = s_P[pl] + r * DPW + 8 * q;
+        const int *src = L.P[pl] + r * DPW + 8 * q;
         int v[15];
 #pragma unroll
         for (int u = 0; u < 15; ++u) v[u] = src[u];
         int acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        int *dst = s_H[pl] + r * DTW + 8 * q;
+        int *dst = L.H[pl] + r * DTW + 8 * q;
         dst[0] = acc;
 #pragma unroll
         for (int u = 1; u < 8; ++u) { acc += v[u + 7] - v[u - 1]; dst[u] = acc; }
     }
     __syncthreads();
-
     // ---- vertical 8-sums + score: thread = (column c, run of 4 rows)
     {
         const int c = tid & (DTW - 1), q = tid >> 5;          // 32 columns x 8 runs
@@ -181,7 +161,7 @@ __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams
 #pragma unroll
             for (int u = 0; u < 11; ++u) {
                 const int o = (4 * q + u) * DTW + c;
-                v0[u] = s_H[0][o]; v1[u] = s_H[1][o]; v2[u] = s_H[2][o];
+                v0[u] = L.H[0][o]; v1[u] = L.H[1][o]; v2[u] = L.H[2][o];
             }
             int a = 0, b = 0, d = 0;
 #pragma unroll
@@ -193,9 +173,9 @@ __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams
                 sa[u] = a; sb[u] = b; sc[u] = d;
             }
         }
-        const int cx = s_cx[c];
-        const int cx_first = s_cx[0], cy_first = s_cy[0];
-        const int ncx = s_cx[DTW - 1] - cx_first + 1, ncy = s_cy[DTH - 1] - cy_first + 1;
+        const int cx = L.cx[c];
+        const int cx_first = L.cx[0], cy_first = L.cy[0];
+        const int ncx = L.cx[DTW - 1] - cx_first + 1, ncy = L.cy[DTH - 1] - cy_first + 1;
         const bool use_lds = ncx * ncy <= DET_SLOTS;
         const bool x_ok = x >= DET_BORDER && x < W - DET_BORDER;
         int cur_cell = -1, cur_slot = 0;
@@ -210,36 +190,110 @@ __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams
             const double discd = (double)df * (double)df + 4.0 * ((double)b * (double)b);   // exact: < 2^48
             const int score = (a + d) - (int)isqrt48((unsigned long long)disc, discd);
             if (score <= 0) continue;
-            const int cy = s_cy[4 * q + u];
+            const int cy = L.cy[4 * q + u];
             const int cell = cy * S.det_cols + cx;
             const unsigned int order = (unsigned int)((y - cy * ch) * cw + (x - cx * cw));
-            const unsigned long long key = ((unsigned long long)(unsigned int)score << 32) | (0xFFFFFFFFu - order);
+            const unsigned long long key = det_key(gen, score, order);
             if (cell != cur_cell) {
                 if (cur_key) {
-                    if (use_lds) atomicMax(&s_key[cur_slot], cur_key);
+                    if (use_lds) atomicMax(&L.key[cur_slot], cur_key);
                     else atomicMax(&S.cell_keys[cur_cell], cur_key);
                 }
                 cur_cell = cell; cur_slot = (cy - cy_first) * ncx + (cx - cx_first); cur_key = key;
             } else if (key > cur_key) cur_key = key;
         }
         if (cur_key) {
-            if (use_lds) atomicMax(&s_key[cur_slot], cur_key);
+            if (use_lds) atomicMax(&L.key[cur_slot], cur_key);
             else atomicMax(&S.cell_keys[cur_cell], cur_key);
         }
         __syncthreads();
         if (use_lds && tid < ncx * ncy) {
-            const unsigned long long k = s_key[tid];
+            const unsigned long long k = L.key[tid];
             if (k) {
                 const int ly = tid / ncx, lx = tid - ly * ncx;
                 atomicMax(&S.cell_keys[(cy_first + ly) * S.det_cols + (cx_first + lx)], k);
             }
         }
     }
+    __syncthreads();
 }
 
-extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, hipStream_t st) {
-    const int tiles_x = (max_w + DTW - 1) / DTW, tiles_y = (max_h + DTH - 1) / DTH;
-    hipLaunchKernelGGL(k_detect_cells, dim3(tiles_x * tiles_y, n_streams), dim3(256), 0, st, streams_dev, tiles_x);
+// Level 1 of both pyramids of every stream and, for cam0, the detector's per-cell maxima, from ONE pass over level 0:
+// a workgroup stages a 128 x 32 pixel region (+ halo) of level 0 once, writes the 64 x 16 level-1 tile it covers
+// ([1 4 6 4 1] separable, (s+128)>>8, BORDER_REFLECT_101) and, for cam0, scores the region as four 32 x 32 detector
+// sub-tiles out of the same LDS bytes.  jobs[2 i + c] = level-1 job of camera c of stream i.
+__global__ __launch_bounds__(256) void k_pyr_detect(const PyrJob *jobs, const FeStreamDev *streams, unsigned int gen) {
+    const PyrJob job = jobs[blockIdx.z];
+    const int x0 = blockIdx.x * PDF_W, y0 = blockIdx.y * PDF_H;             // level-0 origin of the region
+    if (x0 >= job.sw || y0 >= job.sh) return;
+    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;           // level-1 origin of the tile
+    __shared__ __attribute__((aligned(8))) uint8_t s_src[PDF_SH][PDF_SW];
+    __shared__ uint16_t s_h[2 * PD_TH + 4][PD_TW];
+    __shared__ DetLds s_det;
+    const int tid = threadIdx.x;
+    const int sx0 = x0 - 8, sy0 = y0 - 5;
+    const bool inside = sx0 >= 0 && sy0 >= 0 && sx0 + PDF_SW <= job.sw && sy0 + PDF_SH <= job.sh;
+    if (inside) {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        const uint8_t *base = job.src + (size_t)sy0 * job.sw + sx0;
+        for (int i = tid; i < (PDF_SW / 4) * PDF_SH; i += 256) {
+            const int r = i / (PDF_SW / 4), c = i - r * (PDF_SW / 4);
+            *reinterpret_cast<uint32_t *>(&s_src[r][4 * c]) = *reinterpret_cast<const u32u *>(base + (size_t)r * job.sw + 4 * c);
+        }
+    } else {
+        // border region: pixels replicated (what the detector wants; the pyramid reflects and reads level 0 itself below)
+        for (int i = tid; i < PDF_SW * PDF_SH; i += 256) {
+            const int r = i / PDF_SW, c = i - r * PDF_SW;
+            const int gx = min(max(sx0 + c, 0), job.sw - 1), gy = min(max(sy0 + r, 0), job.sh - 1);
+            s_src[r][c] = job.src[(size_t)gy * job.sw + gx];
+        }
+    }
+    __syncthreads();
+    // ---- level 1: horizontal pass into s_h (source rows 2 oy0 - 2 .. 2 oy0 + 33 = staged rows 3 .. 38), then vertical
+    constexpr int SH = 2 * PD_TH + 4;
+    for (int i = tid; i < SH * PD_TW; i += 256) {
+        const int r = i / PD_TW, c = i - r * PD_TW;
+        int v;
+        if (inside) {
+            const uint8_t *p = &s_src[r + 3][2 * c + 6];                   // image x = 2 (ox0 + c) - 2 -> staged column 2 c + 6
+            v = p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4];
+        } else {
+            // image border: BORDER_REFLECT_101 differs from the replicated staging only in WHICH pixel stands in for one
+            // outside the image, and the mirrored pixel (at most 2 inside the edge) is in the staged region as well
+            const uint8_t *row = s_src[min(max(reflect101(2 * oy0 - 2 + r, job.sh) - sy0, 0), PDF_SH - 1)];   // (clamped: rows past the image feed no output)
+            const int gx = 2 * (ox0 + c) - 2;
+            v = 0;
+            if (gx - 2 < job.sw) {           // (columns of the tile beyond the image produce no output)
+                v = row[reflect101(gx, job.sw) - sx0] + 4 * row[reflect101(gx + 1, job.sw) - sx0] + 6 * row[reflect101(gx + 2, job.sw) - sx0] +
+                    4 * row[reflect101(gx + 3, job.sw) - sx0] + row[reflect101(gx + 4, job.sw) - sx0];
+            }
+        }
+        s_h[r][c] = (uint16_t)v;
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_TW * PD_TH; i += 256) {
+        const int r = i / PD_TW, c = i - r * PD_TW;
+        const int ox = ox0 + c, oy = oy0 + r;
+        if (ox < job.dw && oy < job.dh) {
+            const int sv = s_h[2 * r][c] + 4 * s_h[2 * r + 1][c] + 6 * s_h[2 * r + 2][c] + 4 * s_h[2 * r + 3][c] + s_h[2 * r + 4][c];
+            job.dst[(size_t)oy * job.dw + ox] = (uint8_t)((sv + 128) >> 8);
+        }
+    }
+    // ---- detector on cam0: four 32 x 32 sub-tiles of the staged region
+    if ((blockIdx.z & 1) == 0) {
+        const FeStreamDev &S = streams[blockIdx.z >> 1];
+#pragma unroll 1
+        for (int sub = 0; sub < PDF_W / DTW; ++sub) {
+            const int tx0 = x0 + DTW * sub;
+            if (tx0 >= job.sw) break;
+            detect_tile(S, &s_src[0][DTW * sub], PDF_SW, tx0, y0, gen, s_det);
+        }
+    }
+}
+
+extern "C" void fe_launch_pyr_detect(const PyrJob *jobs_dev, const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st) {
+    dim3 grid((max_w + PDF_W - 1) / PDF_W, (max_h + PDF_H - 1) / PDF_H, 2 * n_streams);
+    hipLaunchKernelGGL(k_pyr_detect, grid, dim3(256), 0, st, jobs_dev, streams_dev, gen);
 }
 
 // ------------------------------------------------------------------------------------------ point math
