@@ -422,8 +422,7 @@ def main(argv=None):
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
         else:
-            # k_pyr_detect: per cam0 level-0 pixel both level-0 images are read once and a quarter pixel of each level 1 is written
-            per_unit = {"k_lk_points": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_pyr_detect": 2.5}.get(dom, 0)
+            per_unit = {"k_lk_points": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
             achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}

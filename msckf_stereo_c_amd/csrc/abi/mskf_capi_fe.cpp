@@ -271,8 +271,7 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
         s->has_curr = true;
         max_w = std::max(max_w, s->w); max_h = std::max(max_h, s->h);
     }
-    // pyramid levels 1..3 of both cameras; level 1 is fused with the detector (one pass over level 0), levels 2 and 3 are
-    // one launch each over all streams
+    // pyramid levels 1..3 of both cameras, one launch per level over all streams
     int max_dw[MSKF_LEVELS] = {0}, max_dh[MSKF_LEVELS] = {0};
     for (int l = 1; l < MSKF_LEVELS; ++l)
         for (int i = 0; i < n; ++i) {
@@ -288,27 +287,28 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
             max_dw[l] = std::max(max_dw[l], s->lw[l]); max_dh[l] = std::max(max_dh[l], s->lh[l]);
         }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(PyrJob) * (size_t)n * 2 * (MSKF_LEVELS - 1), hipMemcpyHostToDevice, st));
+    for (int l = 1; l < MSKF_LEVELS; ++l) {
+        long long px = 0;
+        for (int i = 0; i < n; ++i) px += 2LL * streams[i]->lw[l] * streams[i]->lh[l];
+        const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
+        fe_launch_pyr_down(ctx->jobs.d + (size_t)(l - 1) * 2 * n, 2 * n, max_dw[l], max_dh[l], st);
+        mskf_t_end(ctx, ts, px);
+    }
+    // detector per-cell maxima on cam0 level 0
     for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
     {
-        // per-cell maxima carry the push generation in their top byte: a newer push wins every atomicMax, so the key
-        // array is cleared only when it is fresh or the 8-bit generation wraps
+        // the keys carry the push generation in their top byte: a newer push wins every atomicMax, so the key array is
+        // cleared only when it is fresh or the 8-bit generation wraps (not once per frame)
         const unsigned int gen = (unsigned int)((ctx->push_gen - 1) % 255ULL) + 1U;
         if (ctx->cell_keys_dirty || gen == 1U) {
             MSKF_HIPCHK(hipMemsetAsync(ctx->cell_arena.d, 0, ctx->cell_arena.cap, st));
             ctx->cell_keys_dirty = false;
         }
-        long long px0 = 0, px1 = 0;
-        for (int i = 0; i < n; ++i) { px0 += (long long)streams[i]->w * streams[i]->h; px1 += 2LL * streams[i]->lw[1] * streams[i]->lh[1]; }
-        const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
-        fe_launch_pyr_detect(ctx->jobs.d, ctx->desc[0].d, n, max_w, max_h, gen, st);
-        mskf_t_end(ctx, ts, px0 + px1 * 0);      // units: level-0 pixels of cam0 scored (the level-1 outputs ride along)
-    }
-    for (int l = 2; l < MSKF_LEVELS; ++l) {
         long long px = 0;
-        for (int i = 0; i < n; ++i) px += 2LL * streams[i]->lw[l] * streams[i]->lh[l];
-        const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
-        fe_launch_pyr_down(ctx->jobs.d + (size_t)(l - 1) * 2 * n, 2 * n, max_dw[l], max_dh[l], st);
+        for (int i = 0; i < n; ++i) px += (long long)streams[i]->w * streams[i]->h;
+        const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
+        fe_launch_detect(ctx->desc[0].d, n, max_w, max_h, gen, st);
         mskf_t_end(ctx, ts, px);
     }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));

@@ -16,7 +16,7 @@ void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_
 // more waiting host threads than it has cores to spin on) parks the thread on an interrupt-driven event instead of
 // spinning in hipStreamSynchronize, leaving the core to the other groups' host phases.
 int mskf_wait(mskf_ctx *c);
-void fe_launch_pyr_detect(const PyrJob *jobs_dev, const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st);
+void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st);
 void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st);
 void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st);
 }

@@ -1,8 +1,7 @@
 // fe_kernels.hip — hand-written gfx950 kernels of the stereo KLT front-end.
 //
-//  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242), levels 2 and 3
-//  k_pyr_detect   : level 1 of both pyramids fused with cg::CornerDetector (:132,259,657) — per-cell integer Shi-Tomasi
-//                   maximum — on cam0: one pass over level 0
+//  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242)
+//  k_detect_cells : cg::CornerDetector      (:132,259,657) — per-cell integer Shi-Tomasi maximum (32x32 px tiles)
 //  k_lk_points    : cg::optical_flow_multi_level (:410 temporal, :569 stereo) fused with the
 //                   prediction (:321-350), the image-bounds gates (:416-424, :575-583), the stereo
 //                   initial guess (:542-548), undistortion and the epipolar gate (:587-617).
@@ -10,7 +9,7 @@
 // Arithmetic contract: every decision-bearing quantity is integer or a fixed
 // sequence of IEEE-754 double operations; this file must be compiled with -ffp-contract=off.
 // Work shapes: one 64-lane wavefront per tracked point (a 15x15 window = 225 pixels, <= 4 per
-// lane), one workgroup per 128x32 level-0 region (level-1 tile + four 32x32 detector sub-tiles), one per 64x16 pyramid output tile; the
+// lane), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
 #include "fe_device.h"
@@ -81,16 +80,14 @@ extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_d
     hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, st, jobs_dev);
 }
 
-// ------------------------------------------------------------------------------------------ detector (fused with level 1)
+// ------------------------------------------------------------------------------------------ detector
 #define DET_BORDER 8
-#define DTW 32                 // detector sub-tile: 32 x 32 output pixels
+#define DTW 32                 // detector tile: 32 x 32 output pixels
 #define DTH 32
-#define DPW 40                 // gradient-product plane of a sub-tile: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
-#define DET_SLOTS 64           // per-sub-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
-#define PDF_W (2 * PD_TW)      // level-0 region of a workgroup: 128 x 32 pixels = one 64 x 16 level-1 tile = four detector sub-tiles
-#define PDF_H (2 * PD_TH)
-#define PDF_SW (PDF_W + 16)    // staged bytes per row: image x in [x0 - 8, x0 + 136)
-#define PDF_SH (PDF_H + 10)    // staged rows:          image y in [y0 - 5, y0 + 37)
+#define DPW 40                 // gradient-product plane of a tile: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
+#define DET_SLOTS 64           // per-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
+#define DSW 48                 // staged bytes per row: image x in [tx0-8, tx0+40)
+#define DSH 42                 // staged rows:          image y in [ty0-5, ty0+37)
 
 // Per-cell maxima are merged as 64-bit keys  gen (8 bits) | score (24 bits) | ~order (32 bits):
 //   score  = integer Shi-Tomasi score (< 2^24: two sums of 64 squared differences of bytes),
@@ -116,7 +113,7 @@ struct DetLds {
     int cx[DTW], cy[DTH];
 };
 
-// cg::CornerDetector per-cell maxima of one 32 x 32 sub-tile at image (tx0, ty0).  t8 points at the staged byte of image
+// cg::CornerDetector per-cell maxima of one 32 x 32 tile at image (tx0, ty0).  t8 points at the staged byte of image
 // (ty0 - 5, tx0 - 8), rows `stride` bytes apart, border pixels replicated.  The three gradient products dx*dx, dx*dy, dy*dy
 // are formed once per pixel, the 8x8 box sums are separable with sliding windows (horizontal runs of 8, vertical runs of
 // 4), the integer Shi-Tomasi score (a + c) - isqrt((a - c)^2 + 4 b^2) is exact.  All 256 threads of the workgroup call this.
@@ -218,82 +215,45 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
     __syncthreads();
 }
 
-// Level 1 of both pyramids of every stream and, for cam0, the detector's per-cell maxima, from ONE pass over level 0:
-// a workgroup stages a 128 x 32 pixel region (+ halo) of level 0 once, writes the 64 x 16 level-1 tile it covers
-// ([1 4 6 4 1] separable, (s+128)>>8, BORDER_REFLECT_101) and, for cam0, scores the region as four 32 x 32 detector
-// sub-tiles out of the same LDS bytes.  jobs[2 i + c] = level-1 job of camera c of stream i.
-__global__ __launch_bounds__(256) void k_pyr_detect(const PyrJob *jobs, const FeStreamDev *streams, unsigned int gen) {
-    const PyrJob job = jobs[blockIdx.z];
-    const int x0 = blockIdx.x * PDF_W, y0 = blockIdx.y * PDF_H;             // level-0 origin of the region
-    if (x0 >= job.sw || y0 >= job.sh) return;
-    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;           // level-1 origin of the tile
-    __shared__ __attribute__((aligned(8))) uint8_t s_src[PDF_SH][PDF_SW];
-    __shared__ uint16_t s_h[2 * PD_TH + 4][PD_TW];
+// cg::CornerDetector per-cell maxima of cam0 level 0: one workgroup per 32 x 32 pixel tile, its 48 x 42 byte footprint
+// staged in LDS once (border pixels replicated).
+// (Tried and dropped, round 2: fusing this pass into the level-1 pyr_down tile pass — one workgroup staging a 128 x 32
+// region of level 0, writing its level-1 tile and scoring the region as four sub-tiles.  It removes a launch and the
+// second read of cam0, but the detector is LDS / latency bound, not bandwidth bound: four serial sub-tiles per workgroup
+// at 46 KB of LDS ran 33 % slower than the two separate kernels, 315 vs 237 ms per 40 steps.)
+__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams, int tiles_x, unsigned int gen) {
+    const FeStreamDev &S = streams[blockIdx.y];
+    const int W = S.curr0.w[0], H = S.curr0.h[0];
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int tx0 = txi * DTW, ty0 = tyi * DTH;
+    if (tx0 >= W || ty0 >= H) return;
+    const uint8_t *img = S.curr0.lvl[0];
+    __shared__ uint32_t s_tile[DSW / 4 * DSH];
     __shared__ DetLds s_det;
     const int tid = threadIdx.x;
-    const int sx0 = x0 - 8, sy0 = y0 - 5;
-    const bool inside = sx0 >= 0 && sy0 >= 0 && sx0 + PDF_SW <= job.sw && sy0 + PDF_SH <= job.sh;
-    if (inside) {
+    const int sx0 = tx0 - 8, sy0 = ty0 - 5;
+    const bool fast = sx0 >= 0 && sy0 >= 0 && sx0 + DSW <= W && sy0 + DSH <= H;
+    if (fast) {
         typedef uint32_t __attribute__((aligned(1))) u32u;
-        const uint8_t *base = job.src + (size_t)sy0 * job.sw + sx0;
-        for (int i = tid; i < (PDF_SW / 4) * PDF_SH; i += 256) {
-            const int r = i / (PDF_SW / 4), c = i - r * (PDF_SW / 4);
-            *reinterpret_cast<uint32_t *>(&s_src[r][4 * c]) = *reinterpret_cast<const u32u *>(base + (size_t)r * job.sw + 4 * c);
+        for (int i = tid; i < DSW / 4 * DSH; i += 256) {
+            const int r = i / (DSW / 4), c = i - r * (DSW / 4);
+            s_tile[i] = *(const u32u *)(img + (size_t)(sy0 + r) * W + sx0 + 4 * c);
         }
     } else {
-        // border region: pixels replicated (what the detector wants; the pyramid reflects and reads level 0 itself below)
-        for (int i = tid; i < PDF_SW * PDF_SH; i += 256) {
-            const int r = i / PDF_SW, c = i - r * PDF_SW;
-            const int gx = min(max(sx0 + c, 0), job.sw - 1), gy = min(max(sy0 + r, 0), job.sh - 1);
-            s_src[r][c] = job.src[(size_t)gy * job.sw + gx];
+        uint8_t *t8 = (uint8_t *)s_tile;
+        for (int i = tid; i < DSW * DSH; i += 256) {
+            const int r = i / DSW, c = i - r * DSW;
+            const int gx = min(max(sx0 + c, 0), W - 1), gy = min(max(sy0 + r, 0), H - 1);
+            t8[i] = img[(size_t)gy * W + gx];
         }
     }
     __syncthreads();
-    // ---- level 1: horizontal pass into s_h (source rows 2 oy0 - 2 .. 2 oy0 + 33 = staged rows 3 .. 38), then vertical
-    constexpr int SH = 2 * PD_TH + 4;
-    for (int i = tid; i < SH * PD_TW; i += 256) {
-        const int r = i / PD_TW, c = i - r * PD_TW;
-        int v;
-        if (inside) {
-            const uint8_t *p = &s_src[r + 3][2 * c + 6];                   // image x = 2 (ox0 + c) - 2 -> staged column 2 c + 6
-            v = p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4];
-        } else {
-            // image border: BORDER_REFLECT_101 differs from the replicated staging only in WHICH pixel stands in for one
-            // outside the image, and the mirrored pixel (at most 2 inside the edge) is in the staged region as well
-            const uint8_t *row = s_src[min(max(reflect101(2 * oy0 - 2 + r, job.sh) - sy0, 0), PDF_SH - 1)];   // (clamped: rows past the image feed no output)
-            const int gx = 2 * (ox0 + c) - 2;
-            v = 0;
-            if (gx - 2 < job.sw) {           // (columns of the tile beyond the image produce no output)
-                v = row[reflect101(gx, job.sw) - sx0] + 4 * row[reflect101(gx + 1, job.sw) - sx0] + 6 * row[reflect101(gx + 2, job.sw) - sx0] +
-                    4 * row[reflect101(gx + 3, job.sw) - sx0] + row[reflect101(gx + 4, job.sw) - sx0];
-            }
-        }
-        s_h[r][c] = (uint16_t)v;
-    }
-    __syncthreads();
-    for (int i = tid; i < PD_TW * PD_TH; i += 256) {
-        const int r = i / PD_TW, c = i - r * PD_TW;
-        const int ox = ox0 + c, oy = oy0 + r;
-        if (ox < job.dw && oy < job.dh) {
-            const int sv = s_h[2 * r][c] + 4 * s_h[2 * r + 1][c] + 6 * s_h[2 * r + 2][c] + 4 * s_h[2 * r + 3][c] + s_h[2 * r + 4][c];
-            job.dst[(size_t)oy * job.dw + ox] = (uint8_t)((sv + 128) >> 8);
-        }
-    }
-    // ---- detector on cam0: four 32 x 32 sub-tiles of the staged region
-    if ((blockIdx.z & 1) == 0) {
-        const FeStreamDev &S = streams[blockIdx.z >> 1];
-#pragma unroll 1
-        for (int sub = 0; sub < PDF_W / DTW; ++sub) {
-            const int tx0 = x0 + DTW * sub;
-            if (tx0 >= job.sw) break;
-            detect_tile(S, &s_src[0][DTW * sub], PDF_SW, tx0, y0, gen, s_det);
-        }
-    }
+    detect_tile(S, (const uint8_t *)s_tile, DSW, tx0, ty0, gen, s_det);
 }
 
-extern "C" void fe_launch_pyr_detect(const PyrJob *jobs_dev, const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st) {
-    dim3 grid((max_w + PDF_W - 1) / PDF_W, (max_h + PDF_H - 1) / PDF_H, 2 * n_streams);
-    hipLaunchKernelGGL(k_pyr_detect, grid, dim3(256), 0, st, jobs_dev, streams_dev, gen);
+extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st) {
+    const int tiles_x = (max_w + DTW - 1) / DTW, tiles_y = (max_h + DTH - 1) / DTH;
+    hipLaunchKernelGGL(k_detect_cells, dim3(tiles_x * tiles_y, n_streams), dim3(256), 0, st, streams_dev, tiles_x, gen);
 }
 
 // ------------------------------------------------------------------------------------------ point math
