@@ -48,6 +48,7 @@ MsckfVio::MsckfVio(const mskf_calib &calib, const mskf_ekf_cfg &cfg) : calib_(ca
 
 MsckfVio::~MsckfVio() {
     if (pose_outfile_.is_open()) pose_outfile_.close();
+    if (debug_.is_open()) debug_.close();
 }
 
 void MsckfVio::fail(const char *what, int rc) {
@@ -98,7 +99,7 @@ bool MsckfVio::initialize() {
     if (!stream_) { error_ = "MsckfVio: no device stream attached"; return false; }
     resetCloneSlots();
     resetCov();
-    if (have_yaml_) pose_outfile_.open("pose_out.txt");
+    if (have_yaml_) enableFileOutputs();
     return error_.empty();
 }
 
@@ -457,7 +458,72 @@ void MsckfVio::applyCorrection(const std::vector<double> &dx) {
     ++n_update_;
 }
 
+// featureJacobian's debug output (msckf_vio.cpp:719-723): in the frame with n_pub == 9 the reference writes the
+// un-projected stacked Jacobians H_xj (4 M x d), H_fj (4 M x 3) and the residual r_j of every feature it linearises.
+// The device keeps those only in LDS, so this (cold, file-output-only) path restates measurementJacobian (:610-677) on
+// the host from the clone states and observations the update was built from and the position the device returned.
+// Matrices are written row by row, blank separated.
+void MsckfVio::dumpFeatureJacobians() {
+    if (!debug_.is_open() || n_pub_ != 9) return;
+    const int d = 21 + 6 * (int)clones_.size();
+    for (size_t j = 0; j < feats_.size(); ++j) {
+        if (!(feat_status_[j] & 1)) continue;      // featureJacobian is only reached with a valid position (:962-970, :1113-1116)
+        const mskf_ekf_feature &f = feats_[j];
+        const int M = f.n_obs;
+        std::vector<double> Hx((size_t)4 * M * d, 0.0), Hf((size_t)4 * M * 3, 0.0), r((size_t)4 * M, 0.0);
+        const Vector3 p_w(f.position[0], f.position[1], f.position[2]);
+        for (int o = 0; o < M; ++o) {
+            const int ci = obs_clone_[f.obs_start + o];
+            const mskf_clone_state &cam = clones_[ci];
+            const double *z = &obs_z_[(size_t)4 * (f.obs_start + o)];
+            const hm::Mat3 R_w_c0 = kin::rotation_of(cam.q);
+            const Vector3 t_c0_w(cam.p[0], cam.p[1], cam.p[2]);
+            const hm::Mat3 R_c0_c1 = T_cam0_cam1_.R;
+            const hm::Mat3 R_w_c1 = R_c0_c1 * R_w_c0;
+            const Vector3 t_c1_w = t_c0_w - R_w_c1.transpose() * T_cam0_cam1_.t;
+            const Vector3 p_c0 = R_w_c0 * (p_w - t_c0_w), p_c1 = R_w_c1 * (p_w - t_c1_w);
+            double dz0[4][3] = {{0}}, dz1[4][3] = {{0}};
+            dz0[0][0] = 1 / p_c0[2]; dz0[1][1] = 1 / p_c0[2]; dz0[0][2] = -p_c0[0] / (p_c0[2] * p_c0[2]); dz0[1][2] = -p_c0[1] / (p_c0[2] * p_c0[2]);
+            dz1[2][0] = 1 / p_c1[2]; dz1[3][1] = 1 / p_c1[2]; dz1[2][2] = -p_c1[0] / (p_c1[2] * p_c1[2]); dz1[3][2] = -p_c1[1] / (p_c1[2] * p_c1[2]);
+            const hm::Mat3 sk = hm::skew(p_c0), Rsk = R_c0_c1 * sk;
+            double A[4][6];
+            for (int i = 0; i < 4; ++i)
+                for (int c = 0; c < 3; ++c) {
+                    double a = 0, b = 0;
+                    for (int k = 0; k < 3; ++k) { a += dz0[i][k] * sk(k, c) + dz1[i][k] * Rsk(k, c); b += -dz0[i][k] * R_w_c0(k, c) - dz1[i][k] * R_w_c1(k, c); }
+                    A[i][c] = a; A[i][3 + c] = b;
+                }
+            const Vector3 g = gravity_;
+            const Vector3 u0 = kin::rotation_of(cam.q_null) * g;
+            const Vector3 u1 = hm::skew(p_w - Vector3(cam.p_null[0], cam.p_null[1], cam.p_null[2])) * g;
+            const double u[6] = {u0[0], u0[1], u0[2], u1[0], u1[1], u1[2]};
+            double uu = 0;
+            for (int k = 0; k < 6; ++k) uu += u[k] * u[k];
+            for (int i = 0; i < 4; ++i) {
+                double Au = 0;
+                for (int k = 0; k < 6; ++k) Au += A[i][k] * u[k];
+                for (int c = 0; c < 6; ++c) {
+                    const double h = A[i][c] - Au * (1.0 / uu) * u[c];
+                    Hx[(size_t)(4 * o + i) * d + 21 + 6 * ci + c] = h;
+                    if (c >= 3) Hf[(size_t)(4 * o + i) * 3 + (c - 3)] = -h;
+                }
+            }
+            r[4 * o + 0] = z[0] - p_c0[0] / p_c0[2]; r[4 * o + 1] = z[1] - p_c0[1] / p_c0[2];
+            r[4 * o + 2] = z[2] - p_c1[0] / p_c1[2]; r[4 * o + 3] = z[3] - p_c1[1] / p_c1[2];
+        }
+        auto mat = [&](const char *name, const std::vector<double> &m, int cols) {
+            debug_ << name << "\n";
+            for (size_t i = 0; i < m.size(); ++i) debug_ << m[i] << (((int)(i % cols) == cols - 1) ? "\n" : " ");
+            debug_ << std::endl;
+        };
+        mat("featureJacobian H_xj:", Hx, d);
+        mat("featureJacobian H_fj:", Hf, 3);
+        mat("featureJacobian r_j:", r, 1);
+    }
+}
+
 void MsckfVio::phaseB(mskf_ekf_update_args &upd) {
+    dumpFeatureJacobians();                      // (no-op unless file outputs are on and this is frame 9)
     // tail of removeLostFeatures (:1016-1021)
     if (!feats_.empty() && rows_out_ > 0) { hostprof::Scope hp(hostprof::EKF_APPLY1); applyCorrection(delta_x_); }
     {
@@ -557,6 +623,7 @@ void MsckfVio::phaseC(bool defer_device) {
     pending_rm_[0] = pending_rm_[1] = -1;
     if (!frame_active_) return;
     if (prune_pending_) {
+        dumpFeatureJacobians();
         hostprof::Scope hp(hostprof::EKF_TAIL_PRUNE);
         // tail of pruneCamStateBuffer (:1100-1181)
         for (size_t j = 0; j < feats_.size(); ++j)
@@ -584,6 +651,7 @@ void MsckfVio::phaseC(bool defer_device) {
     }
     hostprof::Scope hp_pub(hostprof::EKF_PUBLISH);
     publish(frame_time_);
+    ++n_pub_;                                    // :356
 }
 
 // :1186-1236

@@ -84,7 +84,10 @@ class MsckfVio {
     // phase D: online reset decision from the position variances (msckf_vio.cpp:1186-1236)
     void phaseD(const double pos_var[3]);
     bool frameActive() const { return frame_active_; }
-    void enableFileOutputs() { if (!pose_outfile_.is_open()) pose_outfile_.open("pose_out.txt"); }   // msckf_vio.cpp:169
+    void enableFileOutputs() {   // msckf_vio.cpp:169-171
+        if (!pose_outfile_.is_open()) pose_outfile_.open("pose_out.txt");
+        if (!debug_.is_open()) debug_.open("debug_msckfvio.txt");
+    }
     // optional: records [start, size) of `msg` are untouched value-initialised records (Q1 tail)
     // total_size > msg->features.size(): `msg` is a snapshot truncated inside the zero tail of a longer message
     void setZeroTailHint(const CameraMeasurement *msg, size_t start, size_t total_size = 0) {
@@ -124,6 +127,7 @@ class MsckfVio {
     void resetCloneSlots();
     void finishArgs(mskf_ekf_update_args &upd, int dof_offset, int apply_cap);
     void fail(const char *what, int rc);
+    void dumpFeatureJacobians();   // debug_msckfvio.txt, frame n_pub == 9 (msckf_vio.cpp:719-723)
 
     YAML::Node cfg_cam_imu_;
     bool have_yaml_ = false;
@@ -173,7 +177,8 @@ class MsckfVio {
     int rm_order_[2] = {-1, -1};                           // window positions of the two clones being pruned
     const CameraMeasurement *zero_tail_msg_ = nullptr;
     size_t zero_tail_start_ = 0, zero_tail_total_ = 0;
-    std::ofstream pose_outfile_;
+    std::ofstream pose_outfile_, debug_;
+    int n_pub_ = 0;                                        // published frames (msckf_vio.cpp:356)
 };
 
 typedef MsckfVio::Ptr MsckfVioPtr;
