@@ -42,7 +42,7 @@ CONFIGS = {
                name="configs[2] Single MI355X stress: 1280x720 stereo, 50 cam clones, 1000 features/frame"),
     "c4": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=8, groups=1, loop=100, cpu_frames=150, cpu_all_frames=80,
                name="configs[3] 8xMI355X: 64 EuRoC-shaped streams sharded 8/GPU"),
-    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=8, groups=8, loop=30, cpu_frames=16, cpu_all_frames=6,
+    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=8, groups=8, loop=30, cpu_frames=40, cpu_all_frames=6,
                name="configs[4] 4K stereo streams, 2000 features/frame, 60 cam clones"),
 }
 
@@ -457,7 +457,10 @@ def main(argv=None):
                                    % (CONFIGS[args.config]["name"], args.config, args.width, args.height, args.clones, args.grid, n_feat, n_streams,
                                       n_groups, args.host_threads, ", FE|EKF pipelined" if pipe else "", seq_note),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
-                       "ekf_updates_stream0": n_upd, "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1),
+                       "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": run.num_tsqr_updates(0),
+                       "ekf_uncompressed_updates_stream0": run.num_uncompressed_updates(0),
+                       "ekf_rows_per_update_stream0": round(run.stacked_rows(0) / max(n_upd, 1), 1),
+                       "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1),
                        "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},

@@ -157,8 +157,9 @@ typedef struct mskf_ekf_update_args {
     uint8_t *feat_status;           /* out per feature: bit0 triangulation valid, bit1 gating passed (stacked) */
     double *gamma;                  /* out per feature (may be NULL): Mahalanobis gate value */
     int32_t *rows_out;              /* out: number of stacked rows (0 => no update applied) */
-    int32_t *diag_out;              /* out, optional (may be NULL), 2 ints: [0] 1 if the compression ran as Householder TSQR, 0 for
-                                       Gram + Cholesky; [1] pivots of the Gram factor below 100 lambda (-1: not computed) */
+    int32_t *diag_out;              /* out, optional (may be NULL), 2 ints: [0] how the stack was compressed: 0 Gram + Cholesky,
+                                       1 Householder TSQR, 2 not at all (rows <= active columns, msckf_vio.cpp:818-821);
+                                       [1] pivots of the Gram factor below 100 lambda (-1: not computed) */
 } mskf_ekf_update_args;
 
 /* What processModel (msckf_vio.cpp:409-469) needs to propagate the covariance over one IMU sample.

@@ -474,7 +474,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         L.o_gamma = align_up(L.o_dx + sizeof(double) * (size_t)E.ld, 16);
         L.o_pos = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
         L.o_rows = align_up(L.o_pos + sizeof(double) * 3 * (size_t)a.n_feat, 16);
-        L.o_status = L.o_rows + 16;
+        L.o_status = L.o_rows + 32;
         out_bytes = align_up(L.o_status + (size_t)a.n_feat, 64);
         if (m_total > E.max_rows) {
             MSKF_HIPCHK(hipStreamSynchronize(st));
@@ -612,7 +612,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         std::memcpy(a.delta_x, hout + L.o_dx, sizeof(double) * (size_t)d);
         if (a.gamma) std::memcpy(a.gamma, hout + L.o_gamma, sizeof(double) * (size_t)a.n_feat);
         *a.rows_out = ((const int *)(hout + L.o_rows))[0];
-        if (a.diag_out) { const int dg = ((const int *)(hout + L.o_rows))[3]; a.diag_out[0] = dg & 1; a.diag_out[1] = dg >> 8; }
+        if (a.diag_out) { const int dg = ((const int *)(hout + L.o_rows))[3]; a.diag_out[0] = (dg & 4) ? 2 : (dg & 1); a.diag_out[1] = dg >> 8; }
         std::memcpy(a.feat_status, hout + L.o_status, (size_t)a.n_feat);
         const double *po = (const double *)(hout + L.o_pos);
         for (int j = 0; j < a.n_feat; ++j)

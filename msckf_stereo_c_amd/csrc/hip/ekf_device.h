@@ -54,7 +54,9 @@ struct EkfStreamDev {
     int n_tri;
     int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns,
                               // [3] compression diagnostics: bit 0 = Householder TSQR used, bit 1 = the lambda prior of the Gram path
-                              //     would bias P by more than QR_BIAS_LIMIT, bits 8.. = pivots of the Gram factor below 100 lambda
+                              //     would bias P by more than QR_BIAS_LIMIT, bit 2 = no compression (rows <= active columns: the
+                              //     stacked rows themselves are the measurement), bits 8.. = pivots of the Gram factor below 100 lambda
+                              // [4] nk = rows of the compressed measurement = dimension of S: na, or rows_out[1] without compression
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)
     const mskf_imu_step *imu_steps;   // or: n_steps compact IMU records, Phi/Q formed on the device

@@ -1062,6 +1062,8 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
         S.rows_out[0] = st;
         S.rows_out[1] = me;       // rows beyond the last stacked block carry nothing: the Gram pass stops there
         S.rows_out[2] = na;
+        S.rows_out[3] = 0;
+        S.rows_out[4] = na;       // rows of the compressed measurement (k_ekf_qr lowers it when nothing is compressed)
     }
 }
 

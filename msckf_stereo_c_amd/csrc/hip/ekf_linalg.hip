@@ -34,7 +34,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define QR_BIAS_LIMIT 1e-6
 // auto mode, stack with no more rows than active columns (the reference compresses nothing there, msckf_vio.cpp:818-821):
 // the Gram pass and its factorisation are skipped, k_ekf_qr triangularises the few rows directly
-__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]); }
+__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[1] <= S.rows_out[2]); }
+// the stream's stacked rows are used uncompressed (decided by k_ekf_qr): R = H_act (rows_out[1] x na, dense, rowmask-gathered)
+__device__ __forceinline__ bool ekf_direct(const EkfStreamDev &S) { return (S.rows_out[3] & 4) != 0; }
 
 enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
 
@@ -65,9 +67,11 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     int M, N, K;
     double alpha = 1.0, beta = 0.0, diag_add = 0.0;
     if (MODE == GM_GRAM)      { A = S.Hs; B = S.Hs; C = S.S; M = N = na + 1; K = S.rows_out[1]; }       // G_c = [H_act|r]^T [H_act|r]
-    else if (MODE == GM_T)    { A = S.S;  B = S.P;  C = S.T; M = na; N = d; K = na; }                   // T = R_c P[act, :]
-    else if (MODE == GM_S2)   { A = S.T;  B = S.S;  C = S.W; M = N = na; K = na; diag_add = S.sigma2; } // S = T[:, act] R_c^T + sigma^2 I
-    else                      { A = S.T;  B = S.T;  C = S.P; M = N = d; K = na; alpha = -1.0; beta = 1.0; }   // P -= Y^T Y
+    const int nk = MODE == GM_GRAM ? 0 : S.rows_out[4];                                               // rows of the compressed measurement
+    const bool direct = MODE != GM_GRAM && MODE != GM_PUPD && ekf_direct(S);                          // R = H_act itself (no compression)
+    if (MODE == GM_T)         { A = direct ? S.Hs : S.S;  B = S.P;  C = S.T; M = nk; N = d; K = na; }   // T = R P[act, :]
+    else if (MODE == GM_S2)   { A = S.T;  B = direct ? S.Hs : S.S;  C = S.W; M = N = nk; K = na; diag_add = S.sigma2; } // S = T[:, act] R^T + sigma^2 I
+    else if (MODE == GM_PUPD) { A = S.T;  B = S.T;  C = S.P; M = N = d; K = nk; alpha = -1.0; beta = 1.0; }   // P -= Y^T Y
     const int tiles_n = (N + GT - 1) / GT, tiles_m = (M + GT - 1) / GT;
     const int tile = blockIdx.x;
     if (MODE == GM_PUPD && tile >= tiles_m * tiles_n) {
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         const int c = c0 + cl;
         double s2 = 0;
         if (c < d)
-            for (int k = ks; k < na; k += 8) s2 += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
+            for (int k = ks; k < nk; k += 8) s2 += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
         s_part[ks][cl] = s2;
         __syncthreads();
         if (ks == 0 && c < d) {
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
     const int lo = tid & 31, hi = tid >> 5;          // hi in [0,8)
     int k_begin = 0;
-    if (TR::KMIN_I) k_begin = (i0 / GK) * GK;
-    if (TR::KMIN_J) k_begin = (j0 / GK) * GK;
+    if (TR::KMIN_I && !direct) k_begin = (i0 / GK) * GK;
+    if (TR::KMIN_J && !direct) k_begin = (j0 / GK) * GK;
     const int k_end = K;
     // gathered source columns of this thread's fixed (i = lo / j = lo) operand lanes
     int colA = i0 + lo, colB = j0 + lo;
@@ -138,15 +142,23 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
             const int ii = TR::TA ? lo : hi + 8 * e, kk = TR::TA ? hi + 8 * e : lo;
             const int gi = i0 + ii, gk = k0 + kk;
             double v = 0.0;
-            if (gi < M && gk < K && !(TR::KMIN_I && gk < gi)) {
+            if (gi < M && gk < K && !(TR::KMIN_I && !direct && gk < gi)) {
                 if (MODE == GM_S2) v = A[(size_t)gi * ld + act[gk]];              // T[:, act]
+                else if (MODE == GM_T && direct) {                                // H_act row gi, rowmask-gathered
+                    const int col = act[gk];
+                    if ((rowmask[gi] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) v = A[(size_t)gi * ld + col];
+                }
                 else v = A[(size_t)gk * ld + (MODE == GM_GRAM ? colA : gi)];
             }
             ra[e] = v;
             const int gj = j0 + lo, gkb = k0 + hi + 8 * e;
             double w = 0.0;
-            if (gj < N && gkb < K && !(TR::KMIN_J && gkb < gj)) {
+            if (gj < N && gkb < K && !(TR::KMIN_J && !direct && gkb < gj)) {
                 if (MODE == GM_T) w = B[(size_t)act[gkb] * ld + gj];             // P[act, :]
+                else if (MODE == GM_S2 && direct) {                               // (H_act)^T: row gj of H, column act[gkb]
+                    const int col = act[gkb];
+                    if ((rowmask[gj] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) w = B[(size_t)gj * ld + col];
+                }
                 else w = B[(size_t)gkb * ld + (MODE == GM_GRAM ? colB : gj)];
             }
             rb[e] = w;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
     if (which == 0 && ekf_skip_gram(S)) { if (threadIdx.x == 0) S.rows_out[3] = 0; return; }
-    const int n = S.rows_out[2];                          // active columns
+    const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
     const int nt = n + (which == 0 ? 1 : 0);              // + the extra Q^T r row of the Gram factorisation
     const int lda = S.ld;
     double *A = which == 0 ? S.S : S.W;                   // G_c = [H_act|r]^T [H_act|r]  /  S = T[:, act] R^T + sigma^2 I
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     if (which == 0 && ekf_skip_gram(S)) { if (threadIdx.x == 0) S.rows_out[3] = 0; return; }
     double *A = which == 0 ? S.S : S.W;
     const int off = 0, lda = S.ld;                 // compact storage: index i <-> column act[i]
-    const int n = S.rows_out[2];                   // active columns
+    const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
     const int nt = n + (which == 0 ? 1 : 0);       // rows incl. the extra row
     const bool semidef = which == 0;
     extern __shared__ double s_dyn[];
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
 __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
-    const int n = S.rows_out[2], ld = S.ld, ncols = S.d + 1;      // na rows (compact), all d+1 columns
+    const int n = S.rows_out[4], ld = S.ld, ncols = S.d + 1;      // rows of the compressed measurement, all d+1 columns
     const int c0 = blockIdx.x * TS_COLS;
     if (c0 >= ncols) return;
     const double *L = S.W;
@@ -511,10 +523,19 @@ __device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, con
 __global__ __launch_bounds__(256) void k_ekf_qr(const EkfStreamDev *streams, int r_in_lds) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
-    const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], m = S.rows_out[0], d = S.d, ld = S.ld;
+    const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], d = S.d, ld = S.ld;
     const int diag = S.rows_out[3];
-    const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && na > 0 && (m <= na || (diag & 2)));
-    if (!need || na <= 0) return;
+    if (na <= 0) return;
+    if (S.qr_mode == 0 && K <= na) {
+        // The reference's m <= d case (msckf_vio.cpp:818-821): no more stacked rows than active columns, nothing to
+        // compress.  The rows themselves are the measurement: R = H_act (K x na, read through the rowmask by the T and
+        // S GEMMs), Q^T r = r, S is K x K.  (Rows of blocks that were not stacked are zero rows: sigma^2 on S's diagonal.)
+        for (int i = threadIdx.x; i < K; i += 256) S.T[(size_t)i * ld + d] = S.rowmask[i] ? S.Hs[(size_t)i * ld + d] : 0.0;
+        if (threadIdx.x == 0) { S.rows_out[3] = diag | 4; S.rows_out[4] = K; }
+        return;
+    }
+    const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && (diag & 2));
+    if (!need) return;
     extern __shared__ double s_dyn[];
     __shared__ int s_col[QR_MAX_N1], s_clone[QR_MAX_N1];
     const int tid = threadIdx.x;

@@ -147,6 +147,9 @@ void mskfh_get_imu_state(void *h, int stream, double *out) {   // same 28-double
     for (int i = 0; i < 3; ++i) out[k++] = s.t_cam0_imu[i];
 }
 int mskfh_num_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numUpdates(); }
+int mskfh_num_tsqr_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numTsqrUpdates(); }
+int mskfh_num_uncompressed_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numUncompressedUpdates(); }
+long long mskfh_stacked_rows(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->stackedRows(); }
 long long mskfh_num_resets(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numResets(); }
 int mskfh_num_clones(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numClones(); }
 void *mskfh_group_hip_stream(void *h, int stream) { int l; return mskf_ctx_hip_stream(((MultiRunner *)h)->group_of(stream, l).ctx()); }

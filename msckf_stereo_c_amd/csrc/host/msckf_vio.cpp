@@ -392,6 +392,8 @@ void MsckfVio::finishArgs(mskf_ekf_update_args &upd, int dof_offset, int apply_c
     upd.feat_status = feat_status_.data();
     upd.gamma = gamma_.data();
     upd.rows_out = &rows_out_;
+    upd.diag_out = diag_out_;
+    diag_out_[0] = diag_out_[1] = 0;
 }
 
 // removeLostFeatures, selection part (:937-984).  Features are visited in ascending id (the reference's map order);
@@ -447,6 +449,9 @@ void MsckfVio::applyCorrection(const std::vector<double> &dx) {
     kin::small_angle(Vector3(dx[15], dx[16], dx[17]), dq);
     s.R_imu_cam0 = kin::rotation_of(dq) * s.R_imu_cam0;
     for (int i = 0; i < 3; ++i) s.t_cam0_imu[i] += dx[18 + i];
+    n_tsqr_ += diag_out_[0] == 1 ? 1 : 0;
+    n_direct_ += diag_out_[0] == 2 ? 1 : 0;
+    rows_sum_ += rows_out_;
     int ci = 0;
     for (auto &kv : state_server.cam_states) {
         const double *d = &dx[21 + 6 * ci];

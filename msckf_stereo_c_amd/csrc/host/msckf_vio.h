@@ -98,6 +98,10 @@ class MsckfVio {
     const IMUState &imuState() const { return state_server.imu_state; }
     int numClones() const { return (int)state_server.cam_states.size(); }
     int numUpdates() const { return n_update_; }
+    // diagnostics of the QR compression (include/mskf_hip.h diag_out): updates that ran as Householder TSQR, sum of stacked rows
+    int numTsqrUpdates() const { return n_tsqr_; }
+    int numUncompressedUpdates() const { return n_direct_; }
+    long long stackedRows() const { return rows_sum_; }
     long long numResets() const { return online_reset_counter_; }
     size_t mapSize() const { return map_server.size(); }
     bool keepTrajectory = true;   // path_/points3d_ grow forever in the reference (Q20); benches may switch it off
@@ -169,6 +173,9 @@ class MsckfVio {
     std::vector<double> delta_x_, gamma_;
     std::vector<uint8_t> feat_status_;
     int32_t rows_out_ = 0;
+    int32_t diag_out_[2] = {0, 0};
+    int n_tsqr_ = 0, n_direct_ = 0;
+    long long rows_sum_ = 0;
     std::vector<StateIDType> rm_cam_state_ids_;
     bool prune_pending_ = false;
     bool defer_device_ = false, have_J_ = false;

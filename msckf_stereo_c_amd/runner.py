@@ -41,6 +41,12 @@ def lib():
                      "mskfh_num_clones"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
             getattr(L, name).restype = C.c_int
+        L.mskfh_num_tsqr_updates.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_num_tsqr_updates.restype = C.c_int
+        L.mskfh_num_uncompressed_updates.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_num_uncompressed_updates.restype = C.c_int
+        L.mskfh_stacked_rows.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_stacked_rows.restype = C.c_longlong
         L.mskfh_num_resets.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_num_resets.restype = C.c_longlong
         L.mskfh_get_dump.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(TrackingInfo)]
@@ -195,6 +201,17 @@ class Runner:
 
     def num_updates(self, stream=0):
         return self.L.mskfh_num_updates(self.h, stream)
+
+    def num_tsqr_updates(self, stream=0):
+        """Updates of the stream whose QR compression ran as Householder TSQR (the rest: Gram + Cholesky)."""
+        return self.L.mskfh_num_tsqr_updates(self.h, stream)
+
+    def num_uncompressed_updates(self, stream=0):
+        """Updates whose stack had no more rows than active columns and was used as it is (msckf_vio.cpp:818-821)."""
+        return self.L.mskfh_num_uncompressed_updates(self.h, stream)
+
+    def stacked_rows(self, stream=0):
+        return self.L.mskfh_stacked_rows(self.h, stream)
 
     def num_resets(self, stream=0):
         return self.L.mskfh_num_resets(self.h, stream)

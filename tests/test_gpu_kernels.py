@@ -337,10 +337,15 @@ def test_ekf_update_householder_tsqr(gpu_ctx, oracle, n_clones, n_feat, seed, kw
 def test_ekf_update_rows_not_more_than_columns_skips_gram(gpu_ctx, oracle):
     """The reference's m <= d case (msckf_vio.cpp:818-821: no compression when the stack has no more rows than
     columns): in auto mode the Gram pass and its factorisation are skipped (H^T H would be singular by construction) and
-    the few rows are triangularised directly; with more rows than columns the default Gram path runs."""
+    the stacked rows are the measurement as they are (S is rows x rows); with more rows than columns the default Gram
+    path runs."""
     few = _update_vs_oracle(gpu_ctx, oracle, 13, 2, 1301, 0, min_obs=3)
-    assert few["got"]["rows"] <= few["na"] and few["got"]["used_qr"] == 1
+    assert few["got"]["rows"] <= few["na"] and few["got"]["used_qr"] == 2        # 2 = used uncompressed
     assert few["errP"] < 1e-12 and few["errdx"] < 1e-9
+    for n_clones, n_feat, seed in ((24, 2, 2402), (8, 2, 801), (30, 3, 3003)):
+        r = _update_vs_oracle(gpu_ctx, oracle, n_clones, n_feat, seed, 0, min_obs=3)
+        if r["got"]["rows"] <= r["na"]:
+            assert r["got"]["used_qr"] == 2 and r["errP"] < 1e-12, (n_clones, n_feat, r["errP"])
     many = _update_vs_oracle(gpu_ctx, oracle, 13, 8, 1301, 0, min_obs=3)
     assert many["got"]["rows"] > many["na"] and many["got"]["used_qr"] == 0
     assert many["errP"] < 2e-9
