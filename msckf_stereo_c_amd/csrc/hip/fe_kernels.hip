@@ -2,18 +2,17 @@
 //
 //  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242)
 //  k_detect_cells : cg::CornerDetector      (:132,259,657) — per-cell integer Shi-Tomasi maximum (32x32 px tiles)
-//  k_lk_points    : cg::optical_flow_multi_level (:410 temporal, :569 stereo) fused with the
-//                   prediction (:321-350), the image-bounds gates (:416-424, :575-583), the stereo
-//                   initial guess (:542-548), undistortion and the epipolar gate (:587-617).
+//  k_lk_points4   : cg::optical_flow_multi_level (:410 temporal, :569 stereo) with the prediction (:321-350);
+//  k_pt_geom      : the image-bounds gates (:416-424, :575-583), the stereo initial guess (:542-548),
+//                   undistortion and the epipolar gate (:587-617), one thread per point.
 //
 // Arithmetic contract: every decision-bearing quantity is integer or a fixed
 // sequence of IEEE-754 double operations; this file must be compiled with -ffp-contract=off.
-// Work shapes: one 64-lane wavefront per tracked point (a 15x15 window = 225 pixels, <= 4 per
-// lane), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
+// Work shapes: one 16-lane DPP row per tracked point (four points per wavefront, a lane owns one row of the 15x15
+// window), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
 #include "fe_device.h"
-#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ pyr_down
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -396,45 +395,10 @@ __device__ __forceinline__ void distort_pt(const CamDev &cam, float xf, float yf
 #define LK_WIN 15
 #define LK_ITERS 30
 
-__device__ __forceinline__ int px_clamped(const uint8_t *img, int w, int h, int x, int y) {
-    x = min(max(x, 0), w - 1);
-    y = min(max(y, 0), h - 1);
-    return img[(size_t)y * w + x];
-}
-
-// The fractional offsets are wave-uniform; readfirstlane moves the fixed-point weight arithmetic to the scalar unit.
-__device__ __forceinline__ void bilinear_weights(float fa, float fb, int &w00, int &w01, int &w10, int &w11) {
-    int qa = __float2int_rn(fa * 16384.0f), qb = __float2int_rn(fb * 16384.0f);
-    asm volatile("" : "+v"(qa), "+v"(qb));     // keep the conversion ahead of the broadcast (no scalar float->int)
-    qa = __builtin_amdgcn_readfirstlane(qa);
-    qb = __builtin_amdgcn_readfirstlane(qb);
-    w00 = ((16384 - qa) * (16384 - qb) + 8192) >> 14;
-    w01 = (qa * (16384 - qb) + 8192) >> 14;
-    w10 = ((16384 - qa) * qb + 8192) >> 14;
-    w11 = 16384 - w00 - w01 - w10;
-}
-
-__device__ __forceinline__ int sample5(const uint8_t *img, int w, int h, int x, int y, int w00, int w01, int w10, int w11) {
-    const int s = px_clamped(img, w, h, x, y) * w00 + px_clamped(img, w, h, x + 1, y) * w01 +
-                  px_clamped(img, w, h, x, y + 1) * w10 + px_clamped(img, w, h, x + 1, y + 1) * w11;
-    return (s + 256) >> 9;
-}
-
-// ---- wave-level integer reduction without LDS traffic: four DPP butterflies give every lane the sum of
-// its 16-lane row (int32 is enough for a row, see the bounds below), the four row sums are added as
-// 64-bit scalars.  All 64 lanes must be active.
+// ---- DPP butterfly step of the row reductions (l4_row_sum).  All lanes of the row must be active.
 template <int CTRL> __device__ __forceinline__ int dpp_add(int v) {
     return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
-__device__ __forceinline__ long long wave_sum_rows(int v) {
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror
-    return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
-           (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
-}
-
 // (double)b * 2^-20, exactly, for |b| < 2^51, in ONE double-precision instruction: b is added (scalar unit) to the bit
 // pattern of 1.5 * 2^32, whose mantissa LSB weighs 2^-20; subtracting 1.5 * 2^32 leaves b * 2^-20.  The plain form
 // (int64 -> double conversion, then the scaling) is five double-rate instructions per value, and FP64 issues at half
@@ -443,220 +407,11 @@ __device__ __forceinline__ double lk_scaled_f64(long long b) {
     return __longlong_as_double(b + 0x41F8000000000000LL) - 6442450944.0;
 }
 
-// Search/template windows are staged in LDS as a byte region of LK_RH rows x LK_RS columns whose left edge
-// is a multiple of 4 pixels; pixels outside the image are replicated from the border (px_clamped), so the
-// iteration loop needs neither clamps nor 64-bit addressing.
-#define LK_RS 32              // staged columns (multiple of 8): the 17 columns a window reads + 15 of slack
-#define LK_RH 24              // staged rows: the 16 rows a window reads + 8 of slack
-#define LK_MARGIN 4           // slack on the left / top of a freshly staged search region
-__device__ __forceinline__ void lk_stage(const uint8_t *img, int w, int h, int x0, int y0, int rows, uint32_t *s_R) {
-    const int lane = threadIdx.x & 63;
-    // 8 bytes per load; rows of the odd-width pyramid levels are not aligned, so the loads are declared align-1
-    // (gfx950 global memory takes unaligned accesses)
-    typedef unsigned long long __attribute__((aligned(1))) u64u;
-    const bool fast = x0 >= 0 && y0 >= 0 && x0 + LK_RS <= w && y0 + rows <= h;
-    if (fast) {
-        const uint8_t *src = img + (size_t)y0 * w + x0;
-        unsigned long long *dst = (unsigned long long *)s_R;
-        for (int i = lane; i < (LK_RS / 8) * rows; i += 64) {
-            const int r = i / (LK_RS / 8), c = i - r * (LK_RS / 8);
-            dst[i] = *(const u64u *)(src + r * w + 8 * c);
-        }
-    } else {
-        uint8_t *dst = (uint8_t *)s_R;
-        for (int i = lane; i < LK_RS * rows; i += 64) {
-            const int r = i / LK_RS, c = i - r * LK_RS;
-            dst[i] = (uint8_t)px_clamped(img, w, h, x0 + c, y0 + r);
-        }
-    }
-}
-
-// Pyramidal LK for one point, executed by one full wavefront (all 64 lanes call this with identical
-// arguments; control flow is wave-uniform).  Lane (j = lane>>2, seg = lane&3) owns the four window pixels
-// (row j, columns 4*seg .. 4*seg+3) — 60 lanes x 4 covers the 15x15 window, column 15 and row 15 are masked.
-// s_P: 17*17 ints (interpolated template), s_R: LK_RS*LK_RH bytes (staged image region).
-// Integer bounds: samples are <= 255*32 = 8160, Scharr gradients <= 4080, so a lane's four products are
-// < 2^27.1 and a 16-lane row sum < 2^31; the cross-row sum is taken in 64 bits.
-__device__ void lk_point(const PyrDev &A, const PyrDev &B, float ax, float ay, float &bx, float &by, int &status, int *s_P, uint32_t *s_R) {
-    const int lane = threadIdx.x & 63;
-    const int lj = min(lane >> 2, LK_WIN - 1), seg = lane & 3;
-    const bool row_ok = (lane >> 2) < LK_WIN;
-    const int lane_off = lj * LK_RS + seg * 4;
-    const uint8_t *s_Rb = (const uint8_t *)s_R;
-    status = 1;
-    float ncx = 0.f, ncy = 0.f;
-    for (int l = MSKF_LEVELS - 1; l >= 0; --l) {
-        const uint8_t *imA = A.lvl[l];
-        const uint8_t *imB = B.lvl[l];
-        const int aw = A.w[l], ah = A.h[l], bw = B.w[l], bh = B.h[l];
-        const float sc = __int_as_float((127 - l) << 23);        // 2^-l exactly, without the division
-        const float pwx = ax * sc - (float)LK_HALF, pwy = ay * sc - (float)LK_HALF;
-        if (l == MSKF_LEVELS - 1) { ncx = bx * sc; ncy = by * sc; }
-        else { ncx = ncx * 2.0f; ncy = ncy * 2.0f; }
-        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(pwx)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(pwy));   // wave-uniform
-        if (ipx < -LK_WIN || ipx >= aw || ipy < -LK_WIN || ipy >= ah) {
-            if (l == 0) status = 0;
-            continue;
-        }
-        int w00, w01, w10, w11;
-        bilinear_weights(pwx - (float)ipx, pwy - (float)ipy, w00, w01, w10, w11);
-        // 18x18 source pixels -> LDS, then the 17x17 interpolated template -> LDS
-        __syncthreads();
-        {
-            const int ax0 = (ipx - 1) & ~3, ay0 = ipy - 1;
-            lk_stage(imA, aw, ah, ax0, ay0, 18, s_R);
-            __syncthreads();
-            const int oxa = ipx - 1 - ax0;
-            // lane (row = lane >> 2, seg) interpolates columns 5 seg .. 5 seg + 4 of its row (rows 0..15), lanes 0..3
-            // do row 16 in a second pass: five samples share six source bytes per row and no index is divided
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int r = pass == 0 ? (lane >> 2) : 16;
-                if (pass == 0 || lane < 4) {
-                    const int c0 = 5 * seg;
-                    const uint8_t *q = s_Rb + r * LK_RS + oxa + c0;       // columns <= oxa + 20 < LK_RS, rows <= 17: staged
-                    int t0[6], t1[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) { t0[k] = q[k]; t1[k] = q[LK_RS + k]; }
-                    int *dst = s_P + r * 17 + c0;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const int sv = t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11;
-                        if (c0 + k < 17) dst[k] = (sv + 256) >> 9;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        int Pv[4], Ix[4], Iy[4];
-        int A11 = 0, A12 = 0, A22 = 0;
-        {
-            // Scharr gradients of the lane's four pixels from a shared 3 x 6 neighbourhood: horizontal differences per
-            // row and vertical differences per column are formed once (integer arithmetic: any grouping is exact)
-            const int *pu = s_P + lj * 17 + seg * 4;        // row above, column left of the first pixel
-            int u[6], m[6], dn[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { u[c] = pu[c]; m[c] = pu[17 + c]; dn[c] = pu[34 + c]; }
-            int e[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) e[c] = dn[c] - u[c];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool on = row_ok && seg * 4 + k < LK_WIN;
-                const int sx = 3 * ((u[k + 2] - u[k]) + (dn[k + 2] - dn[k])) + 10 * (m[k + 2] - m[k]);
-                const int sy = 3 * (e[k] + e[k + 2]) + 10 * e[k + 1];
-                const int gx = on ? (sx + 16) >> 5 : 0, gy = on ? (sy + 16) >> 5 : 0;
-                Pv[k] = on ? m[k + 1] : 0; Ix[k] = gx; Iy[k] = gy;
-                A11 += __mul24(gx, gx); A12 += __mul24(gx, gy); A22 += __mul24(gy, gy);
-            }
-        }
-        const long long A11s = wave_sum_rows(A11), A12s = wave_sum_rows(A12), A22s = wave_sum_rows(A22);
-        const double a11 = lk_scaled_f64(A11s), a12 = lk_scaled_f64(A12s), a22 = lk_scaled_f64(A22s);   // (double)A * 2^-20
-        double D = a11 * a22 - a12 * a12;
-        const double dd = a11 - a22;
-        // minEig = numer / (2 * 15 * 15) < 1e-4  <=>  numer < 0x1.70a3d70a3d70bp-5: that constant is the smallest double
-        // whose quotient by 450.0 rounds to >= 1e-4 (division is monotonic), so the test is the same without dividing
-        const double numer = a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12);
-        if (numer < 0x1.70a3d70a3d70bp-5 || D < 1.1920928955078125e-07) {
-            if (l == 0) status = 0;
-            continue;
-        }
-        D = 1.0 / D;
-        float wx = ncx - (float)LK_HALF, wy = ncy - (float)LK_HALF;
-        float pdx = 0.f, pdy = 0.f;
-        int bx0 = 0, by0 = 0;
-        bool staged = false;
-        for (int it = 0; it < LK_ITERS; ++it) {
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(wx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(wy));
-            if (inx < -LK_WIN || inx >= bw || iny < -LK_WIN || iny >= bh) {
-                if (l == 0) status = 0;
-                break;
-            }
-            int ox = inx - bx0, oy = iny - by0;
-            // the lanes read columns ox .. ox+16 and rows oy .. oy+15 of the staged region
-            if (!staged || ox < 0 || ox > LK_RS - 17 || oy < 0 || oy > LK_RH - 16) {
-                bx0 = (inx - LK_MARGIN) & ~3; by0 = iny - LK_MARGIN;
-                __syncthreads();
-                lk_stage(imB, bw, bh, bx0, by0, LK_RH, s_R);
-                __syncthreads();
-                staged = true;
-                ox = inx - bx0; oy = iny - by0;
-            }
-            bilinear_weights(wx - (float)inx, wy - (float)iny, w00, w01, w10, w11);
-            const uint8_t *q = s_Rb + lane_off + (oy * LK_RS + ox);
-            int p0[5], p1[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { p0[k] = q[k]; p1[k] = q[LK_RS + k]; }
-            int b1 = 0, b2 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int sv = p0[k] * w00 + p0[k + 1] * w01 + p1[k] * w10 + p1[k + 1] * w11;
-                // masked pixels carry Ix = Iy = 0, so they add nothing
-                const int diff = ((sv + 256) >> 9) - Pv[k];
-                b1 += __mul24(diff, Ix[k]);       // |diff| <= 8160, |I| <= 4080: exact in the 24-bit multiplier
-                b2 += __mul24(diff, Iy[k]);
-            }
-            const long long b1s = wave_sum_rows(b1), b2s = wave_sum_rows(b2);
-            const double db1 = lk_scaled_f64(b1s), db2 = lk_scaled_f64(b2s);
-            const float dx = (float)((a12 * db2 - a22 * db1) * D);
-            const float dy = (float)((a12 * db1 - a11 * db2) * D);
-            wx += dx; wy += dy;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= 1e-4) break;
-            if (it > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
-                wx -= dx * 0.5f; wy -= dy * 0.5f;
-                break;
-            }
-            pdx = dx; pdy = dy;
-        }
-        ncx = wx + (float)LK_HALF; ncy = wy + (float)LK_HALF;
-    }
-    bx = ncx; by = ncy;
-}
-
-// One wavefront (= one 64-thread workgroup) per point; blockIdx.y = stream of the batch.  Two launches per track
-// call: stereo = 0 is the temporal track prev0 -> curr0 (with the gyro-predicted start, :342-347), stereo = 1 the
-// stereo track curr0 -> curr1 of the points that survived.  The per-point double-precision geometry between and after
-// them (bounds gates, undistort / distort, epipolar gate) is k_pt_geom, one THREAD per point: inside this kernel all
-// 64 lanes of the wave would repeat the same ~2500 FP64 instructions per point, which was half of its VALU issue.
-__global__ __launch_bounds__(64) void k_lk_points(const FeStreamDev *streams, int stereo) {
-    const FeStreamDev &S = streams[blockIdx.y];
-    const int pt = blockIdx.x;
-    if (pt >= S.n_pts) return;
-    __shared__ int s_P[17 * 17 + 3];     // + slack: the last lanes read one entry past the template (masked pixel)
-    __shared__ __attribute__((aligned(8))) uint32_t s_R[LK_RS * LK_RH / 4];
-    if (!stereo) {
-        if (!S.do_temporal) return;
-        const mskf_point2f pin = S.in_pts[pt];
-        // predictFeatureTracking (:342-347): p2 = H p1, normalise, round to float
-        const double *Hm = S.Hpred;
-        const double px = (double)pin.x, py = (double)pin.y;
-        const double X = Hm[0] * px + Hm[1] * py + Hm[2] * 1.0;
-        const double Y = Hm[3] * px + Hm[4] * py + Hm[5] * 1.0;
-        const double Z = Hm[6] * px + Hm[7] * py + Hm[8] * 1.0;
-        float bx = (float)(X / Z), by = (float)(Y / Z);
-        int st;
-        lk_point(S.prev0, S.curr0, pin.x, pin.y, bx, by, st, s_P, s_R);
-        if ((threadIdx.x & 63) == 0) {
-            S.out0[pt] = mskf_point2f{bx, by};
-            S.status[pt] = (uint8_t)(st ? 1 : 0);
-        }
-        return;
-    }
-    if (!(__builtin_amdgcn_readfirstlane((int)S.status[pt]) & 1)) return;      // wave-uniform
-    const mskf_point2f c0 = S.out0[pt], g = S.out1[pt];
-    float c1x = g.x, c1y = g.y;
-    int st;
-    lk_point(S.curr0, S.curr1, c0.x, c0.y, c1x, c1y, st, s_P, s_R);
-    if ((threadIdx.x & 63) == 0) {
-        S.out1[pt] = mskf_point2f{c1x, c1y};
-        S.status[pt] = (uint8_t)(1 | (st ? 2 : 0));
-    }
-}
-
 // ------------------------------------------------------------------------------------------ LK, four points per wavefront
-// k_lk_points4: the same arithmetic (bit for bit: every decision-bearing quantity is an integer or a fixed sequence of
-// double operations) with a 16-lane row of the wavefront per point: lane r of a row owns image row r of
-// the 16 x 16 search footprint, i.e. ALL 15 pixels of window row r.  What that buys over one wavefront per point:
+// k_lk_points4: pyramidal LK (OpenCV calcOpticalFlowPyrLK with OPTFLOW_USE_INITIAL_FLOW semantics, fixed point: every
+// decision-bearing quantity is an integer or a fixed sequence of double operations) with a 16-lane row of the
+// wavefront per point: lane r of a row owns image row r of the 16 x 16 search footprint, i.e. ALL 15 pixels of window
+// row r.  What that buys over one wavefront per point (round 1: 2840 VALU instructions per point, now 1950):
 //   * the per-point scalar work of an iteration (weights, 2 x 2 solve, convergence tests) is issued once for four points;
 //   * the cross-lane reduction stays inside a DPP row (no cross-row step, no readlane);
 //   * a lane walks 16 consecutive bytes, so the bilinear sample is two packed 16-bit dot products
@@ -877,7 +632,9 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
         const double a11 = lk_scaled_f64(A11s), a12 = lk_scaled_f64(A12s), a22 = lk_scaled_f64(A22s);   // (double)A * 2^-20
         double D = a11 * a22 - a12 * a12;
         const double dd = a11 - a22;
-        const double numer = a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12);      // minEig test without the division, see lk_point
+        // minEig = numer / (2 * 15 * 15) < 1e-4  <=>  numer < 0x1.70a3d70a3d70bp-5: that constant is the smallest double whose
+        // quotient by 450.0 rounds to >= 1e-4 (division is monotonic), so the test is the same without dividing
+        const double numer = a22 + a11 - sqrt(dd * dd + 4.0 * a12 * a12);
         bool run = lvl_on && !(numer < 0x1.70a3d70a3d70bp-5 || D < 1.1920928955078125e-07);
         if (lvl_on && !run && l == 0) status = 0;
         const bool solved = run;
@@ -1014,8 +771,6 @@ __global__ __launch_bounds__(64) void k_pt_geom(const FeStreamDev *streams, int 
 
 extern "C" void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st) {
     if (max_pts <= 0) return;
-    static const bool v1 = []() { const char *e = getenv("MSKF_LK_V1"); return e && e[0] == '1'; }();
-    if (v1) { hipLaunchKernelGGL(k_lk_points, dim3(max_pts, n_streams), dim3(64), 0, st, streams_dev, stereo); return; }
     const int gps = (max_pts + 3) / 4;
     hipLaunchKernelGGL(k_lk_points4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), 0, st, streams_dev, stereo, n_streams, gps);
 }
