@@ -342,7 +342,7 @@ def main(argv=None):
     if args.stagger < 0:
         args.stagger = (args.loop // n_groups + 1) if n_groups > 1 else 0
     if args.unique <= 0:
-        args.unique = min(per_group, 128)
+        args.unique = per_group
     shared_in_group = args.unique < per_group
     max_offset = args.stagger * (n_groups - 1) if args.unique < n_streams else 0
     total_frames = args.prime + args.warmup + args.steps
@@ -384,6 +384,7 @@ def main(argv=None):
     run.set_timing(not os.environ.get("MSKF_BENCH_NO_KERNEL_TIMING"))
     run.get_timing(reset=True)
     run.get_phases(reset=True)
+    run.get_abi_host_time(reset=True)
     barrier()
     cpu_quota, thr0 = cgroup_cpu()
     t0 = time.perf_counter()
@@ -395,6 +396,7 @@ def main(argv=None):
     _, thr1 = cgroup_cpu()
     timing = run.get_timing(reset=True)
     phases = run.get_phases(reset=True)
+    abi_host = run.get_abi_host_time(reset=True)
     run.set_timing(False)
 
     from msckf_stereo_c_amd.dist_util import aggregate_throughput
@@ -468,6 +470,7 @@ def main(argv=None):
             "roofline": roof, "mfma": mfma, "kernels": kernels,
             "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
             "host_phases_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in phases.items()},
+            "abi_host_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in abi_host.items()},
         }
         if not args.no_cpu and world == 1 and args.cpu_frames > 0:
             for s in syns:

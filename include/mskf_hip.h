@@ -58,6 +58,9 @@ enum {
     MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_COUNT
 };
 int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
+/* host seconds spent inside the batched entry points of this context, outside the device waits: [0] mskf_ekf_update_batch
+ * packing, [1] its unpacking, [2] mskf_fe_track_batch packing, [3] its unpacking */
+int mskf_ctx_get_host_time(mskf_ctx *ctx, double out[4], int reset);
 /* arrays of MSKF_K_COUNT entries: accumulated milliseconds, launches and units since the last reset */
 int mskf_ctx_get_timing(mskf_ctx *ctx, double *ms, long long *launches, long long *units, int reset);
 

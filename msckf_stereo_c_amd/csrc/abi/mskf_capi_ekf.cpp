@@ -1,6 +1,7 @@
 // mskf_capi_ekf.cpp — C-ABI: EKF entry points (include/mskf_hip.h).  The covariance lives in HBM;
 // the host passes small per-frame descriptors (Phi/Q sequence, J, clone states, observation lists).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include "../../../include/mskf_chi2_table.h"
 #include "mskf_internal.h"
@@ -420,6 +421,7 @@ extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
 extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args) {
     if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
+    const auto t_h0 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
@@ -595,9 +597,11 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
+        ctx->host_s[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
         if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
         mskf_t_collect(ctx);
     }
+    const auto t_h1 = std::chrono::steady_clock::now();
     for (int i = 0; i < n; ++i) {
         mskf_ekf_update_args &a = args[i];
         EkfStreamState &E = streams[i]->ekf_state;
@@ -618,6 +622,7 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         for (int j = 0; j < a.n_feat; ++j)
             for (int k = 0; k < 3; ++k) a.features[j].position[k] = po[3 * j + k];
     }
+    ctx->host_s[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
     return MSKF_OK;
 }
 

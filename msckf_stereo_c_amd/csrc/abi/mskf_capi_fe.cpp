@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include "mskf_internal.h"
 
@@ -123,6 +124,12 @@ extern "C" int mskf_ctx_get_timing(mskf_ctx *c, double *ms, long long *launches,
 }
 
 extern "C" void *mskf_ctx_hip_stream(mskf_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int mskf_ctx_get_host_time(mskf_ctx *c, double out[4], int reset) {
+    if (!c || !out) return MSKF_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) { out[k] = c->host_s[k]; if (reset) c->host_s[k] = 0; }
+    return MSKF_OK;
+}
 
 void fill_pyr(const mskf_stream *s, int idx, PyrDev &p) {
     for (int l = 0; l < MSKF_LEVELS; ++l) {
@@ -403,6 +410,7 @@ extern "C" int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_c
 extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args) {
     if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
+    const auto t_h0 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;
     int rc = ctx->desc[1].ensure(n);
     if (rc != MSKF_OK) return rc;
@@ -465,7 +473,9 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     mskf_t_end(ctx, ts_g1, 0);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
     MSKF_HIPCHK(hipGetLastError());
+    ctx->host_s[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
     if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
+    const auto t_h1 = std::chrono::steady_clock::now();
     long long tracks_t = 0, tracks_s = 0, pts = 0;
     for (int i = 0; i < n; ++i) {
         const mskf_fe_track_args &a = args[i];
@@ -488,6 +498,7 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     if (ts_g0 >= 0) ctx->t_pending[ts_g0].units = pts;
     if (ts_g1 >= 0) ctx->t_pending[ts_g1].units = pts;
     mskf_t_collect(ctx);
+    ctx->host_s[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
     return MSKF_OK;
 }
 

@@ -244,6 +244,7 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<FrameBatch>> queue;
+    std::vector<std::unique_ptr<FrameBatch>> pool;      // consumed batches, reused by the producer
     bool producer_done = false;
     std::atomic<int> ekf_rc{MSKF_OK};
     std::string ekf_err;
@@ -262,6 +263,7 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
             int rc = feed_imu(fb->frame, false, true);
             if (rc == MSKF_OK) rc = step_ekf(fb.get());
             if (rc != MSKF_OK) ekf_rc.store(rc);
+            { std::lock_guard<std::mutex> lk(mu); pool.push_back(std::move(fb)); }
         }
     });
     int rc = MSKF_OK;
@@ -269,7 +271,15 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
         rc = feed_imu(k, true, false);
         if (rc == MSKF_OK) rc = step_fe(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
         if (rc != MSKF_OK) break;
-        std::unique_ptr<FrameBatch> fb(new FrameBatch);
+        // hand-off = a snapshot of every stream's message (live + stale entries + the first tail record).  The batches and
+        // their per-stream messages are recycled through `pool` (at most 2 queued + 1 in the filter stage + 1 being
+        // filled), so the steady state allocates nothing
+        std::unique_ptr<FrameBatch> fb;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!pool.empty()) { fb = std::move(pool.back()); pool.pop_back(); }
+        }
+        if (!fb) fb.reset(new FrameBatch);
         fb->frame = k;
         fb->msg.resize(n); fb->tail_start.resize(n); fb->total.resize(n);
         for (int i = 0; i < n; ++i) {
@@ -277,7 +287,7 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
             const CameraMeasurement &live = *ip.feature_msg_ptr_;
             const size_t total = live.features.size(), start = ip.zeroTailStart();
             const size_t keep = std::min(total, start + 1);
-            fb->msg[i].reset(new CameraMeasurement);
+            if (!fb->msg[i] || fb->msg[i].use_count() > 1) fb->msg[i].reset(new CameraMeasurement);
             fb->msg[i]->time_stamp = live.time_stamp;
             fb->msg[i]->features.assign(live.features.begin(), live.features.begin() + keep);
             fb->tail_start[i] = start; fb->total[i] = total;

@@ -74,6 +74,17 @@ void mskfh_runner_get_timing(void *h, double *ms, long long *launches, long long
     }
 }
 
+// host seconds inside the batched C-ABI calls (packing / unpacking around the device work), summed over groups:
+// [0] update pack, [1] update unpack, [2] track pack, [3] track unpack
+void mskfh_runner_get_abi_host_time(void *h, double *out, int reset) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int k = 0; k < 4; ++k) out[k] = 0;
+    for (int g = 0; g < r->n_groups(); ++g) {
+        mskf_ctx *cs[2] = {r->group(g).ctx(), r->group(g).ekf_ctx()};
+        for (mskf_ctx *c : cs) { double t[4]; if (mskf_ctx_get_host_time(c, t, reset) == MSKF_OK) for (int k = 0; k < 4; ++k) out[k] += t[k]; }
+    }
+}
+
 // wall seconds per step() phase summed over groups (BatchGroup::PH_*), optionally reset
 void mskfh_runner_get_phases(void *h, double *out, int reset) {
     MultiRunner *r = (MultiRunner *)h;

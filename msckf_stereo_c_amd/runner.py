@@ -152,6 +152,13 @@ class Runner:
         self.L.mskfh_runner_get_phases(self.h, _p(out), int(reset))
         return {n: float(out[i]) for i, n in enumerate(self.PHASES)}
 
+    def get_abi_host_time(self, reset=True):
+        """Host seconds inside the batched C-ABI calls, outside the device waits, summed over groups."""
+        out = np.zeros(4)
+        self.L.mskfh_runner_get_abi_host_time.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L.mskfh_runner_get_abi_host_time(self.h, _p(out), int(reset))
+        return dict(zip(("update_pack", "update_unpack", "track_pack", "track_unpack"), (float(x) for x in out)))
+
     def get_hostprof(self, reset=True):
         """Seconds of host bookkeeping per slot of csrc/host/host_prof.h, summed over all streams and threads."""
         out = np.zeros(64)
