@@ -36,7 +36,7 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 
 # BASELINE.json configs: image, clone window, grid rows x cols x min x max, streams per GPU, groups
 CONFIGS = {
-    "c2": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=768, groups=8, loop=100, cpu_frames=150, cpu_all_frames=80,
+    "c2": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=1536, groups=8, loop=60, cpu_frames=150, cpu_all_frames=80,
                name="configs[1] Single MI355X: 752x480 stereo, 30 cam clones, 400 features/frame, 200 Hz IMU"),
     "c3": dict(width=1280, height=720, clones=50, grid="10x20x4x5", streams=128, groups=8, loop=60, cpu_frames=60, cpu_all_frames=30,
                name="configs[2] Single MI355X stress: 1280x720 stereo, 50 cam clones, 1000 features/frame"),

@@ -53,6 +53,8 @@ int arena_ensure(char **h, char **d, size_t *cap, size_t need) {
 }  // namespace
 
 struct EkfExtra {  // lives behind EkfStreamState via the stream (kept out of the device header)
+    EkfStreamDev desc_static;         // constant part of the stream's descriptors (base_desc)
+    bool desc_valid = false;
     double *P_alt = nullptr;          // ping-pong target of clone removal
     char *h_small = nullptr, *d_small = nullptr;   // Phi/Q sequence, J
     size_t small_cap = 0;
@@ -111,24 +113,34 @@ void mskf_ekf_stream_free(mskf_stream *s) {
     }
 }
 
+// The per-stream part of a descriptor that never changes (noise levels, extrinsics, buffer pointers that are only
+// replaced together with `desc_valid = false`) is built once and copied; d and the ping-pong P are patched in.
 static void base_desc(const mskf_stream *s, EkfStreamDev &D) {
-    std::memset(&D, 0, sizeof(D));
     const EkfStreamState &E = s->ekf_state;
-    D.P = E.P; D.d = E.d; D.ld = E.ld;
-    D.sigma2 = s->ekf.noise_feature * s->ekf.noise_feature;   // msckf_vio.cpp:74,81
-    D.max_stack_rows = s->ekf.max_stack_rows;
-    D.qr_mode = s->ekf.compression_mode;
-    D.chi2 = E.chi2;
-    D.remove_index = D.remove_index2 = -1;
-    // continuous_noise_cov diagonal blocks: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:70-80, 174-178)
-    D.qc[0] = s->ekf.noise_gyro * s->ekf.noise_gyro;
-    D.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
-    D.qc[2] = s->ekf.noise_acc * s->ekf.noise_acc;
-    D.qc[3] = s->ekf.noise_acc_bias * s->ekf.noise_acc_bias;
-    D.Hs = E.Hs; D.rowmask = (unsigned long long *)E.rs; D.T = E.T; D.S = E.S; D.W = E.W; D.act = E.act; D.gate_S = E.gate_S; D.nmax = E.nmax;
-    hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
-    std::memcpy(D.R_c0_c1, T01.R.m, sizeof(D.R_c0_c1));
-    for (int i = 0; i < 3; ++i) D.t_c0_c1[i] = T01.t[i];
+    EkfExtra *X = extra_of(const_cast<mskf_stream *>(s));
+    if (!X->desc_valid) {
+        EkfStreamDev &T = X->desc_static;
+        std::memset(&T, 0, sizeof(T));
+        T.ld = E.ld;
+        T.sigma2 = s->ekf.noise_feature * s->ekf.noise_feature;   // msckf_vio.cpp:74,81
+        T.max_stack_rows = s->ekf.max_stack_rows;
+        T.qr_mode = s->ekf.compression_mode;
+        T.chi2 = E.chi2;
+        T.remove_index = T.remove_index2 = -1;
+        // continuous_noise_cov diagonal blocks: gyro, gyro bias, acc, acc bias (msckf_vio.cpp:70-80, 174-178)
+        T.qc[0] = s->ekf.noise_gyro * s->ekf.noise_gyro;
+        T.qc[1] = s->ekf.noise_gyro_bias * s->ekf.noise_gyro_bias;
+        T.qc[2] = s->ekf.noise_acc * s->ekf.noise_acc;
+        T.qc[3] = s->ekf.noise_acc_bias * s->ekf.noise_acc_bias;
+        T.T = E.T; T.S = E.S; T.W = E.W; T.act = E.act; T.gate_S = E.gate_S; T.nmax = E.nmax;
+        hm::Rigid T01 = hm::Rigid::from_rowmajor16(s->calib.T_cam1_cam0);   // CAMState::T_cam0_cam1, msckf_vio.cpp:121-122
+        std::memcpy(T.R_c0_c1, T01.R.m, sizeof(T.R_c0_c1));
+        for (int i = 0; i < 3; ++i) T.t_c0_c1[i] = T01.t[i];
+        X->desc_valid = true;
+    }
+    D = X->desc_static;
+    D.P = E.P; D.d = E.d;
+    D.Hs = E.Hs; D.rowmask = (unsigned long long *)E.rs;
 }
 
 static int small_begin(mskf_stream *s, EkfExtra *X, size_t bytes) {

@@ -447,6 +447,28 @@ def test_c5_4k_60_clones(oracle):
     run.close()
 
 
+def test_long_run_c2_grid(oracle):
+    """260 frames of one stream at the benchmark's own shape (752x480, 8x10x(5..6) grid ~ 440 features, 30 clones) in
+    lockstep with the oracle: ~240 filter frames with a lost-feature update (compressed, uncompressed when it stacks no
+    more rows than active columns) and a pruning update (thread-per-feature blocks, fused small update) every other
+    frame.  Ids, lifetimes and pixels bit-exact in every frame, poses at 1e-4 m / 1e-4 rad, covariance at 1e-5."""
+    syn = oracle.Synth(seed=0x5EED0C22, width=752, height=480, n_static=25, n_loop=100)
+    fe = default_fe_cfg(grid_row=8, grid_col=10, grid_min=5, grid_max=6)
+    ekf = default_ekf_cfg(max_cam_state_size=30)
+    osys, run = _lockstep(oracle, syn, fe, ekf, 260, check_every=1)
+    assert len(run.dump()[0]) >= 400 and run.num_clones() >= 28
+    assert osys.num_updates() == run.num_updates() > 300
+    assert run.num_uncompressed_updates() > 5               # both shapes of the lost-feature update occurred
+    compare_msgs(osys, run)
+    dp, da = compare_poses(osys, run)
+    Po, Pg = osys.cov(), run.cov()
+    perr = np.abs(Po - Pg).max() / np.abs(Po).max()
+    print("260 frames: max |dp| %.3e m, max dtheta %.3e rad, |dP|/|P| %.3e, %d updates (%d uncompressed, %d TSQR)"
+          % (dp, da, perr, run.num_updates(), run.num_uncompressed_updates(), run.num_tsqr_updates()))
+    assert perr < 1e-5
+    run.close()
+
+
 def test_staggered_groups_run_ahead(oracle):
     """MultiRunner::set_stagger (bench.py: replicas of a looping sequence in different groups are kept frames apart so
     that they never read the same stereo pair at the same time): group g is g * delta frames ahead, and each group's
