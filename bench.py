@@ -432,10 +432,14 @@ def main(argv=None):
         # separately); only comparable when a launch covers the same number of streams
         try:
             pmc_all = json.load(open(PMC_TRAFFIC_FILE))
-            pmc = pmc_all["kernels"].get(dom)
-            if pmc and per_group == pmc_all.get("streams_per_launch", 64) and args.config == pmc_all.get("config", "c2"):
-                roof["traffic"] = (pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0
-                roof["traffic_note"] = "bytes/launch, raw FETCH_SIZE+WRITE_SIZE of %s (no gfx950 correction applied)" % os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
+            pmc = pmc_all["kernels"].get({"k_lk_points": "k_lk_points4"}.get(dom, dom)) or pmc_all["kernels"].get(dom)
+            spl = pmc_all.get("streams_per_launch", 96)
+            if pmc and args.config == pmc_all.get("config", "c2"):
+                # every stream of a launch reads its own images: traffic per launch is proportional to the streams in it
+                roof["traffic"] = (pmc["fetch_kb_per_launch"] + pmc["write_kb_per_launch"]) * 1024.0 * per_group / spl
+                roof["traffic_note"] = ("bytes/launch, raw FETCH_SIZE+WRITE_SIZE of %s (collected at %d streams per launch, scaled to %d; "
+                                        "no gfx950 correction applied: dword loads, not the calibrated 16 B/lane stream)"
+                                        % (os.path.relpath(PMC_TRAFFIC_FILE, ROOT), spl, per_group))
         except Exception:
             pass
         roof["avg_launch_us"] = avg_s * 1e6

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r01_pmc_hbm_traffic.json.
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/rNN_pmc_hbm_traffic.json.
 
 usage: tools/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>" [streams per launch]
 Values are RAW counter KB per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE under-reports wide coalesced
@@ -30,7 +30,7 @@ def main():
     spl = int(sys.argv[5]) if len(sys.argv) > 5 else 96
     ft, fc = agg(fetch, "FETCH_SIZE")
     wt, wc = agg(write, "WRITE_SIZE")
-    res = {"command": cmd, "streams_per_launch": spl,
+    res = {"command": cmd, "streams_per_launch": spl, "config": "c2",
            "note": "KB per launch, RAW FETCH_SIZE / WRITE_SIZE (separate passes); "
                    "gfx950 FETCH_SIZE halves wide 16 B/lane streams, narrower widths are uncalibrated: no factor applied",
            "kernels": {k: {"launches": fc[k], "fetch_kb_per_launch": round(ft[k] / fc[k], 1),
