@@ -45,6 +45,9 @@ int mskf_ctx_create(int device, mskf_ctx **out);
  * The batch runner puts the filter stage of a pipelined group (the serial dependency chain of the step) on such a
  * context so that its short kernels are dispatched ahead of the front-end's wide ones. */
 int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **out);
+/* A second context (own staging arenas, events, timing) whose work is enqueued on `parent`'s HIP stream: two host threads
+ * (e.g. the front-end and the filter of one group of streams) can then feed one hardware queue.  `parent` must outlive it. */
+int mskf_ctx_create_shared(mskf_ctx *parent, mskf_ctx **out);
 void mskf_ctx_destroy(mskf_ctx *ctx);
 int mskf_ctx_sync(mskf_ctx *ctx);
 /* the HIP stream of this context as a void* (hipStream_t), for event timing by the caller */
@@ -115,6 +118,12 @@ typedef struct mskf_fe_track_args {
 
 int mskf_fe_track(mskf_stream *s, const mskf_fe_track_args *args);
 int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args);
+/* The same in two halves, so that a host thread can prepare another batch (on another context, possibly sharing this
+ * one's HIP stream: mskf_ctx_create_shared) while the device works: _begin validates, stages and enqueues everything and
+ * returns; _end waits and copies the results into the args passed to _begin (they and their arrays must still be valid).
+ * One pending batch per context. */
+int mskf_fe_track_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args);
+int mskf_fe_track_batch_end(mskf_ctx *ctx);
 
 /* curr cam0 pyramid becomes the prev pyramid (image_processor.cpp:194) */
 int mskf_fe_swap(mskf_stream *s);
@@ -186,10 +195,15 @@ int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, co
 /* position variances P(12,12), P(13,13), P(14,14) for onlineReset (msckf_vio.cpp:1194-1196). Synchronises. */
 int mskf_ekf_get_pos_var(mskf_stream *s, double out[3]);
 int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out /* 3n */);
+int mskf_ekf_get_pos_var_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out /* 3n, filled by _end */);
+int mskf_ekf_get_pos_var_batch_end(mskf_ctx *ctx);
 int mskf_ekf_propagate(mskf_stream *s, int n_steps, const double *Phi /* n x 21x21 */, const double *Q /* n x 21x21 */);
 int mskf_ekf_augment(mskf_stream *s, const double *J /* 6x21 */);
 int mskf_ekf_update(mskf_stream *s, mskf_ekf_update_args *args);
 int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args);
+/* begin / end halves as for mskf_fe_track_batch; `streams` and `args` must stay valid until _end */
+int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args);
+int mskf_ekf_update_batch_end(mskf_ctx *ctx);
 int mskf_ekf_remove_clone(mskf_stream *s, int clone_index);
 /* Remove up to two clones per stream in one launch: idx[2*i], idx[2*i+1] are clone indices in the CURRENT
  * state order (distinct; -1 = none).  Equivalent to mskf_ekf_remove_clone calls (msckf_vio.cpp:1161-1181). */

@@ -40,13 +40,14 @@ class EkfUpdateArgs(C.Structure):
 
 
 EXPORTS = [
-    "mskf_last_error", "mskf_abi_version", "mskf_ctx_create", "mskf_ctx_create_prio", "mskf_ctx_destroy", "mskf_ctx_sync", "mskf_ctx_hip_stream",
+    "mskf_last_error", "mskf_abi_version", "mskf_ctx_create", "mskf_ctx_create_prio", "mskf_ctx_create_shared", "mskf_ctx_destroy", "mskf_ctx_sync", "mskf_ctx_hip_stream",
     "mskf_stream_create", "mskf_stream_destroy", "mskf_fe_push_stereo", "mskf_fe_push_stereo_device",
     "mskf_fe_push_stereo_batch", "mskf_fe_get_cell_maxima", "mskf_fe_get_cell_candidates", "mskf_fe_track", "mskf_fe_track_batch", "mskf_fe_swap",
     "mskf_fe_get_level", "mskf_ekf_reset", "mskf_ekf_propagate", "mskf_ekf_augment", "mskf_ekf_update",
     "mskf_ekf_update_batch", "mskf_ekf_remove_clone", "mskf_ekf_remove_clones_batch", "mskf_ekf_predict_batch", "mskf_ekf_propagate_imu",
     "mskf_ekf_get_pos_var", "mskf_ekf_get_pos_var_batch", "mskf_ctx_set_timing", "mskf_ctx_get_timing", "mskf_stream_ctx",
-    "mskf_ekf_get_dim", "mskf_ekf_get_cov", "mskf_ekf_set_cov", "mskf_ekf_debug_read", "mskf_ctx_get_host_time",
+    "mskf_ekf_get_dim", "mskf_ekf_get_cov", "mskf_ekf_set_cov", "mskf_ekf_debug_read", "mskf_ctx_get_host_time", "mskf_fe_track_batch_begin", "mskf_fe_track_batch_end",
+    "mskf_ekf_update_batch_begin", "mskf_ekf_update_batch_end", "mskf_ekf_get_pos_var_batch_begin", "mskf_ekf_get_pos_var_batch_end",
 ]
 
 

@@ -312,7 +312,13 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
 }
 
 extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out) {
+    const int rc = mskf_ekf_get_pos_var_batch_begin(ctx, n, streams, out);
+    return rc != MSKF_OK ? rc : mskf_ekf_get_pos_var_batch_end(ctx);
+}
+
+extern "C" int mskf_ekf_get_pos_var_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, double *out) {
     if (!ctx || n <= 0 || !streams || !out) return MSKF_ERR_INVALID;
+    if (ctx->pend_pv.active) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t desc_bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
@@ -332,9 +338,19 @@ extern "C" int mskf_ekf_get_pos_var_batch(mskf_ctx *ctx, int n, mskf_stream *con
     MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.d, ctx->pred_arena.h, desc_bytes, hipMemcpyHostToDevice, st));
     ekf_launch_posvar((const EkfStreamDev *)ctx->pred_arena.d, n, (double *)(ctx->pred_arena.d + desc_bytes), st);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.h + desc_bytes, ctx->pred_arena.d + desc_bytes, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
-    { const int wrc = mskf_wait(ctx); if (wrc != MSKF_OK) return wrc; }
+    { const int wrc = mskf_wait_event(ctx, &ctx->pend_pv.done, true); if (wrc != MSKF_OK) return wrc; }
+    ctx->pend_pv.active = true; ctx->pend_pv.n = n; ctx->pend_pv.out = out; ctx->pend_pv.desc_bytes = desc_bytes;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ekf_get_pos_var_batch_end(mskf_ctx *ctx) {
+    if (!ctx) return MSKF_ERR_INVALID;
+    if (!ctx->pend_pv.active) return MSKF_OK;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    ctx->pend_pv.active = false;
+    { const int wrc = mskf_wait_event(ctx, &ctx->pend_pv.done, false); if (wrc != MSKF_OK) return wrc; }
     mskf_t_collect(ctx);
-    std::memcpy(out, ctx->pred_arena.h + desc_bytes, sizeof(double) * 3 * (size_t)n);
+    std::memcpy(ctx->pend_pv.out, ctx->pred_arena.h + ctx->pend_pv.desc_bytes, sizeof(double) * 3 * (size_t)ctx->pend_pv.n);
     return MSKF_OK;
 }
 
@@ -431,7 +447,13 @@ extern "C" int mskf_ekf_remove_clone(mskf_stream *s, int clone_index) {
 }
 
 extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args) {
+    const int rc = mskf_ekf_update_batch_begin(ctx, n, streams, args);
+    return rc != MSKF_OK ? rc : mskf_ekf_update_batch_end(ctx);
+}
+
+extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, mskf_ekf_update_args *args) {
     if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
+    if (ctx->pend_upd.active) { mskf_set_error("an update batch of this context is still pending (call mskf_ekf_update_batch_end)"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     const auto t_h0 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;
@@ -609,15 +631,46 @@ extern "C" int mskf_ekf_update_batch(mskf_ctx *ctx, int n, mskf_stream *const *s
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
-        ctx->host_s[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
-        if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
+        if ((rc = mskf_wait_event(ctx, &ctx->pend_upd.done, true)) != MSKF_OK) return rc;
+    }
+    {
+        mskf_ctx::PendingUpdate &U = ctx->pend_upd;
+        U.active = true; U.launched = max_feat > 0; U.n = n; U.streams = streams; U.args = args;
+        U.lay.resize((size_t)5 * n);
+        for (int i = 0; i < n; ++i) {
+            U.lay[5 * i] = lay[i].o_dx; U.lay[5 * i + 1] = lay[i].o_gamma; U.lay[5 * i + 2] = lay[i].o_rows;
+            U.lay[5 * i + 3] = lay[i].o_status; U.lay[5 * i + 4] = lay[i].o_pos;
+        }
+    }
+    ctx->host_s[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
+    return MSKF_OK;
+}
+
+// Wait for the batch started by mskf_ekf_update_batch_begin and copy delta_x, gate results, positions and the stacked
+// row counts into the args given there.  No-op when nothing is pending.
+extern "C" int mskf_ekf_update_batch_end(mskf_ctx *ctx) {
+    if (!ctx) return MSKF_ERR_INVALID;
+    mskf_ctx::PendingUpdate &U = ctx->pend_upd;
+    if (!U.active) return MSKF_OK;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    U.active = false;
+    if (U.launched) {
+        int rc;
+        if ((rc = mskf_wait_event(ctx, &U.done, false)) != MSKF_OK) return rc;
         mskf_t_collect(ctx);
     }
     const auto t_h1 = std::chrono::steady_clock::now();
+    const int n = U.n;
+    mskf_stream *const *streams = U.streams;
+    mskf_ekf_update_args *args = U.args;
+    const char *hout = ctx->upd_out.h;
+    struct LayOut { size_t o_dx, o_gamma, o_rows, o_status, o_pos; };
+    std::vector<LayOut> lay(n);
+    for (int i = 0; i < n; ++i) lay[i] = LayOut{U.lay[5 * i], U.lay[5 * i + 1], U.lay[5 * i + 2], U.lay[5 * i + 3], U.lay[5 * i + 4]};
     for (int i = 0; i < n; ++i) {
         mskf_ekf_update_args &a = args[i];
         EkfStreamState &E = streams[i]->ekf_state;
-        const Lay &L = lay[i];
+        const LayOut &L = lay[i];
         const int d = E.d;
         if (!a.n_feat) {
             if (a.delta_x) std::memset(a.delta_x, 0, sizeof(double) * (size_t)d);

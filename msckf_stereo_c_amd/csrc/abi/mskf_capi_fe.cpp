@@ -39,6 +39,17 @@ extern "C" int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **ou
     return MSKF_OK;
 }
 
+extern "C" int mskf_ctx_create_shared(mskf_ctx *parent, mskf_ctx **out) {
+    if (!parent || !out) return MSKF_ERR_INVALID;
+    mskf_ctx *c = new mskf_ctx();
+    c->device = parent->device;
+    c->stream = parent->stream;
+    c->owns_stream = false;
+    c->wait_block = parent->wait_block;
+    *out = c;
+    return MSKF_OK;
+}
+
 extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -52,19 +63,27 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     c->pred_arena.release();
     if (c->pred_done) (void)hipEventDestroy(c->pred_done);
     if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
-    (void)hipStreamDestroy(c->stream);
+    if (c->cell_ev) (void)hipEventDestroy(c->cell_ev);
+    if (c->pend_trk.done) (void)hipEventDestroy(c->pend_trk.done);
+    if (c->pend_upd.done) (void)hipEventDestroy(c->pend_upd.done);
+    if (c->pend_pv.done) (void)hipEventDestroy(c->pend_pv.done);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
-int mskf_wait(mskf_ctx *c) {
-    if (c->wait_block) {
-        if (!c->wait_ev) MSKF_HIPCHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming | hipEventBlockingSync));
-        MSKF_HIPCHK(hipEventRecord(c->wait_ev, c->stream));
-        MSKF_HIPCHK(hipEventSynchronize(c->wait_ev));
-        return MSKF_OK;
-    }
-    MSKF_HIPCHK(hipStreamSynchronize(c->stream));
+// Record (optionally) and wait for an event on the context's stream: what THIS context has enqueued up to the record,
+// not the whole stream (on a shared stream another context may already have queued later work).  MSKF_WAIT=block parks
+// the thread instead of spinning.
+int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
+    if (!*ev_slot) MSKF_HIPCHK(hipEventCreateWithFlags(ev_slot, hipEventDisableTiming | (c->wait_block ? hipEventBlockingSync : 0)));
+    if (record) { MSKF_HIPCHK(hipEventRecord(*ev_slot, c->stream)); return MSKF_OK; }
+    MSKF_HIPCHK(hipEventSynchronize(*ev_slot));
     return MSKF_OK;
+}
+int mskf_wait(mskf_ctx *c) {
+    int rc = mskf_wait_event(c, &c->wait_ev, true);
+    if (rc != MSKF_OK) return rc;
+    return mskf_wait_event(c, &c->wait_ev, false);
 }
 
 extern "C" int mskf_ctx_sync(mskf_ctx *c) {
@@ -319,6 +338,7 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
         mskf_t_end(ctx, ts, px);
     }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
+    { const int erc = mskf_wait_event(ctx, &ctx->cell_ev, true); if (erc != MSKF_OK) return erc; }
     MSKF_HIPCHK(hipGetLastError());
     return MSKF_OK;
 }
@@ -373,7 +393,9 @@ static int cell_keys_ready(mskf_stream *s) {
     if (!s->has_curr) { mskf_set_error("no stereo pair pushed yet"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(s->ctx->device));
     if (s->push_gen != s->ctx->push_gen) { mskf_set_error("cell maxima are stale: another push happened on this context"); return MSKF_ERR_INVALID; }
-    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));   // no ctx mutation here: callable concurrently for different streams
+    // wait for the copy of this push's maxima only (not the whole stream: on a shared stream another context may have
+    // queued later work); no ctx mutation here: callable concurrently for different streams
+    if (s->ctx->cell_ev) MSKF_HIPCHK(hipEventSynchronize(s->ctx->cell_ev));
     return MSKF_OK;
 }
 
@@ -408,7 +430,13 @@ extern "C" int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_c
 }
 
 extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args) {
+    const int rc = mskf_fe_track_batch_begin(ctx, n, streams, args);
+    return rc != MSKF_OK ? rc : mskf_fe_track_batch_end(ctx);
+}
+
+extern "C" int mskf_fe_track_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args) {
     if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
+    if (ctx->pend_trk.active) { mskf_set_error("a track batch of this context is still pending (call mskf_fe_track_batch_end)"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     const auto t_h0 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;
@@ -416,7 +444,9 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     if (rc != MSKF_OK) return rc;
     int max_pts = 0;
     size_t in_bytes = 0, out_bytes = 0;
-    std::vector<size_t> in_off(n), out_off(n);
+    std::vector<size_t> in_off(n);
+    std::vector<size_t> &out_off = ctx->pend_trk.out_off;
+    out_off.resize(n);
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         const mskf_fe_track_args &a = args[i];
@@ -430,7 +460,7 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
         out_bytes += (4 * sizeof(mskf_point2f) * np + np + 63) & ~(size_t)63;   // out0 out1 und0 und1 status
         max_pts = std::max(max_pts, a.n);
     }
-    if (max_pts <= 0) return MSKF_OK;
+    if (max_pts <= 0) return MSKF_OK;      // nothing to track: no batch pending, _end is a no-op
     if (in_bytes > ctx->trk_in.cap || out_bytes > ctx->trk_out.cap) {
         MSKF_HIPCHK(hipStreamSynchronize(st));
         if ((rc = ctx->trk_in.ensure(in_bytes)) != MSKF_OK) return rc;
@@ -473,8 +503,26 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
     mskf_t_end(ctx, ts_g1, 0);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
     MSKF_HIPCHK(hipGetLastError());
+    if ((rc = mskf_wait_event(ctx, &ctx->pend_trk.done, true)) != MSKF_OK) return rc;
+    ctx->pend_trk.active = true; ctx->pend_trk.n = n; ctx->pend_trk.args = args;
+    ctx->pend_trk.ts_t = ts_t; ctx->pend_trk.ts_s = ts_s; ctx->pend_trk.ts_g0 = ts_g0; ctx->pend_trk.ts_g1 = ts_g1;
     ctx->host_s[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
-    if ((rc = mskf_wait(ctx)) != MSKF_OK) return rc;
+    return MSKF_OK;
+}
+
+// Wait for the batch started by mskf_fe_track_batch_begin and copy its results into the args given there (which, like
+// their output arrays, must still be valid).  No-op when nothing is pending.
+extern "C" int mskf_fe_track_batch_end(mskf_ctx *ctx) {
+    if (!ctx) return MSKF_ERR_INVALID;
+    if (!ctx->pend_trk.active) return MSKF_OK;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = mskf_wait_event(ctx, &ctx->pend_trk.done, false)) != MSKF_OK) return rc;
+    ctx->pend_trk.active = false;
+    const int n = ctx->pend_trk.n;
+    const mskf_fe_track_args *args = ctx->pend_trk.args;
+    const std::vector<size_t> &out_off = ctx->pend_trk.out_off;
+    const int ts_t = ctx->pend_trk.ts_t, ts_s = ctx->pend_trk.ts_s, ts_g0 = ctx->pend_trk.ts_g0, ts_g1 = ctx->pend_trk.ts_g1;
     const auto t_h1 = std::chrono::steady_clock::now();
     long long tracks_t = 0, tracks_s = 0, pts = 0;
     for (int i = 0; i < n; ++i) {

@@ -63,12 +63,14 @@ struct mskf_ctx {
     long long t_launches[MSKF_K_COUNT] = {0}, t_units[MSKF_K_COUNT] = {0};
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;          // false: created by mskf_ctx_create_shared on another context's stream
     PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
     hipEvent_t wait_ev = nullptr;     // blocking-sync event of mskf_wait (MSKF_WAIT=block)
     bool wait_block = false;
     PinnedDev<char> cell_arena;       // per-cell maximum keys of every stream of the last push batch (one D2H copy)
     PinnedDev<char> trk_in, trk_out;  // input points / results of every stream of a track batch (one copy each way)
     unsigned long long push_gen = 0;
+    hipEvent_t cell_ev = nullptr;     // recorded behind the D2H copy of the per-cell maxima of the last push
     bool cell_keys_dirty = true;      // the key array holds bytes no generation tag explains (fresh allocation): clear before use
     PinnedDev<PyrJob> jobs;
     PinnedDev<EkfStreamDev> ekf_desc;
@@ -77,7 +79,21 @@ struct mskf_ctx {
     hipEvent_t pred_done = nullptr;
     bool pred_pending = false;
     std::vector<mskf_stream *> streams;
+    // a batch between its *_begin and *_end call (one of each kind per context)
+    struct PendingTrack {
+        bool active = false; int n = 0; const mskf_fe_track_args *args = nullptr;
+        std::vector<size_t> out_off; int ts_t = -1, ts_s = -1, ts_g0 = -1, ts_g1 = -1;
+        hipEvent_t done = nullptr;
+    } pend_trk;
+    struct PendingUpdate {
+        bool active = false, launched = false; int n = 0; mskf_stream *const *streams = nullptr; mskf_ekf_update_args *args = nullptr;
+        std::vector<size_t> lay;   // per stream: o_dx, o_gamma, o_rows, o_status, o_pos
+        hipEvent_t done = nullptr;
+    } pend_upd;
+    struct PendingPosVar { bool active = false; int n = 0; double *out = nullptr; size_t desc_bytes = 0; hipEvent_t done = nullptr; } pend_pv;
 };
+// wait for an event this context recorded (spinning, or parked with MSKF_WAIT=block)
+int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record);
 
 struct mskf_stream {
     mskf_ctx *ctx = nullptr;

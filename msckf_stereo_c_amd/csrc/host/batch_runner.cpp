@@ -49,19 +49,30 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
     if (const char *e = std::getenv("MSKF_EKF_HOST_THREADS")) ht_ekf = std::max(1, std::atoi(e));
     if (ht_fe > 1) pool_.reset(new ForkJoin(ht_fe));
     if (ht_ekf > 1) pool_ekf_.reset(new ForkJoin(ht_ekf));
-    int rc = mskf_ctx_create(device, &ctx_);
+    // two half-batches from 8 streams up (MSKF_HALVES=1 keeps one batch per group)
+    int nh = n >= 8 ? 2 : 1;
+    if (const char *e = std::getenv("MSKF_HALVES")) nh = std::max(1, std::min(2, std::atoi(e)));
+    if (n < 2) nh = 1;
+    half_.resize(nh);
+    int rc = mskf_ctx_create(device, &half_[0].ctx);
     if (rc == MSKF_OK) {
         const char *pe = std::getenv("MSKF_EKF_PRIORITY");   // default on; MSKF_EKF_PRIORITY=0 disables
-        rc = mskf_ctx_create_prio(device, !(pe && pe[0] == '0'), &ctx_ekf_);
+        rc = mskf_ctx_create_prio(device, !(pe && pe[0] == '0'), &half_[0].ctx_ekf);
+    }
+    for (int h = 1; h < nh && rc == MSKF_OK; ++h) {
+        rc = mskf_ctx_create_shared(half_[0].ctx, &half_[h].ctx);
+        if (rc == MSKF_OK) rc = mskf_ctx_create_shared(half_[0].ctx_ekf, &half_[h].ctx_ekf);
     }
     if (rc != MSKF_OK) { error_ = mskf_last_error(); return; }
+    for (int h = 0; h < nh; ++h) { half_[h].i0 = (int)((long long)n * h / nh); half_[h].n = (int)((long long)n * (h + 1) / nh) - half_[h].i0; }
     for (int i = 0; i < n; ++i) {
-        systems_.emplace_back(new System(calib, fe, ekf, ctx_, device));
+        const Half &H = half_[nh == 2 && i >= half_[1].i0 ? 1 : 0];
+        systems_.emplace_back(new System(calib, fe, ekf, H.ctx, device));
         if (!systems_.back()->ok()) { error_ = std::string("stream setup failed: ") + mskf_last_error(); return; }
         systems_.back()->copy_draw_buffers = false;
         streams_.push_back(systems_.back()->stream());
         // the filter half of every stream runs on its own context (own HIP stream): no device data is shared
-        if (mskf_stream_set_ekf_ctx(streams_.back(), ctx_ekf_) != MSKF_OK) { error_ = mskf_last_error(); return; }
+        if (mskf_stream_set_ekf_ctx(streams_.back(), H.ctx_ekf) != MSKF_OK) { error_ = mskf_last_error(); return; }
     }
     a1_.resize(n); a2_.resize(n); u_.resize(n); p0_.resize(n); p1_.resize(n); t_.resize(n);
     seq.resize(n);
@@ -70,8 +81,10 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
 
 BatchGroup::~BatchGroup() {
     systems_.clear();
-    if (ctx_ekf_) mskf_ctx_destroy(ctx_ekf_);
-    if (ctx_) mskf_ctx_destroy(ctx_);
+    for (size_t h = half_.size(); h-- > 0;) {      // shared contexts first: they borrow half 0's streams
+        if (half_[h].ctx_ekf) mskf_ctx_destroy(half_[h].ctx_ekf);
+        if (half_[h].ctx) mskf_ctx_destroy(half_[h].ctx);
+    }
 }
 
 void BatchGroup::imu(int i, const mskf_imu_sample &s) {
@@ -84,44 +97,59 @@ void BatchGroup::imu(int i, const mskf_imu_sample &s) {
 
 #define BR_CHK(expr) do { int _rc = (expr); if (_rc != MSKF_OK) { error_ = std::string(#expr) + ": " + mskf_last_error(); return _rc; } } while (0)
 
+// Front-end of one frame of every stream (System::stereo_callback): push (pyramids + detector) -> track (temporal LK,
+// stereo LK, gates) -> host bucketing / candidates -> track (candidates) -> host (ids, prune, publish).  The halves are
+// staggered: while the device tracks one half the thread does the other half's host part.
 int BatchGroup::step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw) {
     const int n = size();
     if (!ok_ || n == 0) return MSKF_ERR_INVALID;
     auto tp = std::chrono::steady_clock::now();
-    auto lap = [&](int ph) { auto t = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t - tp).count(); tp = t; };
-    // ---- front-end (System::stereo_callback for every stream)
-    for (int i = 0; i < n; ++i) {
-        mskf_stream *s = streams_[i];
-        (void)s;
-        ImageProcessor &ip = *systems_[i]->imgproc_ptr_;
-        // image size comes from the calibration the stream was created with
-        ip.phaseBegin(t[i], 0, 0);
-    }
-    BR_CHK(mskf_fe_push_stereo_batch(ctx_, n, streams_.data(), cam0, cam1, on_device));
+    auto lap = [&](int ph) { auto t2 = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t2 - tp).count(); tp = t2; };
+    auto parh = [&](const Half &H, const std::function<void(int)> &fn) {
+        if (pool_) pool_->run(H.n, [&](int k) { fn(H.i0 + k); }); else for (int i = H.i0; i < H.i0 + H.n; ++i) fn(i);
+    };
+    // image size comes from the calibration the stream was created with
+    for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phaseBegin(t[i], 0, 0);
+    for (Half &H : half_) BR_CHK(mskf_fe_push_stereo_batch(H.ctx, H.n, streams_.data() + H.i0, cam0 + H.i0, cam1 + H.i0, on_device));
     lap(PH_PUSH);
-    if (systems_[0]->imgproc_ptr_->isFirstImage()) BR_CHK(mskf_ctx_sync(ctx_));   // first frame: detections are read right away
-    par(n, [&](int i) { systems_[i]->imgproc_ptr_->phasePrepare1(a1_[i]); });
-    lap(PH_PREP1);
-    BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a1_.data()));
-    lap(PH_TRACK1);
-    BR_CHK(mskf_ctx_sync(ctx_));
-    par(n, [&](int i) { systems_[i]->imgproc_ptr_->phaseAfter1(a2_[i]); });
-    lap(PH_AFTER1);
-    BR_CHK(mskf_fe_track_batch(ctx_, n, streams_.data(), a2_.data()));
-    lap(PH_TRACK2);
-    par(n, [&](int i) {
-        systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
-        systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
-    });
-    lap(PH_AFTER2);
+    const bool first = systems_[0]->imgproc_ptr_->isFirstImage();
+    for (Half &H : half_) {
+        if (first) BR_CHK(mskf_ctx_sync(H.ctx));   // first frame: detections are read right away
+        parh(H, [&](int i) { systems_[i]->imgproc_ptr_->phasePrepare1(a1_[i]); });
+        lap(PH_PREP1);
+        BR_CHK(mskf_fe_track_batch_begin(H.ctx, H.n, streams_.data() + H.i0, a1_.data() + H.i0));
+        lap(PH_TRACK1);
+    }
+    for (Half &H : half_) {
+        BR_CHK(mskf_fe_track_batch_end(H.ctx));     // (the detector's per-cell maxima of this push have arrived with it)
+        lap(PH_TRACK1);
+        parh(H, [&](int i) { systems_[i]->imgproc_ptr_->phaseAfter1(a2_[i]); });
+        lap(PH_AFTER1);
+        BR_CHK(mskf_fe_track_batch_begin(H.ctx, H.n, streams_.data() + H.i0, a2_.data() + H.i0));
+        lap(PH_TRACK2);
+    }
+    for (Half &H : half_) {
+        BR_CHK(mskf_fe_track_batch_end(H.ctx));
+        lap(PH_TRACK2);
+        parh(H, [&](int i) {
+            systems_[i]->imgproc_ptr_->phaseAfter2(is_draw);
+            systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
+        });
+        lap(PH_AFTER2);
+    }
     return MSKF_OK;
 }
 
+// Filter of one frame of every stream (System::backend_callback -> MsckfVio::featureCallback): predict (IMU propagation +
+// augmentation) -> lost-feature update -> host -> pruning update -> clone removal -> position variances, staggered over
+// the halves like the front-end.
 int BatchGroup::step_ekf(const FrameBatch *fb) {
     const int n = size();
     auto tp = std::chrono::steady_clock::now();
-    auto lap = [&](int ph) { auto t = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t - tp).count(); tp = t; };
-    mskf_ctx *ctx_ = ctx_ekf_;   // every device call below belongs to the filter context
+    auto lap = [&](int ph) { auto t2 = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t2 - tp).count(); tp = t2; };
+    auto parh = [&](const Half &H, const std::function<void(int)> &fn) {
+        if (pool_ekf_) pool_ekf_->run(H.n, [&](int k) { fn(H.i0 + k); }); else for (int i = H.i0; i < H.i0 + H.n; ++i) fn(i);
+    };
     std::vector<std::shared_ptr<CameraMeasurement>> msgs(n);
     for (int i = 0; i < n; ++i) {
         MsckfVio &v = *systems_[i]->msckfvio_ptr();
@@ -131,56 +159,76 @@ int BatchGroup::step_ekf(const FrameBatch *fb) {
             v.setZeroTailHint(msgs[i].get(), systems_[i]->imgproc_ptr_->zeroTailStart());
         }
     }
-    std::vector<mskf_stream *> sub_s;
-    std::vector<mskf_ekf_update_args> sub_a;
-    std::vector<int> sub_i;
-    auto run_updates = [&]() -> int {
-        sub_s.clear(); sub_a.clear(); sub_i.clear();
-        for (int i = 0; i < n; ++i) if (u_[i].n_feat > 0) { sub_s.push_back(streams_[i]); sub_a.push_back(u_[i]); sub_i.push_back(i); }
-        if (sub_s.empty()) return MSKF_OK;
-        return mskf_ekf_update_batch(ctx_, (int)sub_s.size(), sub_s.data(), sub_a.data());
+    // streams of the half with a non-empty update -> one batched launch (args stay in H until the *_end call)
+    auto begin_updates = [&](Half &H) -> int {
+        H.sub_s.clear(); H.sub_a.clear(); H.sub_i.clear(); H.upd_pending = false;
+        for (int i = H.i0; i < H.i0 + H.n; ++i) if (u_[i].n_feat > 0) { H.sub_s.push_back(streams_[i]); H.sub_a.push_back(u_[i]); H.sub_i.push_back(i); }
+        if (H.sub_s.empty()) return MSKF_OK;
+        H.upd_pending = true;
+        return mskf_ekf_update_batch_begin(H.ctx_ekf, (int)H.sub_s.size(), H.sub_s.data(), H.sub_a.data());
     };
-    bool any = false;
-    auto par = [&](int cnt, const std::function<void(int)> &fn) { if (pool_ekf_) pool_ekf_->run(cnt, fn); else for (int i = 0; i < cnt; ++i) fn(i); };
-    par(n, [&](int i) { systems_[i]->msckfvio_ptr()->phaseA(msgs[i], u_[i], true); });
-    for (int i = 0; i < n; ++i) any |= systems_[i]->msckfvio_ptr()->frameActive();
-    if (any) {
-        std::vector<int32_t> ns(n);
-        std::vector<const mskf_imu_step *> sp(n);
-        std::vector<const double *> jp(n);
-        for (int i = 0; i < n; ++i) {
-            MsckfVio &v = *systems_[i]->msckfvio_ptr();
-            const bool act = v.frameActive();
-            ns[i] = act ? (int)v.predictSteps().size() : 0;
-            sp[i] = ns[i] ? v.predictSteps().data() : nullptr;
-            jp[i] = act ? v.predictJ() : nullptr;
+    auto end_updates = [&](Half &H) -> int {
+        if (!H.upd_pending) return MSKF_OK;
+        H.upd_pending = false;
+        return mskf_ekf_update_batch_end(H.ctx_ekf);
+    };
+    bool any_all = false;
+    for (Half &H : half_) {
+        parh(H, [&](int i) { systems_[i]->msckfvio_ptr()->phaseA(msgs[i], u_[i], true); });
+        H.any = false;
+        for (int i = H.i0; i < H.i0 + H.n; ++i) H.any |= systems_[i]->msckfvio_ptr()->frameActive();
+        any_all |= H.any;
+        if (H.any) {
+            H.ns.assign(H.n, 0); H.sp.assign(H.n, nullptr); H.jp.assign(H.n, nullptr);
+            for (int k = 0; k < H.n; ++k) {
+                MsckfVio &v = *systems_[H.i0 + k]->msckfvio_ptr();
+                const bool act = v.frameActive();
+                H.ns[k] = act ? (int)v.predictSteps().size() : 0;
+                H.sp[k] = H.ns[k] ? v.predictSteps().data() : nullptr;
+                H.jp[k] = act ? v.predictJ() : nullptr;
+            }
+            BR_CHK(mskf_ekf_predict_batch(H.ctx_ekf, H.n, streams_.data() + H.i0, H.ns.data(), H.sp.data(), H.jp.data()));
         }
-        BR_CHK(mskf_ekf_predict_batch(ctx_, n, streams_.data(), ns.data(), sp.data(), jp.data()));
+        lap(PH_EKF_A);
+        if (H.any) BR_CHK(begin_updates(H));
+        lap(PH_UPD1);
     }
-    lap(PH_EKF_A);
-    if (!any) return MSKF_OK;
-    BR_CHK(run_updates());
-    lap(PH_UPD1);
-    par(n, [&](int i) { if (systems_[i]->msckfvio_ptr()->frameActive()) systems_[i]->msckfvio_ptr()->phaseB(u_[i]); else std::memset(&u_[i], 0, sizeof(u_[i])); });
-    lap(PH_EKF_B);
-    BR_CHK(run_updates());
-    lap(PH_UPD2);
-    {
-        std::vector<int32_t> rm(2 * (size_t)n, -1);
-        bool any_rm = false;
-        par(n, [&](int i) {
+    if (!any_all) return MSKF_OK;
+    for (Half &H : half_) {
+        if (!H.any) continue;
+        BR_CHK(end_updates(H));
+        lap(PH_UPD1);
+        parh(H, [&](int i) { if (systems_[i]->msckfvio_ptr()->frameActive()) systems_[i]->msckfvio_ptr()->phaseB(u_[i]); else std::memset(&u_[i], 0, sizeof(u_[i])); });
+        lap(PH_EKF_B);
+        BR_CHK(begin_updates(H));
+        lap(PH_UPD2);
+    }
+    for (Half &H : half_) {
+        if (!H.any) continue;
+        BR_CHK(end_updates(H));
+        lap(PH_UPD2);
+        H.rm.assign(2 * (size_t)H.n, -1);
+        parh(H, [&](int i) {
             MsckfVio &v = *systems_[i]->msckfvio_ptr();
             v.phaseC(true);
-            rm[2 * i] = v.pendingRemovals()[0]; rm[2 * i + 1] = v.pendingRemovals()[1];
+            H.rm[2 * (i - H.i0)] = v.pendingRemovals()[0]; H.rm[2 * (i - H.i0) + 1] = v.pendingRemovals()[1];
         });
-        for (int i = 0; i < n; ++i) any_rm |= rm[2 * i] >= 0;
-        if (any_rm) BR_CHK(mskf_ekf_remove_clones_batch(ctx_, n, streams_.data(), rm.data()));
+        bool any_rm = false;
+        for (int k = 0; k < H.n; ++k) any_rm |= H.rm[2 * k] >= 0;
+        if (any_rm) BR_CHK(mskf_ekf_remove_clones_batch(H.ctx_ekf, H.n, streams_.data() + H.i0, H.rm.data()));
+        lap(PH_EKF_C);
+        H.pv.assign(3 * (size_t)H.n, 0.0);
+        BR_CHK(mskf_ekf_get_pos_var_batch_begin(H.ctx_ekf, H.n, streams_.data() + H.i0, H.pv.data()));
+        H.pv_pending = true;
+        lap(PH_POSVAR);
     }
-    lap(PH_EKF_C);
-    std::vector<double> pv(3 * (size_t)n);
-    BR_CHK(mskf_ekf_get_pos_var_batch(ctx_, n, streams_.data(), pv.data()));
-    for (int i = 0; i < n; ++i) systems_[i]->msckfvio_ptr()->phaseD(&pv[3 * i]);
-    lap(PH_POSVAR);
+    for (Half &H : half_) {
+        if (!H.pv_pending) continue;
+        H.pv_pending = false;
+        BR_CHK(mskf_ekf_get_pos_var_batch_end(H.ctx_ekf));
+        for (int k = 0; k < H.n; ++k) systems_[H.i0 + k]->msckfvio_ptr()->phaseD(&H.pv[3 * k]);
+        lap(PH_POSVAR);
+    }
     return MSKF_OK;
 }
 

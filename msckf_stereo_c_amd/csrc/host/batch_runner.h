@@ -68,9 +68,12 @@ class BatchGroup {
     // same frames as a two-stage pipeline: a front-end thread (context ctx()) and a filter thread (context
     // ekf_ctx()); the front-end never reads filter state, so the results are identical to run()
     int run_pipelined(int first, int n);
-    mskf_ctx *ekf_ctx() const { return ctx_ekf_; }
+    // device contexts: the streams of a group are driven as up to two half-batches, each with its own staging
+    // context; the halves of a stage share one HIP stream (mskf_ctx_create_shared), so a group still uses two queues
+    int n_halves() const { return (int)half_.size(); }
+    mskf_ctx *ctx(int h = 0) const { return half_[h].ctx; }
+    mskf_ctx *ekf_ctx(int h = 0) const { return half_[h].ctx_ekf; }
     std::vector<StreamSequence> seq;
-    mskf_ctx *ctx() const { return ctx_; }
     const std::string &error() const { return error_; }
     enum { PH_PUSH = 0, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_IMU, PH_COUNT };
     double phase_s[PH_COUNT] = {0};   // wall seconds per phase of step() (host bookkeeping vs device calls)
@@ -79,7 +82,21 @@ class BatchGroup {
     int step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw);
     int step_ekf(const FrameBatch *fb);
     int feed_imu(int k, bool to_fe, bool to_ekf);
-    mskf_ctx *ctx_ = nullptr, *ctx_ekf_ = nullptr;
+    // A half-batch: streams [i0, i0 + n).  While the device works on one half the host thread prepares or digests the
+    // other (the *_begin / *_end entry points of the C-ABI), so host bookkeeping and device time overlap inside a thread.
+    struct Half {
+        mskf_ctx *ctx = nullptr, *ctx_ekf = nullptr;
+        int i0 = 0, n = 0;
+        std::vector<mskf_stream *> sub_s;              // streams with a non-empty update, and their args (valid until *_end)
+        std::vector<mskf_ekf_update_args> sub_a;
+        std::vector<int> sub_i;
+        std::vector<int32_t> ns, rm;
+        std::vector<const mskf_imu_step *> sp;
+        std::vector<const double *> jp;
+        std::vector<double> pv;
+        bool any = false, upd_pending = false, pv_pending = false;
+    };
+    std::vector<Half> half_;
     bool ok_ = false;
     std::string error_;
     std::vector<std::unique_ptr<System>> systems_;

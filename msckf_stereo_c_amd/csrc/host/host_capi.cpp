@@ -58,20 +58,22 @@ void mskfh_runner_keep_trajectory(void *h, int keep) {
 
 void mskfh_runner_set_timing(void *h, int enable) {
     MultiRunner *r = (MultiRunner *)h;
-    for (int g = 0; g < r->n_groups(); ++g) { mskf_ctx_set_timing(r->group(g).ctx(), enable); mskf_ctx_set_timing(r->group(g).ekf_ctx(), enable); }
+    for (int g = 0; g < r->n_groups(); ++g)
+        for (int h = 0; h < r->group(g).n_halves(); ++h) { mskf_ctx_set_timing(r->group(g).ctx(h), enable); mskf_ctx_set_timing(r->group(g).ekf_ctx(h), enable); }
 }
 // sums over groups; arrays of MSKF_K_COUNT
 void mskfh_runner_get_timing(void *h, double *ms, long long *launches, long long *units, int reset) {
     MultiRunner *r = (MultiRunner *)h;
     for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] = 0; launches[k] = 0; units[k] = 0; }
-    for (int g = 0; g < r->n_groups(); ++g) {
-        mskf_ctx *cs[2] = {r->group(g).ctx(), r->group(g).ekf_ctx()};
-        for (mskf_ctx *c : cs) {
-            double m[MSKF_K_COUNT]; long long l[MSKF_K_COUNT], u[MSKF_K_COUNT];
-            if (mskf_ctx_get_timing(c, m, l, u, reset) != MSKF_OK) continue;
-            for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] += m[k]; launches[k] += l[k]; units[k] += u[k]; }
+    for (int g = 0; g < r->n_groups(); ++g)
+        for (int h = 0; h < r->group(g).n_halves(); ++h) {
+            mskf_ctx *cs[2] = {r->group(g).ctx(h), r->group(g).ekf_ctx(h)};
+            for (mskf_ctx *c : cs) {
+                double m[MSKF_K_COUNT]; long long l[MSKF_K_COUNT], u[MSKF_K_COUNT];
+                if (mskf_ctx_get_timing(c, m, l, u, reset) != MSKF_OK) continue;
+                for (int k = 0; k < MSKF_K_COUNT; ++k) { ms[k] += m[k]; launches[k] += l[k]; units[k] += u[k]; }
+            }
         }
-    }
 }
 
 // host seconds inside the batched C-ABI calls (packing / unpacking around the device work), summed over groups:
@@ -79,10 +81,11 @@ void mskfh_runner_get_timing(void *h, double *ms, long long *launches, long long
 void mskfh_runner_get_abi_host_time(void *h, double *out, int reset) {
     MultiRunner *r = (MultiRunner *)h;
     for (int k = 0; k < 4; ++k) out[k] = 0;
-    for (int g = 0; g < r->n_groups(); ++g) {
-        mskf_ctx *cs[2] = {r->group(g).ctx(), r->group(g).ekf_ctx()};
-        for (mskf_ctx *c : cs) { double t[4]; if (mskf_ctx_get_host_time(c, t, reset) == MSKF_OK) for (int k = 0; k < 4; ++k) out[k] += t[k]; }
-    }
+    for (int g = 0; g < r->n_groups(); ++g)
+        for (int h = 0; h < r->group(g).n_halves(); ++h) {
+            mskf_ctx *cs[2] = {r->group(g).ctx(h), r->group(g).ekf_ctx(h)};
+            for (mskf_ctx *c : cs) { double t[4]; if (mskf_ctx_get_host_time(c, t, reset) == MSKF_OK) for (int k = 0; k < 4; ++k) out[k] += t[k]; }
+        }
 }
 
 // wall seconds per step() phase summed over groups (BatchGroup::PH_*), optionally reset
