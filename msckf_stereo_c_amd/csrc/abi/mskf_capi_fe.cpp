@@ -63,6 +63,7 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     c->pred_arena.release();
     if (c->pred_done) (void)hipEventDestroy(c->pred_done);
     if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+    if (c->flag_h) (void)hipHostFree((void *)c->flag_h);
     if (c->cell_ev) (void)hipEventDestroy(c->cell_ev);
     if (c->pend_trk.done) (void)hipEventDestroy(c->pend_trk.done);
     if (c->pend_upd.done) (void)hipEventDestroy(c->pend_upd.done);
@@ -71,13 +72,33 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     delete c;
 }
 
-// Record (optionally) and wait for an event on the context's stream: what THIS context has enqueued up to the record,
-// not the whole stream (on a shared stream another context may already have queued later work).  MSKF_WAIT=block parks
-// the thread instead of spinning.
+extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hipStream_t st);
+
 int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
-    if (!*ev_slot) MSKF_HIPCHK(hipEventCreateWithFlags(ev_slot, hipEventDisableTiming | (c->wait_block ? hipEventBlockingSync : 0)));
-    if (record) { MSKF_HIPCHK(hipEventRecord(*ev_slot, c->stream)); return MSKF_OK; }
-    MSKF_HIPCHK(hipEventSynchronize(*ev_slot));
+    if (c->wait_block) {
+        if (!*ev_slot) MSKF_HIPCHK(hipEventCreateWithFlags(ev_slot, hipEventDisableTiming | hipEventBlockingSync));
+        if (record) { MSKF_HIPCHK(hipEventRecord(*ev_slot, c->stream)); return MSKF_OK; }
+        MSKF_HIPCHK(hipEventSynchronize(*ev_slot));
+        return MSKF_OK;
+    }
+    if (!c->flag_h) {
+        unsigned int *p = nullptr;
+        MSKF_HIPCHK(hipHostMalloc((void **)&p, 8 * 64, hipHostMallocCoherent | hipHostMallocMapped));      // one cache line per slot
+        std::memset(p, 0, 8 * 64);
+        c->flag_h = p;
+    }
+    int k = 0;
+    while (k < 8 && c->flag_slot[k] && c->flag_slot[k] != ev_slot) ++k;
+    if (k == 8) { mskf_set_error("too many completion marks"); return MSKF_ERR_INVALID; }
+    c->flag_slot[k] = ev_slot;
+    volatile unsigned int *w = c->flag_h + 16 * k;
+    if (record) {
+        fe_launch_mark(w, ++c->flag_seq[k], c->stream);
+        MSKF_HIPCHK(hipGetLastError());
+        return MSKF_OK;
+    }
+    const unsigned int want = c->flag_seq[k];
+    while ((int)(__atomic_load_n((const unsigned int *)w, __ATOMIC_ACQUIRE) - want) < 0) __builtin_ia32_pause();
     return MSKF_OK;
 }
 int mskf_wait(mskf_ctx *c) {
@@ -395,8 +416,7 @@ static int cell_keys_ready(mskf_stream *s) {
     if (s->push_gen != s->ctx->push_gen) { mskf_set_error("cell maxima are stale: another push happened on this context"); return MSKF_ERR_INVALID; }
     // wait for the copy of this push's maxima only (not the whole stream: on a shared stream another context may have
     // queued later work); no ctx mutation here: callable concurrently for different streams
-    if (s->ctx->cell_ev) MSKF_HIPCHK(hipEventSynchronize(s->ctx->cell_ev));
-    return MSKF_OK;
+    return mskf_wait_event(s->ctx, &s->ctx->cell_ev, false);
 }
 
 extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out) {

@@ -65,8 +65,11 @@ struct mskf_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = true;          // false: created by mskf_ctx_create_shared on another context's stream
     PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
-    hipEvent_t wait_ev = nullptr;     // blocking-sync event of mskf_wait (MSKF_WAIT=block)
+    hipEvent_t wait_ev = nullptr;     // mark of mskf_wait
     bool wait_block = false;
+    volatile unsigned int *flag_h = nullptr;   // pinned host words the mark kernels write (spinning mode), one per mark slot
+    unsigned int flag_seq[8] = {0};
+    hipEvent_t *flag_slot[8] = {nullptr};
     PinnedDev<char> cell_arena;       // per-cell maximum keys of every stream of the last push batch (one D2H copy)
     PinnedDev<char> trk_in, trk_out;  // input points / results of every stream of a track batch (one copy each way)
     unsigned long long push_gen = 0;
@@ -92,7 +95,11 @@ struct mskf_ctx {
     } pend_upd;
     struct PendingPosVar { bool active = false; int n = 0; double *out = nullptr; size_t desc_bytes = 0; hipEvent_t done = nullptr; } pend_pv;
 };
-// wait for an event this context recorded (spinning, or parked with MSKF_WAIT=block)
+// Completion marks.  mskf_wait_event(c, slot, true) marks the point the context's stream has reached, (.., false) waits
+// for that mark.  Spinning mode (default): the mark is a sequence number a one-thread kernel writes into pinned host
+// memory, the wait spins on that word in user space (no HIP call inside the wait: hipEventSynchronize / hipStreamSynchronize
+// spinning in several threads at once slows every other thread's launches down, measured -25 %).  MSKF_WAIT=block: a
+// blocking-sync HIP event, the thread is parked.  `slot` identifies the mark (one per kind of pending batch).
 int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record);
 
 struct mskf_stream {

@@ -769,6 +769,16 @@ __global__ __launch_bounds__(64) void k_pt_geom(const FeStreamDev *streams, int 
     S.status[pt] = (uint8_t)(1 | (st ? 2 : 0));
 }
 
+// completion mark of the spinning wait (mskf_wait_event): one thread stores a sequence number into pinned host memory
+// once everything enqueued before it on the stream (the D2H copies included) is done
+__global__ void k_mark(volatile unsigned int *flag, unsigned int seq) {
+    *flag = seq;
+    __threadfence_system();
+}
+extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, st, flag, seq);
+}
+
 extern "C" void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st) {
     if (max_pts <= 0) return;
     const int gps = (max_pts + 3) / 4;
