@@ -11,7 +11,8 @@ void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_phiq(const EkfStreamDev *d, int n, int max_steps, hipStream_t st);
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
-void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, int max_clones, hipStream_t st);
+void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave, const int *work_small, int n_small, const int *work_big, int n_big,
+                         int max_rows, int max_rows_small, int wave_per_feature, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
@@ -460,6 +461,11 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
     int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0, max_na_bound = 0, max_tri = 0;
+    // size classes of the feature kernel and their work lists: [1] at most FEAT_SMALL_CLONES = 16 observations, [2] more;
+    // [0] is the whole batch when every feature has <= 4 observations (wave-per-feature variant)
+    int max_frows_cls[3] = {0, 0, 0}, max_init = 0;
+    std::vector<int> &cnt_cls = ctx->pend_upd.cnt_cls;          // [3][n]
+    cnt_cls.assign((size_t)3 * n, 0);
     bool all_pairs = true;     // every feature of the batch has exactly two Jacobian observations of ONE clone pair per stream
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, tri; int n_tri; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
@@ -485,6 +491,12 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
             m_total += 4 * f.n_obs - 3;
             max_frows = std::max(max_frows, 4 * f.n_obs);
+            if (f.needs_init) max_init = std::max(max_init, f.n_init);
+            {
+                const int cls_n = std::max(f.n_obs, f.needs_init ? f.n_init : 0), cls = cls_n <= 16 ? 1 : 2;
+                max_frows_cls[cls] = std::max(max_frows_cls[cls], 4 * f.n_obs);
+                ++cnt_cls[(size_t)cls * n + i];
+            }
             for (int o = 0; o < f.n_obs; ++o) {
                 const int c = a.obs_clone[f.obs_start + o];
                 if (c < 0 || c >= a.n_clones) return MSKF_ERR_INVALID;
@@ -530,12 +542,28 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         max_m = std::max(max_m, m_total);
         max_d = std::max(max_d, E.d);
     }
+    // work lists: stream << 16 | slot << 8 | n_slots per feature group in flight
+    const bool wave_per_feature = max_frows <= 16 && max_init <= 32;      // (TRI_SMALL_CLONES)
+    if (n > 0xffff) { mskf_set_error("too many streams in one update batch"); return MSKF_ERR_CAPACITY; }
+    int n_work[3] = {0, 0, 0};
+    if (wave_per_feature) for (int i = 0; i < n; ++i) { cnt_cls[i] += cnt_cls[(size_t)n + i] + cnt_cls[(size_t)2 * n + i]; cnt_cls[(size_t)n + i] = 0; cnt_cls[(size_t)2 * n + i] = 0; }
+    for (int c = 0; c < 3; ++c) for (int i = 0; i < n; ++i) n_work[c] += std::min(cnt_cls[(size_t)c * n + i], EKF_SLOTS);
+    const size_t work_off = in_bytes;
+    in_bytes = align_up(in_bytes + sizeof(int) * (size_t)(n_work[0] + n_work[1] + n_work[2]), 64);
     if (in_bytes > ctx->upd_in.cap || out_bytes > ctx->upd_out.cap) {
         MSKF_HIPCHK(hipStreamSynchronize(st));
         if ((rc = ctx->upd_in.ensure(in_bytes)) != MSKF_OK) return rc;
         if ((rc = ctx->upd_out.ensure(out_bytes)) != MSKF_OK) return rc;
     }
     char *hin = ctx->upd_in.h, *din = ctx->upd_in.d, *hout = ctx->upd_out.h, *dout = ctx->upd_out.d;
+    {
+        int *w = (int *)(hin + work_off);
+        for (int c = 0; c < 3; ++c)
+            for (int i = 0; i < n; ++i) {
+                const int ns = std::min(cnt_cls[(size_t)c * n + i], EKF_SLOTS);
+                for (int k = 0; k < ns; ++k) *w++ = (i << 16) | (k << 8) | ns;
+            }
+    }
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         mskf_ekf_update_args &a = args[i];
@@ -582,7 +610,11 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
         if (all_pairs) ekf_launch_pair_features(ctx->ekf_desc.d, n, max_feat, max_tri, st);      // the pruning update
-        else ekf_launch_features(ctx->ekf_desc.d, n, max_feat, max_frows, (max_d - 21) / 6, st);
+        else {
+            const int *w0 = (const int *)(din + work_off);
+            ekf_launch_features(ctx->ekf_desc.d, w0, n_work[0], w0 + n_work[0], n_work[1], w0 + n_work[0] + n_work[1], n_work[2], max_frows,
+                                max_frows_cls[1], wave_per_feature ? 1 : 0, st);
+        }
         mskf_t_end(ctx, ts, (long long)fl_feat);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);

@@ -91,6 +91,7 @@ struct mskf_ctx {
     struct PendingUpdate {
         bool active = false, launched = false; int n = 0; mskf_stream *const *streams = nullptr; mskf_ekf_update_args *args = nullptr;
         std::vector<size_t> lay;   // per stream: o_dx, o_gamma, o_rows, o_status, o_pos
+        std::vector<int> cnt_cls;              // scratch: features per size class of the feature kernel and stream, [3][n]
         hipEvent_t done = nullptr;
     } pend_upd;
     struct PendingPosVar { bool active = false; int n = 0; double *out = nullptr; size_t desc_bytes = 0; hipEvent_t done = nullptr; } pend_pv;

@@ -436,13 +436,29 @@ __device__ __forceinline__ size_t pk(int i, int j) { return (size_t)i * (i + 1) 
 // features per workgroup side by side, wave-level barriers only) for launches whose features all have <= MAXC = 4
 // observations in the Jacobian — the pruning update hands over hundreds of 2-observation features per stream, for
 // which the workgroup-wide barriers were the whole cost (~140 us per feature, measured).
-template <int MAXC, bool WAVE>
-__global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev *streams, int lds_rows, int arena_doubles) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    constexpr int GS = WAVE ? 64 : WG;          // threads per feature
-    constexpr int NSUB = WG / GS;               // features side by side in a workgroup
+// Size classes (TPB = threads of the workgroup): most lost features have few observations (84 % have <= 16 at the C2
+// shape), and for those every loop below is at most one wavefront wide: a 256-thread workgroup only adds barrier
+// latency and, with its LDS sized for the largest feature of the batch, leaves a CU with one or two features in flight.
+// The <16, false, 64> instantiation gives such a feature one wavefront in a 64-thread workgroup with <= 30 KiB of LDS
+// (five per CU, barriers at wave cost); a launch handles the features whose class max(n_obs, n_init) lies in
+// [cls_lo, cls_hi].
+// Work list: the grid is flat, one entry of `work` per feature group in flight = stream << 16 | slot << 8 | n_slots: the
+// group handles the class members of its stream whose ordinal is congruent to slot modulo n_slots (n_slots =
+// min(members, EKF_SLOTS), so the global gate scratch of a slot is never shared).  A (slots x streams) grid sized for
+// the stream with the most features launched mostly empty workgroups, each holding the full LDS allocation until it
+// found nothing to do: the 2 x 192 large features of a batch took 280 us that way.
+#define FEAT_SMALL_CLONES 16
+template <int MAXC, bool WAVE, int TPB>
+__global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDev *streams, const int *work, int n_work, int lds_rows, int arena_doubles, int cls_lo, int cls_hi) {
+    constexpr int GS = WAVE ? 64 : TPB;         // threads per feature
+    constexpr int NSUB = TPB / GS;              // features side by side in a workgroup
     const int gt = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int sub = WAVE ? (int)(threadIdx.x >> 6) : 0;
+    const int item = (int)blockIdx.x * NSUB + sub;
+    if (item >= n_work) return;                 // (WAVE: a whole wavefront; it shares no barrier with the others)
+    const int wcode = work[item];
+    const int w_slot = (wcode >> 8) & 0xff, w_nslots = wcode & 0xff;
+    const EkfStreamDev &S = streams[wcode >> 16];
     const int d = S.d, ld = S.ld;
     // Jacobian / reflector scratch, one block per feature in flight: it is dead once the gate matrix is reflected,
     // and the 16-wide Cholesky panel (LNB x PAN_RS doubles) of the workgroup variant reuses it
@@ -462,7 +478,8 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
     __shared__ int sCloneOfObs_all[NSUB][MAXC];
     extern __shared__ double s_arena_all[];
     double *s_arena = s_arena_all + (size_t)sub * arena_doubles;
-    typedef typename std::conditional<WAVE, TriScratchT<2 * TRI_SMALL_CLONES>, TriScratch>::type TriT;
+    typedef typename std::conditional<WAVE, TriScratchT<2 * TRI_SMALL_CLONES>,
+                                      typename std::conditional<(MAXC <= FEAT_SMALL_CLONES), TriScratchT<2 * MAXC>, TriScratch>::type>::type TriT;
     TriT &sTri = *reinterpret_cast<TriT *>(s_arena);
     __shared__ double sW_all[NSUB][4 * MAXC];
     __shared__ double sRo_all[NSUB][4 * MAXC];      // projected residual r_o (also written to global for the stacked system)
@@ -480,9 +497,22 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
     };
     auto gsum = [&](double v) { return WAVE ? wave_sum(v) : block_sum(v, sRed); };
 
-    for (int j = blockIdx.x * NSUB + sub; j < S.n_feat; j += gridDim.x * NSUB) {
-        GSYNC();
+    int ordinal = -1;
+    for (int j = 0; j < S.n_feat; ++j) {
         EkfFeatDev &F = S.feats[j];
+        {
+            const int cls = F.needs_init && F.n_init > F.n_obs ? F.n_init : F.n_obs;
+            if (cls < cls_lo || cls > cls_hi) continue;       // another launch's size class (uniform across the feature's threads)
+            if (++ordinal % w_nslots != w_slot) continue;     // another group's feature
+        }
+        GSYNC();
+#ifdef FEAT_DBG
+        long long tdbg[12]; int ndbg = 0;
+#define TDBG() do { if (ndbg < 12) tdbg[ndbg++] = wall_clock64(); } while (0)
+#else
+#define TDBG() do {} while (0)
+#endif
+        TDBG();
         const int M = F.n_obs, rows = 4 * M, n = rows - 3;
         double *Hrow0 = S.Hs + (size_t)F.row_off * ld;
         // ---- 1. position
@@ -503,6 +533,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             if (gt == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; F.colmask = 0ULL; }
             continue;
         }
+        TDBG();
         // ---- 2. per-observation Jacobians (msckf_vio.cpp:610-677)
         if (gt < M) {
             const int o = F.obs_start + gt;
@@ -559,6 +590,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             sr[4 * gt + 3] = z[3] - p_c1[1] / p_c1[2];
         }
         GSYNC();
+        TDBG();
         // ---- 3. three Householder reflectors of H_f (left null space, msckf_vio.cpp:757-766)
         for (int k = 0; k < 3; ++k) {
             double part = 0;
@@ -591,6 +623,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             if (gt == 0) { sVV[0] = a; sVV[1] = b; sVV[2] = c; }
         }
         GSYNC();
+        TDBG();
         // ---- 4. coefficients c_k of every compact column (6M Jacobian columns + the residual)
         for (int cc = gt; cc <= 6 * M; cc += GS) {
             double s1 = 0, s2 = 0, s3 = 0;
@@ -609,6 +642,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             sCoef[cc][0] = c1; sCoef[cc][1] = c2; sCoef[cc][2] = c3;
         }
         GSYNC();
+        TDBG();
         // ---- 5. write the projected block: rows 3..4M-1 of Q^T [H_xj | r_j], only the 6 M columns of the observed
         //         clones and the residual column (the rest of a row is never read: rowmask, k_ekf_cap)
         for (int i = 3 + (gt >> 6); i < rows; i += GS / 64) {       // one output row per wave pass, compact columns across lanes
@@ -627,10 +661,11 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             Hrow0[(size_t)(i - 3) * ld + d] = rv;   // column d of the stacked matrix carries the residual ([H | r])
         }
         GSYNC();
+        TDBG();
         // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
         // H = A^T H_xj with H_xj block diagonal (4x6 per observation), so H P H^T = A^T Mm A with
         // Mm[a][b] = H_a P_ab H_b^T (4x4 blocks from 6x6 blocks of P), and A^T . A = rows/cols 3.. of Q^T . Q.
-        double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)blockIdx.x * S.nmax * S.nmax);   // packed lower
+        double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)w_slot * S.nmax * S.nmax);   // packed lower
         const double *P = S.P;
         for (int pr = gt; pr < M * M; pr += GS) {
             const int a = pr / M, b = pr - a * M;
@@ -652,6 +687,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             }
         }
         GSYNC();
+        TDBG();
         // two-sided reflectors in one pass: Q = Q_1 Q_2 Q_3 = I - V T V^T (compact WY, T 3x3 upper triangular), so
         //   Q^T Mm Q = Mm - Z V^T - V Z^T,   Z = W T - 1/2 V (T^T G T),   W = Mm V,   G = V^T W
         // (Mm symmetric, lower stored; in LDS or, for features with more rows than fit, in the stream's global scratch).
@@ -711,6 +747,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
         // r_o rides along as an extra row (sW): after step k it holds y_k = (L^-1 r_o)_k, so gamma = y . y
         // needs no separate triangular solve.
 #define SG(i, j) Mm[pk((i) + 3, (j) + 3)]
+        TDBG();
         bool pd_ok = true;
         // workgroup variant: blocked factorisation (chol_block.h) whether the gate matrix sits in LDS or, for features
         // with more rows than fit, in the stream's global scratch (same code through a generic pointer)
@@ -721,7 +758,7 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             for (int i = gt; i < LNB * PAN_RS; i += GS) s_blk[i] = 0.0;            // panel buffer (scratch is dead)
             if (gt < 16) Mm[pk(rows, 3 + n) + gt] = 0.0;                          // readable slack behind the last row
             GSYNC();
-            chol_blocked_lds<WG / 64>(Mm, [](int i, int j) { return (int)pk(i + 3, j + 3); }, n, n + 1, 0.0, s_blk, PAN_RS, s_cb);
+            chol_blocked_lds<TPB / 64>(Mm, [](int i, int j) { return (int)pk(i + 3, j + 3); }, n, n + 1, 0.0, s_blk, PAN_RS, s_cb);
             int bad = 0;
             for (int i = gt; i < n; i += GS) { bad |= !(SG(i, i) > 0.0); sW[i] = SG(n, i); }
             pd_ok = !__syncthreads_or(bad);
@@ -747,6 +784,11 @@ __global__ __launch_bounds__(WG, 2) void k_ekf_feature_blocks(const EkfStreamDev
             }
         }
 #undef SG
+        TDBG();
+#ifdef FEAT_DBG
+        if (item == 0 && gt == 0) printf("feat M=%d TPB=%d: tri %lld jac %lld hh %lld coef %lld write %lld gateM %lld reflect %lld chol %lld\n", M, TPB,
+            (tdbg[1]-tdbg[0])*10, (tdbg[2]-tdbg[1])*10, (tdbg[3]-tdbg[2])*10, (tdbg[4]-tdbg[3])*10, (tdbg[5]-tdbg[4])*10, (tdbg[6]-tdbg[5])*10, (tdbg[7]-tdbg[6])*10, (tdbg[8]-tdbg[7])*10);
+#endif
         double gamma = 1e300;
         if (pd_ok) {
             GSYNC();
@@ -1077,28 +1119,40 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunc
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);
 }
-void ekf_launch_features(const EkfStreamDev *d, int n, int max_feat, int max_rows, int max_clones, hipStream_t st) {
+// work_small / work_big: the work lists of the two size classes (see the kernel); with wave_per_feature every feature of
+// the batch has <= 4 Jacobian observations and all of them are in work_wave
+void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave, const int *work_small, int n_small, const int *work_big, int n_big,
+                         int max_rows, int max_rows_small, int wave_per_feature, hipStream_t st) {
     const int packed_max = ((GATE_LDS_ROWS + 1) * (GATE_LDS_ROWS + 2) / 2 + 16) * (int)sizeof(double);   // + the r_o row + slack
     const int tri_doubles = (int)((sizeof(TriScratchT<2 * TRI_SMALL_CLONES>) + 7) / 8);
     static std::once_flag attr_once;
     std::call_once(attr_once, [=]() {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<MAX_CLONES_DEV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * tri_doubles * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<32, false, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<MAX_CLONES_DEV, false, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, packed_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<4, true, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * tri_doubles * 8);
     });
-    if (max_rows <= 16 && max_clones <= TRI_SMALL_CLONES) {
+    const int ALL = 1 << 30;
+    if (wave_per_feature) {
         // every feature has <= 4 Jacobian observations (and its triangulation fits the small scratch): one wavefront per feature, four per workgroup
-        const int groups = (max_feat + 3) / 4;
-        const int slots = groups < EKF_SLOTS ? (groups > 0 ? groups : 1) : EKF_SLOTS;
-        hipLaunchKernelGGL((k_ekf_feature_blocks<4, true>), dim3(slots, n), dim3(WG), (size_t)4 * tri_doubles * 8, st, d, 16, tri_doubles);
+        if (n_wave > 0)
+            hipLaunchKernelGGL((k_ekf_feature_blocks<4, true, WG>), dim3((n_wave + 3) / 4), dim3(WG), (size_t)4 * tri_doubles * 8, st, d, work_wave, n_wave, 16, tri_doubles, 0, ALL);
         return;
     }
-    const int slots = max_feat < EKF_SLOTS ? (max_feat > 0 ? max_feat : 1) : EKF_SLOTS;
+    // small class: features of at most FEAT_SMALL_CLONES observations (Jacobian and triangulation), one wavefront each.
+    // (A third class of <= 8 observations, 12 KiB of LDS and eight features per CU, was measured and dropped: every class
+    // launch is a single latency-bound round, so a further split only adds another round to the chain.)
+    if (n_small > 0) {
+        const int lr = max_rows_small;                                   // <= 4 * FEAT_SMALL_CLONES: always in LDS
+        size_t lds = ((size_t)(lr + 1) * (lr + 2) / 2 + 16) * sizeof(double);
+        if (lds < sizeof(TriScratchT<2 * FEAT_SMALL_CLONES>)) lds = sizeof(TriScratchT<2 * FEAT_SMALL_CLONES>);
+        hipLaunchKernelGGL((k_ekf_feature_blocks<FEAT_SMALL_CLONES, false, 64>), dim3(n_small), dim3(64), lds, st, d, work_small, n_small, lr, 0, 0, FEAT_SMALL_CLONES);
+    }
+    if (n_big <= 0) return;
     const int lds_rows = max_rows <= GATE_LDS_ROWS ? max_rows : GATE_LDS_ROWS;
     size_t lds = ((size_t)(lds_rows + 1) * (lds_rows + 2) / 2 + 16) * sizeof(double);
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
-    if (max_rows <= 4 * 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false>), dim3(slots, n), dim3(WG), lds, st, d, lds_rows, 0);
-    else hipLaunchKernelGGL((k_ekf_feature_blocks<MAX_CLONES_DEV, false>), dim3(slots, n), dim3(WG), lds, st, d, lds_rows, 0);
+    if (max_rows <= 4 * 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
+    else hipLaunchKernelGGL((k_ekf_feature_blocks<MAX_CLONES_DEV, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
 }
 // pruning update: every feature of every stream has exactly two Jacobian observations (the host checked)
 void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st) {

@@ -84,6 +84,8 @@ extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_d
 #define DTW 32                 // detector tile: 32 x 32 output pixels
 #define DTH 32
 #define DPW 40                 // gradient-product plane of a tile: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
+#define DPS 41                 // row stride of a product plane in LDS words: rows of the horizontal pass land in different banks
+#define DHS 33                 // row stride of a horizontal-sum plane (same reason)
 #define DET_SLOTS 64           // per-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
 #define DSW 48                 // staged bytes per row: image x in [tx0-8, tx0+40)
 #define DSH 42                 // staged rows:          image y in [ty0-5, ty0+37)
@@ -106,8 +108,8 @@ __device__ __forceinline__ unsigned int isqrt48(unsigned long long v, double vd)
 }
 
 struct DetLds {
-    int P[3][DPW * DPW];
-    int H[3][DPW * DTW];
+    int P[3][DPW * DPS];
+    int H[3][DPW * DHS];
     unsigned long long key[DET_SLOTS];
     int cx[DTW], cy[DTH];
 };
@@ -129,19 +131,20 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
         const uint8_t *t = t8 + (r + 1) * stride + (c + 4);
         const int dx = (int)t[1] - (int)t[-1];
         const int dy = (int)t[stride] - (int)t[-stride];
-        L.P[0][i] = dx * dx; L.P[1][i] = dx * dy; L.P[2][i] = dy * dy;
+        const int o = r * DPS + c;
+        L.P[0][o] = dx * dx; L.P[1][o] = dx * dy; L.P[2][o] = dy * dy;
     }
     __syncthreads();
     // ---- horizontal 8-sums: item = (plane, row, run of 8 outputs)
     for (int it = tid; it < 3 * DPW * (DTW / 8); it += 256) {
         const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
         const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
-        const int *src = L.P[pl] + r * DPW + 8 * q;
+        const int *src = L.P[pl] + r * DPS + 8 * q;
         int v[15];
 #pragma unroll
         for (int u = 0; u < 15; ++u) v[u] = src[u];
         int acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        int *dst = L.H[pl] + r * DTW + 8 * q;
+        int *dst = L.H[pl] + r * DHS + 8 * q;
         dst[0] = acc;
 #pragma unroll
         for (int u = 1; u < 8; ++u) { acc += v[u + 7] - v[u - 1]; dst[u] = acc; }
@@ -156,7 +159,7 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
             int v0[11], v1[11], v2[11];
 #pragma unroll
             for (int u = 0; u < 11; ++u) {
-                const int o = (4 * q + u) * DTW + c;
+                const int o = (4 * q + u) * DHS + c;
                 v0[u] = L.H[0][o]; v1[u] = L.H[1][o]; v2[u] = L.H[2][o];
             }
             int a = 0, b = 0, d = 0;
@@ -426,8 +429,22 @@ typedef short l4_v2s __attribute__((ext_vector_type(2)));
 #define L4_MAXOX 8             // window column offset inside the staged rows: 0 .. 8
 #define L4_MAXOY (L4_SROWS - 16)
 
-__device__ __forceinline__ int l4_dot2(int pair, int w, int acc) {
+typedef unsigned short l4_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int l4_dot2(int pair, int w, int acc) {          // running sums: acc is the destination (v_dot2c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(l4_v2s, pair), __builtin_bit_cast(l4_v2s, w), acc, false);
+}
+// Same product with a CONSTANT addend.  The two-operand form above needs the addend in the destination register, i.e. a
+// v_mov per call when it is a constant (47 of the 270 instructions of an LK iteration were such moves); with the clamp
+// bit set the compiler has to take the three-operand encoding, whose addend is an inline constant or a scalar register.
+// Saturation never triggers here (|sums| < 2^23), so the value is the same.
+__device__ __forceinline__ int l4_dot2k(int pair, int w, int k) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(l4_v2s, pair), __builtin_bit_cast(l4_v2s, w), k, true);
+}
+// ((a >> 9), (b >> 9)) as two 16-bit lanes for 0 <= a, b < 2^24: one byte permute takes bits 8..23 of both, one packed
+// shift drops the ninth bit (three instructions fewer per pair than shift, shift, pack)
+__device__ __forceinline__ int l4_pack_shr9(int a, int b) {
+    const l4_v2u v = __builtin_bit_cast(l4_v2u, __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x06050201u));
+    return __builtin_bit_cast(int, (l4_v2u)(v >> (unsigned short)1));
 }
 // DPP row operations (a row = the 16 lanes of one point).  row_shl:n: lane i reads lane i + n, row_shr:n: lane i - n.
 #define L4_SHL1 0x101
@@ -442,11 +459,11 @@ __device__ __forceinline__ long long l4_row_sum(int v) {
     v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
     long long s = (long long)v;
     {
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)s, 0x141, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)(s >> 32), 0x141, 0xf, 0xf, false);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)s, 0x141, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, (int)(s >> 32), 0x141, 0xf, 0xf, true);
         s += (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);     // row_half_mirror
     }
     {
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)s, 0x140, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)(s >> 32), 0x140, 0xf, 0xf, false);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)s, 0x140, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, (int)(s >> 32), 0x140, 0xf, 0xf, true);
         s += (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);     // row_mirror
     }
     return s;
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
             L4Pairs<17>::run(a, pr);
             int Bv[17];
 #pragma unroll
-            for (int c = 0; c < 17; ++c) { V[c] = l4_dot2(pr[c], wtop, 256); Bv[c] = l4_dot2(pr[c], wbot, 0); }
+            for (int c = 0; c < 17; ++c) { V[c] = l4_dot2k(pr[c], wtop, 256); Bv[c] = l4_dot2k(pr[c], wbot, 0); }
             // extra row: source row 0 for lane 0 (top weights, added to its own B), source row 17 for lane 15 (bottom
             // weights, added to its own T)
             const uint32_t *ep = sT + (r == 0 ? 0 : 17) * L4_DW;
@@ -610,20 +627,24 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
                 const int dn = l4_dpp0<L4_SHL1>(V[c]);
                 f[c] = up + dn; e[c] = dn - up;
             }
+            // 24-bit multiply-adds (all terms are below 2^19): the 32-bit integer multiply issues at quarter rate
             int gx[16], gy[16], pv[16];
 #pragma unroll
             for (int i = 0; i < 15; ++i) {
-                const int sx = 3 * (f[i + 2] - f[i]) + 10 * (V[i + 2] - V[i]);
-                const int sy = 3 * (e[i] + e[i + 2]) + 10 * e[i + 1];
-                gx[i] = winrow ? (sx + 16) >> 5 : 0;
-                gy[i] = winrow ? (sy + 16) >> 5 : 0;
+                const int sx = __mul24(10, V[i + 2] - V[i]) + (__mul24(3, f[i + 2] - f[i]) + 16);
+                const int sy = __mul24(10, e[i + 1]) + (__mul24(3, e[i] + e[i + 2]) + 16);
+                gx[i] = sx >> 5;
+                gy[i] = sy >> 5;
                 pv[i] = V[i + 1];
             }
             gx[15] = 0; gy[15] = 0; pv[15] = 0;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                Ixp[m] = (int)__builtin_amdgcn_perm((uint32_t)gx[2 * m + 1], (uint32_t)gx[2 * m], 0x05040100u);
-                Iyp[m] = (int)__builtin_amdgcn_perm((uint32_t)gy[2 * m + 1], (uint32_t)gy[2 * m], 0x05040100u);
+                // lane 15 is no window row: its gradients are zero, so its pixels drop out of every sum
+                const int ix = (int)__builtin_amdgcn_perm((uint32_t)gx[2 * m + 1], (uint32_t)gx[2 * m], 0x05040100u);
+                const int iy = (int)__builtin_amdgcn_perm((uint32_t)gy[2 * m + 1], (uint32_t)gy[2 * m], 0x05040100u);
+                Ixp[m] = winrow ? ix : 0;
+                Iyp[m] = winrow ? iy : 0;
                 Pp[m] = (int)__builtin_amdgcn_perm((uint32_t)pv[2 * m + 1], (uint32_t)pv[2 * m], 0x05040100u);
                 A11 = l4_dot2(Ixp[m], Ixp[m], A11); A12 = l4_dot2(Ixp[m], Iyp[m], A12); A22 = l4_dot2(Iyp[m], Iyp[m], A22);
             }
@@ -667,17 +688,17 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
             for (int i = 0; i < 4; ++i) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], ox & 3);
             int pr[15];
             L4Pairs<15>::run(a, pr);
-            int sv[16];
+            int sv[16];                                      // 512 x the bilinear sample (< 2^23, positive)
 #pragma unroll
             for (int k = 0; k < 15; ++k) {
-                const int t = l4_dot2(pr[k], wt, 256), b = l4_dot2(pr[k], wb, 0);
-                sv[k] = (t + l4_dpp0<L4_SHL1>(b)) >> 9;
+                const int t = l4_dot2k(pr[k], wt, 256), b = l4_dot2k(pr[k], wb, 0);
+                sv[k] = t + l4_dpp0<L4_SHL1>(b);
             }
             sv[15] = 0;
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const l4_v2s sp = __builtin_bit_cast(l4_v2s, (int)__builtin_amdgcn_perm((uint32_t)sv[2 * m + 1], (uint32_t)sv[2 * m], 0x05040100u));
+                const l4_v2s sp = __builtin_bit_cast(l4_v2s, l4_pack_shr9(sv[2 * m], sv[2 * m + 1]));
                 const int df = __builtin_bit_cast(int, (l4_v2s)(sp - __builtin_bit_cast(l4_v2s, Pp[m])));
                 b1 = l4_dot2(df, Ixp[m], b1);            // masked pixels carry Ix = Iy = 0
                 b2 = l4_dot2(df, Iyp[m], b2);
