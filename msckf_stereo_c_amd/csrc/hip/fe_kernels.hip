@@ -430,6 +430,28 @@ typedef short l4_v2s __attribute__((ext_vector_type(2)));
 #define L4_MAXOY (L4_SROWS - 16)
 
 typedef unsigned short l4_v2u __attribute__((ext_vector_type(2)));
+// a * b + c on the 24-bit multiplier (full rate; exact while |a|, |b| < 2^23).  The compiler lowers the C expression to
+// separate multiplies and a three-operand add, or to the quarter-rate 32 x 32 -> 64 bit multiply-add.
+template <int KA, int KC> __device__ __forceinline__ int l4_mad24_k(int x) {        // KA * x + KC, inline constants
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "n"(KA), "v"(x), "n"(KC));
+    return d;
+}
+template <int KA> __device__ __forceinline__ int l4_mad24_kv(int x, int c) {        // KA * x + c
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "n"(KA), "v"(x), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int l4_mad24(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ int l4_mad24_vvv(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ int l4_dot2(int pair, int w, int acc) {          // running sums: acc is the destination (v_dot2c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(l4_v2s, pair), __builtin_bit_cast(l4_v2s, w), acc, false);
 }
@@ -483,9 +505,9 @@ __device__ __forceinline__ void l4_stage(const uint8_t *img, int w, int h, int x
         v[i] = 0;
         if (on && e < N) {
             const int row = (e * 43) >> 8, c = e - L4_DW * row;       // e / 6 for e < 128
-            if (fast) v[i] = *(const u32u *)(img + (size_t)(y0 + row) * w + x0 + 4 * c);
+            if (fast) v[i] = *(const u32u *)(img + l4_mad24_vvv(y0 + row, w, x0 + 4 * c));      // (a level is far below 2^31 bytes)
             else {
-                const uint8_t *rp = img + (size_t)min(max(y0 + row, 0), h - 1) * w;
+                const uint8_t *rp = img + l4_mad24_vvv(min(max(y0 + row, 0), h - 1), w, 0);
                 const int xb = x0 + 4 * c;
                 v[i] = (uint32_t)rp[min(max(xb, 0), w - 1)] | ((uint32_t)rp[min(max(xb + 1, 0), w - 1)] << 8) |
                        ((uint32_t)rp[min(max(xb + 2, 0), w - 1)] << 16) | ((uint32_t)rp[min(max(xb + 3, 0), w - 1)] << 24);
@@ -511,9 +533,10 @@ template <int N> struct L4Pairs<N, N> { static __device__ __forceinline__ void r
 
 __device__ __forceinline__ void l4_weights(float fa, float fb, int &wtop, int &wbot) {
     const int qa = __float2int_rn(fa * 16384.0f), qb = __float2int_rn(fb * 16384.0f);
-    const int w00 = ((16384 - qa) * (16384 - qb) + 8192) >> 14;
-    const int w01 = (qa * (16384 - qb) + 8192) >> 14;
-    const int w10 = ((16384 - qa) * qb + 8192) >> 14;
+    // (operands <= 2^14: 24-bit multiply-adds; the 32 x 32 -> 64 bit form the compiler picks otherwise is quarter rate)
+    const int w00 = l4_mad24(16384 - qa, 16384 - qb, 8192) >> 14;
+    const int w01 = l4_mad24(qa, 16384 - qb, 8192) >> 14;
+    const int w10 = l4_mad24(16384 - qa, qb, 8192) >> 14;
     const int w11 = 16384 - w00 - w01 - w10;                    // may be -1: kept signed in its 16-bit lane
     wtop = (w00 & 0xffff) | (w01 << 16);
     wbot = (w10 & 0xffff) | (w11 << 16);
@@ -631,8 +654,8 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
             int gx[16], gy[16], pv[16];
 #pragma unroll
             for (int i = 0; i < 15; ++i) {
-                const int sx = __mul24(10, V[i + 2] - V[i]) + (__mul24(3, f[i + 2] - f[i]) + 16);
-                const int sy = __mul24(10, e[i + 1]) + (__mul24(3, e[i] + e[i + 2]) + 16);
+                const int sx = l4_mad24_kv<10>(V[i + 2] - V[i], l4_mad24_k<3, 16>(f[i + 2] - f[i]));
+                const int sy = l4_mad24_kv<10>(e[i + 1], l4_mad24_k<3, 16>(e[i] + e[i + 2]));
                 gx[i] = sx >> 5;
                 gy[i] = sy >> 5;
                 pv[i] = V[i + 1];
@@ -681,7 +704,7 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
             int wt, wb;
             l4_weights(wx - (float)inx, wy - (float)iny, wt, wb);
             uint32_t d[5], a[4];
-            const uint32_t *rp = sS + (oy + r) * L4_DW + (ox >> 2);
+            const uint32_t *rp = sS + l4_mad24_kv<L4_DW>(oy + r, ox >> 2);
 #pragma unroll
             for (int i = 0; i < 5; ++i) d[i] = rp[i];
 #pragma unroll
