@@ -93,7 +93,17 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
     c->flag_slot[k] = ev_slot;
     volatile unsigned int *w = c->flag_h + 16 * k;
     if (record) {
-        fe_launch_mark(w, ++c->flag_seq[k], c->stream);
+        // the mark is a stream write-value command (no dispatch: a one-thread kernel waits 37 us for a CU slot on a busy
+        // device, profiles/r02_kernel_stats.csv of the kernel-mark build); MSKF_MARK=kernel, or a runtime that refuses the
+        // command on pinned host memory, falls back to the one-thread kernel k_mark
+        static bool use_write = [] { const char *e = std::getenv("MSKF_MARK"); return !(e && e[0] == 'k'); }();
+        ++c->flag_seq[k];
+        if (use_write) {
+            if (hipStreamWriteValue32(c->stream, (void *)w, c->flag_seq[k], 0) == hipSuccess) return MSKF_OK;
+            (void)hipGetLastError();
+            use_write = false;
+        }
+        fe_launch_mark(w, c->flag_seq[k], c->stream);
         MSKF_HIPCHK(hipGetLastError());
         return MSKF_OK;
     }

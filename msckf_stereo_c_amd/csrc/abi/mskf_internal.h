@@ -97,8 +97,8 @@ struct mskf_ctx {
     struct PendingPosVar { bool active = false; int n = 0; double *out = nullptr; size_t desc_bytes = 0; hipEvent_t done = nullptr; } pend_pv;
 };
 // Completion marks.  mskf_wait_event(c, slot, true) marks the point the context's stream has reached, (.., false) waits
-// for that mark.  Spinning mode (default): the mark is a sequence number a one-thread kernel writes into pinned host
-// memory, the wait spins on that word in user space (no HIP call inside the wait: hipEventSynchronize / hipStreamSynchronize
+// for that mark.  Spinning mode (default): the mark is a sequence number written into pinned host memory by a stream
+// write-value command (or a one-thread kernel), the wait spins on that word in user space (no HIP call inside the wait: hipEventSynchronize / hipStreamSynchronize
 // spinning in several threads at once slows every other thread's launches down, measured -25 %).  MSKF_WAIT=block: a
 // blocking-sync HIP event, the thread is parked.  `slot` identifies the mark (one per kind of pending batch).
 int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record);
