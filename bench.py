@@ -381,7 +381,10 @@ def main(argv=None):
     pipe = not args.no_pipeline
     run.run(0, args.prime, pipelined=pipe)                       # untimed: gravity/bias init, clone window fills, group offsets
     run.run(args.prime, args.warmup, pipelined=pipe)             # W untimed warmup steps
-    run.set_timing(not os.environ.get("MSKF_BENCH_NO_KERNEL_TIMING"))
+    # per-kernel HIP events on every 5th launch of a kind (5 is coprime to the launches per step of every kind, so all of a
+    # step's launches are sampled in turn); MSKF_BENCH_TIMING_PERIOD=1 times every launch, MSKF_BENCH_NO_KERNEL_TIMING=1 none
+    timing_period = 0 if os.environ.get("MSKF_BENCH_NO_KERNEL_TIMING") else int(os.environ.get("MSKF_BENCH_TIMING_PERIOD", "5"))
+    run.set_timing(timing_period)
     run.get_timing(reset=True)
     run.get_phases(reset=True)
     run.get_abi_host_time(reset=True)
@@ -466,7 +469,7 @@ def main(argv=None):
                        "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": run.num_tsqr_updates(0),
                        "ekf_uncompressed_updates_stream0": run.num_uncompressed_updates(0),
                        "ekf_rows_per_update_stream0": round(run.stacked_rows(0) / max(n_upd, 1), 1),
-                       "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1),
+                       "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1), "kernel_timing_period": timing_period,
                        "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},

@@ -126,6 +126,7 @@ extern "C" int mskf_ctx_sync(mskf_ctx *c) {
 
 int mskf_t_begin(mskf_ctx *c, int kind) {
     if (!c->timing) return -1;
+    if ((c->t_all[kind]++ % c->timing_period) != 0) return -1;      // sampled: the events themselves cost device and host time
     TimingSlot t;
     if (!c->t_pool.empty()) { t.a = c->t_pool.back().first; t.b = c->t_pool.back().second; c->t_pool.pop_back(); }
     else {
@@ -158,6 +159,7 @@ extern "C" int mskf_ctx_set_timing(mskf_ctx *c, int enable) {
     MSKF_HIPCHK(hipStreamSynchronize(c->stream));
     mskf_t_collect(c);
     c->timing = enable != 0;
+    c->timing_period = enable > 1 ? enable : 1;
     return MSKF_OK;
 }
 
@@ -167,8 +169,10 @@ extern "C" int mskf_ctx_get_timing(mskf_ctx *c, double *ms, long long *launches,
     MSKF_HIPCHK(hipStreamSynchronize(c->stream));
     mskf_t_collect(c);
     for (int k = 0; k < MSKF_K_COUNT; ++k) {
-        ms[k] = c->t_ms[k]; launches[k] = c->t_launches[k]; units[k] = c->t_units[k];
-        if (reset) { c->t_ms[k] = 0; c->t_launches[k] = 0; c->t_units[k] = 0; }
+        // sampled timing: the sums are scaled from the timed launches to all launches of the kind
+        const double sc = c->t_launches[k] > 0 ? (double)c->t_all[k] / (double)c->t_launches[k] : 0.0;
+        ms[k] = c->t_ms[k] * sc; launches[k] = c->t_launches[k] > 0 ? c->t_all[k] : 0; units[k] = (long long)((double)c->t_units[k] * sc);
+        if (reset) { c->t_ms[k] = 0; c->t_launches[k] = 0; c->t_units[k] = 0; c->t_all[k] = 0; }
     }
     return MSKF_OK;
 }

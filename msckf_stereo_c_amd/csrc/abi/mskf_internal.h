@@ -56,6 +56,8 @@ struct TimingSlot { hipEvent_t a, b; int kind; long long units; };
 
 struct mskf_ctx {
     bool timing = false;
+    int timing_period = 1;                       // every n-th launch of a kind is timed (mskf_ctx_set_timing)
+    long long t_all[MSKF_K_COUNT] = {0};         // launches of a kind since the last reset, timed or not
     double host_s[4] = {0, 0, 0, 0};   // host seconds inside the batched entry points: [0] update pack, [1] update unpack, [2] track pack, [3] track unpack
     std::vector<TimingSlot> t_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pool;
