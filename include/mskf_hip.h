@@ -100,12 +100,17 @@ int mskf_fe_push_stereo_device(mskf_stream *s, const uint8_t *d_cam0, const uint
 int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
                               const uint8_t *const *cam1, int on_device);
 
-/* All det_rows*det_cols per-cell maxima of the last pushed cam0 image (score 0 = no corner). Synchronises. */
+/* Detector floor of a stream, in score units (1/256 of the response): from the next push on only per-cell maxima ABOVE the
+ * floor are recorded (default 0: every cell with a positive score).  A caller that only ever asks for the candidates above
+ * its detector threshold (image_processor.cpp:132: fast_threshold) sets the floor to that threshold: the comparison is made
+ * exactly, before the integer square root of the Shi-Tomasi score, which most pixels then never need. */
+int mskf_fe_set_detect_floor(mskf_stream *s, int min_score);
+/* All det_rows*det_cols per-cell maxima of the last pushed cam0 image (score 0 = no corner above the floor). Synchronises. */
 int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out);
 /* Same, restricted to the cells whose maximum score exceeds min_score (the detector threshold of
  * image_processor.cpp:132, in 1/256 units), in cell order; out[k].cell identifies the cell.  This is what
  * detect_features() needs — converting and copying the ~1400 sub-threshold cells of a 752x480 frame was a
- * measurable share of the host time per frame. */
+ * measurable share of the host time per frame.  min_score must not be below the stream's detector floor. */
 int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_corner *out, int capacity, int *n_out);
 
 typedef struct mskf_fe_track_args {

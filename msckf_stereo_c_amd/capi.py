@@ -42,7 +42,7 @@ class EkfUpdateArgs(C.Structure):
 EXPORTS = [
     "mskf_last_error", "mskf_abi_version", "mskf_ctx_create", "mskf_ctx_create_prio", "mskf_ctx_create_shared", "mskf_ctx_destroy", "mskf_ctx_sync", "mskf_ctx_hip_stream",
     "mskf_stream_create", "mskf_stream_destroy", "mskf_fe_push_stereo", "mskf_fe_push_stereo_device",
-    "mskf_fe_push_stereo_batch", "mskf_fe_get_cell_maxima", "mskf_fe_get_cell_candidates", "mskf_fe_track", "mskf_fe_track_batch", "mskf_fe_swap",
+    "mskf_fe_push_stereo_batch", "mskf_fe_set_detect_floor", "mskf_fe_get_cell_maxima", "mskf_fe_get_cell_candidates", "mskf_fe_track", "mskf_fe_track_batch", "mskf_fe_swap",
     "mskf_fe_get_level", "mskf_ekf_reset", "mskf_ekf_propagate", "mskf_ekf_augment", "mskf_ekf_update",
     "mskf_ekf_update_batch", "mskf_ekf_remove_clone", "mskf_ekf_remove_clones_batch", "mskf_ekf_predict_batch", "mskf_ekf_propagate_imu",
     "mskf_ekf_get_pos_var", "mskf_ekf_get_pos_var_batch", "mskf_ctx_set_timing", "mskf_ctx_get_timing", "mskf_stream_ctx",
@@ -147,6 +147,9 @@ class Stream:
             assert cam0.shape[1] == pitch and cam1.shape == cam0.shape
             w = self.calib.width
         _chk(self.L.mskf_fe_push_stereo(self.h, _p(cam0), _p(cam1), w, h, w if pitch is None else pitch, t))
+
+    def set_detect_floor(self, min_score):
+        _chk(self.L.mskf_fe_set_detect_floor(self.h, int(min_score)))
 
     def cell_maxima(self):
         n = self.fe_cfg.det_rows * self.fe_cfg.det_cols

@@ -290,6 +290,7 @@ static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
     std::memcpy(d.E, s->E, sizeof(d.E));
     d.epi_thresh = s->epi_thresh;
     d.det_rows = s->fe.det_rows; d.det_cols = s->fe.det_cols; d.cell_w = s->det_cw; d.cell_h = s->det_ch;
+    d.det_floor = s->det_floor;
     d.cell_keys = (unsigned long long *)(s->ctx->cell_arena.d + s->cell_off);
 }
 
@@ -433,6 +434,12 @@ static int cell_keys_ready(mskf_stream *s) {
     return mskf_wait_event(s->ctx, &s->ctx->cell_ev, false);
 }
 
+extern "C" int mskf_fe_set_detect_floor(mskf_stream *s, int min_score) {
+    if (!s || min_score < 0 || min_score >= (1 << 24)) return MSKF_ERR_INVALID;
+    s->det_floor = min_score;           // takes effect with the next push
+    return MSKF_OK;
+}
+
 extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int capacity, int *n_out) {
     if (!s || !out || !n_out) return MSKF_ERR_INVALID;
     const int n = s->fe.det_rows * s->fe.det_cols;
@@ -448,6 +455,7 @@ extern "C" int mskf_fe_get_cell_maxima(mskf_stream *s, mskf_corner *out, int cap
 extern "C" int mskf_fe_get_cell_candidates(mskf_stream *s, int min_score, mskf_corner *out, int capacity, int *n_out) {
     if (!s || !out || !n_out) return MSKF_ERR_INVALID;
     const int n = s->fe.det_rows * s->fe.det_cols;
+    if (min_score < s->det_floor) { mskf_set_error("min_score is below the stream's detector floor (mskf_fe_set_detect_floor)"); return MSKF_ERR_INVALID; }
     const int rc = cell_keys_ready(s);
     if (rc != MSKF_OK) return rc;
     const unsigned long long *keys = (const unsigned long long *)(s->ctx->cell_arena.h + s->cell_off);

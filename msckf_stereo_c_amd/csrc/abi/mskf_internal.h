@@ -126,6 +126,7 @@ struct mskf_stream {
     CamDev cam0, cam1;
     double R01[9], E[9], epi_thresh = 0;
     int det_cw = 0, det_ch = 0;
+    int det_floor = 0;                // mskf_fe_set_detect_floor
     double time_stamp = 0;
     // ---- EKF
     EkfStreamState ekf_state;

@@ -36,5 +36,6 @@ struct FeStreamDev {
     uint8_t *status;              // bit0: temporal track ok (incl. bounds), bit1: stereo inlier
     // detector
     int det_rows, det_cols, cell_w, cell_h;
+    int det_floor;                 // only scores above this are recorded (mskf_fe_set_detect_floor; 0 = every positive score)
     unsigned long long *cell_keys; // det_rows*det_cols per-cell maxima of curr0 level 0 as keys score<<32 | ~order (0 = none)
 };

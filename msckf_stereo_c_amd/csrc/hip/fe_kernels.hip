@@ -84,8 +84,7 @@ extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_d
 #define DTW 32                 // detector tile: 32 x 32 output pixels
 #define DTH 32
 #define DPW 40                 // gradient-product plane of a tile: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
-#define DPS 41                 // row stride of a product plane in LDS words: rows of the horizontal pass land in different banks
-#define DHS 33                 // row stride of a horizontal-sum plane (same reason)
+#define DPS 41                 // row stride of a product plane in LDS words: the rows a half-wave touches in the horizontal pass land in different banks
 #define DET_SLOTS 64           // per-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
 #define DSW 48                 // staged bytes per row: image x in [tx0-8, tx0+40)
 #define DSH 42                 // staged rows:          image y in [ty0-5, ty0+37)
@@ -108,8 +107,7 @@ __device__ __forceinline__ unsigned int isqrt48(unsigned long long v, double vd)
 }
 
 struct DetLds {
-    int P[3][DPW * DPS];
-    int H[3][DPW * DHS];
+    int P[3][DPW * DPS];           // gradient products, then (in place) their horizontal 8-sums
     unsigned long long key[DET_SLOTS];
     int cx[DTW], cy[DTH];
 };
@@ -125,29 +123,60 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
     if (tid < DTW) L.cx[tid] = (tx0 + tid) / cw;
     else if (tid < DTW + DTH) L.cy[tid - DTW] = (ty0 + tid - DTW) / ch;
     if (tid < DET_SLOTS) L.key[tid] = 0ULL;
-    // ---- gradient products at image (ty0-4+r, tx0-4+c): staged position (r+1, c+4)
-    for (int i = tid; i < DPW * DPW; i += 256) {
-        const int r = i / DPW, c = i - r * DPW;
-        const uint8_t *t = t8 + (r + 1) * stride + (c + 4);
-        const int dx = (int)t[1] - (int)t[-1];
-        const int dy = (int)t[stride] - (int)t[-stride];
-        const int o = r * DPS + c;
-        L.P[0][o] = dx * dx; L.P[1][o] = dx * dy; L.P[2][o] = dy * dy;
+    // ---- gradient products at image (ty0-4+r, tx0-4+c): staged position (r+1, c+4).  Item = (row, four pixels): five dword
+    //      reads (the row's bytes c+3 .. c+8, the dwords above and below) instead of sixteen byte reads.  `stride` is DSW.
+    {
+        const uint32_t *t32 = (const uint32_t *)t8;
+        constexpr int SW = DSW / 4;
+        for (int it = tid; it < DPW * (DPW / 4); it += 256) {
+            const int r = it / (DPW / 4), k = it - r * (DPW / 4);
+            const uint32_t *row = t32 + (r + 1) * SW + k;
+            const uint32_t m0 = row[0], m1 = row[1], m2 = row[2], up = row[1 - SW], dn = row[1 + SW];
+            // bytes c+3 .. c+8 of the row: b[0] = m0 >> 24, b[1..4] = m1, b[5] = m2 & 255
+            const int b0 = (int)(m0 >> 24), b1 = (int)(m1 & 255u), b2 = (int)((m1 >> 8) & 255u), b3 = (int)((m1 >> 16) & 255u),
+                      b4 = (int)(m1 >> 24), b5 = (int)(m2 & 255u);
+            const int dx[4] = {b2 - b0, b3 - b1, b4 - b2, b5 - b3};
+            int *p0 = L.P[0] + r * DPS + 4 * k, *p1 = L.P[1] + r * DPS + 4 * k, *p2 = L.P[2] + r * DPS + 4 * k;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dy = (int)((dn >> (8 * j)) & 255u) - (int)((up >> (8 * j)) & 255u);
+                p0[j] = dx[j] * dx[j]; p1[j] = dx[j] * dy; p2[j] = dy * dy;
+            }
+        }
     }
     __syncthreads();
-    // ---- horizontal 8-sums: item = (plane, row, run of 8 outputs)
-    for (int it = tid; it < 3 * DPW * (DTW / 8); it += 256) {
-        const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
-        const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
-        const int *src = L.P[pl] + r * DPS + 8 * q;
-        int v[15];
+    // ---- horizontal 8-sums: item = (plane, row, run of 8 outputs), IN PLACE over the product planes (the sums of a row
+    //      overwrite its first 32 products): every item first takes its 15 products into registers, the workgroup syncs,
+    //      then the sums are written.  Without a second set of planes a workgroup needs 22 KB of LDS instead of 38 KB:
+    //      seven per CU instead of four, and the kernel is bound by latency (three barrier-separated passes).
+    {
+        constexpr int ITEMS = 3 * DPW * (DTW / 8);          // 480: at most two per thread
+        int v[2][15];
 #pragma unroll
-        for (int u = 0; u < 15; ++u) v[u] = src[u];
-        int acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        int *dst = L.H[pl] + r * DHS + 8 * q;
-        dst[0] = acc;
+        for (int k = 0; k < 2; ++k) {
+            const int it = tid + 256 * k;
+            if (it < ITEMS) {
+                const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
+                const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
+                const int *src = L.P[pl] + r * DPS + 8 * q;
 #pragma unroll
-        for (int u = 1; u < 8; ++u) { acc += v[u + 7] - v[u - 1]; dst[u] = acc; }
+                for (int u = 0; u < 15; ++u) v[k][u] = src[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int it = tid + 256 * k;
+            if (it < ITEMS) {
+                const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
+                const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
+                int acc = ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
+                int *dst = L.P[pl] + r * DPS + 8 * q;
+                dst[0] = acc;
+#pragma unroll
+                for (int u = 1; u < 8; ++u) { acc += v[k][u + 7] - v[k][u - 1]; dst[u] = acc; }
+            }
+        }
     }
     __syncthreads();
     // ---- vertical 8-sums + score: thread = (column c, run of 4 rows)
@@ -159,8 +188,8 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
             int v0[11], v1[11], v2[11];
 #pragma unroll
             for (int u = 0; u < 11; ++u) {
-                const int o = (4 * q + u) * DHS + c;
-                v0[u] = L.H[0][o]; v1[u] = L.H[1][o]; v2[u] = L.H[2][o];
+                const int o = (4 * q + u) * DPS + c;
+                v0[u] = L.P[0][o]; v1[u] = L.P[1][o]; v2[u] = L.P[2][o];
             }
             int a = 0, b = 0, d = 0;
 #pragma unroll
@@ -185,10 +214,14 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
             if (!x_ok || y < DET_BORDER || y >= H - DET_BORDER) continue;
             const int a = sa[u], b = sb[u], d = sc[u];
             const int df = a - d;
-            const long long disc = (long long)df * df + 4LL * ((long long)b * b);
+            // score = (a + d) - isqrt(disc) > floor  <=>  isqrt(disc) < X := a + d - floor  <=>  disc < X^2 (X > 0): decided
+            // exactly in doubles (everything is below 2^50) before the square root, which most pixels then never need
+            const int X = (a + d) - S.det_floor;
+            if (X <= 0) continue;
             const double discd = (double)df * (double)df + 4.0 * ((double)b * (double)b);   // exact: < 2^48
+            if (discd >= (double)X * (double)X) continue;
+            const long long disc = (long long)df * df + 4LL * ((long long)b * b);
             const int score = (a + d) - (int)isqrt48((unsigned long long)disc, discd);
-            if (score <= 0) continue;
             const int cy = L.cy[4 * q + u];
             const int cell = cy * S.det_cols + cx;
             const unsigned int order = (unsigned int)((y - cy * ch) * cw + (x - cx * cw));

@@ -150,6 +150,7 @@ void ImageProcessor::stereoCallback(const cg::Image &cam0_img, const cg::Image &
         if (rc == MSKF_OK) rc = mskf_stream_create(own_ctx_, &calib_, &cfg_, &e, &stream_);
         if (rc != MSKF_OK) { fail("mskf_stream_create", rc); return; }
         own_stream_ = true;
+        mskf_fe_set_detect_floor(stream_, cfg_.fast_threshold * 256);
     }
     phaseBegin(cam0_img.time_stamp, w, h);
     int rc = mskf_fe_push_stereo(stream_, cam0_img.image.data(), cam1_img.image.data(), w, h, w, cam0_img.time_stamp);

@@ -69,7 +69,8 @@ class ImageProcessor {
     typedef std::shared_ptr<const ImageProcessor> ConstPtr;
 
     // ---- device attachment + phased interface (BatchRunner)
-    void attach(mskf_stream *s) { stream_ = s; }
+    // (the detector floor: this class only ever asks for the cells above its threshold, image_processor.cpp:132)
+    void attach(mskf_stream *s) { stream_ = s; if (s) mskf_fe_set_detect_floor(s, cfg_.fast_threshold * 256); }
     mskf_stream *stream() const { return stream_; }
     void phaseBegin(double time_stamp, int width, int height);      // timestamps, Q2 aliasing, grid size (Q7)
     void phasePrepare1(mskf_fe_track_args &args);                   // first frame: detections; else prev features

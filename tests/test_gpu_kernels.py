@@ -79,6 +79,33 @@ def test_detector_flat_and_ties(gpu_ctx, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("floor", [1, 10 * 256, 40 * 256, 300 * 256])
+def test_detector_floor_is_exact(gpu_ctx, oracle, floor):
+    """mskf_fe_set_detect_floor: only scores ABOVE the floor are recorded, decided before the integer square root
+    (disc < (a + d - floor)^2).  The recorded maxima must be exactly the oracle's maxima above the floor (score, position,
+    tie-break), everything else reads as "no corner", and candidates cannot be asked for below the floor."""
+    for w, h, seed in ((752, 480, 11), (376, 240, 12)):
+        syn = oracle.Synth(seed=seed, width=w, height=h)
+        a, b = syn.render(5)
+        s, _ = _stream(gpu_ctx, oracle, w, h)
+        s.set_detect_floor(floor)
+        s.push_stereo(a, b)
+        got, ref = s.cell_maxima(), oracle.cell_maxima(a)
+        keep = ref["score"] > floor
+        assert np.array_equal(got["score"], np.where(keep, ref["score"], 0))
+        assert np.array_equal(got["x"][keep], ref["x"][keep]) and np.array_equal(got["y"][keep], ref["y"][keep])
+        cand = s.cell_candidates(floor)
+        assert len(cand) == keep.sum() and np.array_equal(cand["score"], ref["score"][keep])
+        if floor > 1:
+            with pytest.raises(Exception):
+                s.cell_candidates(floor - 1)
+        # back to "every positive score" with the next push
+        s.set_detect_floor(0)
+        s.push_stereo(a, b)
+        assert np.array_equal(s.cell_maxima()["score"], ref["score"])
+        s.close()
+
+
 def test_cell_candidates_are_the_maxima_above_threshold(gpu_ctx, oracle):
     """mskf_fe_get_cell_candidates == the records of mskf_fe_get_cell_maxima with score > min_score, in cell order."""
     syn = oracle.Synth(seed=5, width=752, height=480)
