@@ -1151,6 +1151,8 @@ void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave
     const int lds_rows = max_rows <= GATE_LDS_ROWS ? max_rows : GATE_LDS_ROWS;
     size_t lds = ((size_t)(lds_rows + 1) * (lds_rows + 2) / 2 + 16) * sizeof(double);
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
+    // (The two class launches are independent, but an any-order launch of the second one, hipExtAnyOrderLaunch, is not
+    // honoured on gfx9: the trace shows it starting when the first ends.)
     if (max_rows <= 4 * 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
     else hipLaunchKernelGGL((k_ekf_feature_blocks<MAX_CLONES_DEV, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
 }
