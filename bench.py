@@ -38,11 +38,11 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 CONFIGS = {
     "c2": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=1536, groups=8, loop=60, cpu_frames=150, cpu_all_frames=80,
                name="configs[1] Single MI355X: 752x480 stereo, 30 cam clones, 400 features/frame, 200 Hz IMU"),
-    "c3": dict(width=1280, height=720, clones=50, grid="10x20x4x5", streams=128, groups=8, loop=60, cpu_frames=60, cpu_all_frames=30,
+    "c3": dict(width=1280, height=720, clones=50, grid="10x20x4x5", streams=128, groups=4, loop=60, cpu_frames=60, cpu_all_frames=30,
                name="configs[2] Single MI355X stress: 1280x720 stereo, 50 cam clones, 1000 features/frame"),
     "c4": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=8, groups=1, loop=100, cpu_frames=150, cpu_all_frames=80,
                name="configs[3] 8xMI355X: 64 EuRoC-shaped streams sharded 8/GPU"),
-    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=8, groups=8, loop=30, cpu_frames=40, cpu_all_frames=6,
+    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=8, groups=2, loop=30, cpu_frames=40, cpu_all_frames=6,
                name="configs[4] 4K stereo streams, 2000 features/frame, 60 cam clones"),
 }
 
