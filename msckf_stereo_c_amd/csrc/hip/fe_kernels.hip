@@ -612,6 +612,9 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
     const PyrDev &B = stereo ? S.curr1 : S.curr0;
     int status = 1;
     float ncx = 0.f, ncy = 0.f;
+#ifdef LK_ITER_DBG
+    unsigned int dbg_iters = 0;
+#endif
     const bool winrow = r < LK_WIN;                       // lane 15 only feeds the row below window row 14
     for (int l = MSKF_LEVELS - 1; l >= 0; --l) {
         const uint8_t *imA = A.lvl[l];
@@ -719,6 +722,9 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
         float pdx = 0.f, pdy = 0.f;
         for (int it = 0; it < LK_ITERS; ++it) {
             if (!__any(run)) break;
+#ifdef LK_ITER_DBG
+            if (run) dbg_iters += 1u << (8 * l);
+#endif
             int inx = (int)floorf(wx), iny = (int)floorf(wy);
             if (run && (inx < -LK_WIN || inx >= bw || iny < -LK_WIN || iny >= bh)) {
                 if (l == 0) status = 0;
@@ -775,6 +781,9 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
         }
         if (solved) { ncx = wx + (float)LK_HALF; ncy = wy + (float)LK_HALF; }
     }
+#ifdef LK_ITER_DBG
+    if (pt < S.n_pts && r == 0) { if (!stereo) ((unsigned int *)S.und1)[2 * pt] = dbg_iters; else ((unsigned int *)S.und1)[2 * pt + 1] = dbg_iters; }
+#endif
     if (alive && r == 0) {
         if (!stereo) {
             S.out0[pt] = mskf_point2f{ncx, ncy};
@@ -842,7 +851,9 @@ __global__ __launch_bounds__(64) void k_pt_geom(const FeStreamDev *streams, int 
         if (err > S.epi_thresh) st = 0;
     }
     S.und0[pt] = mskf_point2f{u0x, u0y};
+#ifndef LK_ITER_DBG
     S.und1[pt] = mskf_point2f{u1x, u1y};
+#endif
     S.status[pt] = (uint8_t)(1 | (st ? 2 : 0));
 }
 
