@@ -526,11 +526,33 @@ __device__ __forceinline__ long long l4_row_sum(int v) {
 
 // Stage ROWS x 24 bytes at image (x0, y0) as LDS dwords dst[row * 6 + c]; the 16 lanes of a point cooperate (r = lane & 15).
 // Pixels outside the image are replicated from the border.
+struct __attribute__((packed, aligned(4))) l4_u4 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(4))) l4_u2 { uint32_t v[2]; };
 template <int ROWS>
 __device__ __forceinline__ void l4_stage(const uint8_t *img, int w, int h, int x0, int y0, uint32_t *dst, int r, bool on) {
-    typedef uint32_t __attribute__((aligned(1))) u32u;
-    constexpr int N = ROWS * L4_DW, PER = (N + 15) / 16;
     const bool fast = x0 >= 0 && y0 >= 0 && x0 + 4 * L4_DW <= w && y0 + ROWS <= h;
+    if (fast) {
+        // inside the image: lane r takes row r whole (24 bytes = a 16-byte and an 8-byte load at a dword-aligned address),
+        // lanes 0 .. ROWS-17 take rows 16 .. ROWS-1 as well: four loads with one address each instead of seven or eight
+        // dword loads with an element -> (row, column) division each
+        if (on) {
+            const uint8_t *p = img + l4_mad24_vvv(y0 + r, w, x0);
+            const l4_u4 a = *(const l4_u4 *)p;
+            const l4_u2 b = *(const l4_u2 *)(p + 16);
+            uint32_t *d = dst + L4_DW * r;
+            d[0] = a.v[0]; d[1] = a.v[1]; d[2] = a.v[2]; d[3] = a.v[3]; d[4] = b.v[0]; d[5] = b.v[1];
+            if (r < ROWS - 16) {
+                const uint8_t *p2 = img + l4_mad24_vvv(y0 + 16 + r, w, x0);
+                const l4_u4 a2 = *(const l4_u4 *)p2;
+                const l4_u2 b2 = *(const l4_u2 *)(p2 + 16);
+                uint32_t *d2 = dst + L4_DW * (16 + r);
+                d2[0] = a2.v[0]; d2[1] = a2.v[1]; d2[2] = a2.v[2]; d2[3] = a2.v[3]; d2[4] = b2.v[0]; d2[5] = b2.v[1];
+            }
+        }
+        return;
+    }
+    // at the border: element-wise, pixels outside the image replicated from the edge
+    constexpr int N = ROWS * L4_DW, PER = (N + 15) / 16;
     uint32_t v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -538,13 +560,10 @@ __device__ __forceinline__ void l4_stage(const uint8_t *img, int w, int h, int x
         v[i] = 0;
         if (on && e < N) {
             const int row = (e * 43) >> 8, c = e - L4_DW * row;       // e / 6 for e < 128
-            if (fast) v[i] = *(const u32u *)(img + l4_mad24_vvv(y0 + row, w, x0 + 4 * c));      // (a level is far below 2^31 bytes)
-            else {
-                const uint8_t *rp = img + l4_mad24_vvv(min(max(y0 + row, 0), h - 1), w, 0);
-                const int xb = x0 + 4 * c;
-                v[i] = (uint32_t)rp[min(max(xb, 0), w - 1)] | ((uint32_t)rp[min(max(xb + 1, 0), w - 1)] << 8) |
-                       ((uint32_t)rp[min(max(xb + 2, 0), w - 1)] << 16) | ((uint32_t)rp[min(max(xb + 3, 0), w - 1)] << 24);
-            }
+            const uint8_t *rp = img + l4_mad24_vvv(min(max(y0 + row, 0), h - 1), w, 0);
+            const int xb = x0 + 4 * c;
+            v[i] = (uint32_t)rp[min(max(xb, 0), w - 1)] | ((uint32_t)rp[min(max(xb + 1, 0), w - 1)] << 8) |
+                   ((uint32_t)rp[min(max(xb + 2, 0), w - 1)] << 16) | ((uint32_t)rp[min(max(xb + 3, 0), w - 1)] << 24);
         }
     }
 #pragma unroll
