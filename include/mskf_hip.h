@@ -38,7 +38,7 @@ typedef struct mskf_ctx mskf_ctx;
 typedef struct mskf_stream mskf_stream;
 
 const char *mskf_last_error(void);
-int mskf_abi_version(void);
+int mskf_abi_version(void);   /* 2 since round 2: update args carry diag_out, mskf_ekf_cfg.compression_mode, *_begin / *_end entry points */
 
 int mskf_ctx_create(int device, mskf_ctx **out);
 /* Same, with the context's HIP stream created at the device's most urgent priority when high_priority != 0.
