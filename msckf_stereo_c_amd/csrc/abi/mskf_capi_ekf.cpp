@@ -77,16 +77,20 @@ int mskf_ekf_stream_init(mskf_stream *s) {
     int rc;
     const size_t pl = (size_t)E.ld * E.ld;
     hipStream_t st = s->ctx->stream;     // the fills are drained below: the stream may be re-attached to another context later
-    if ((rc = dev_alloc(&E.P, pl, st)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.T, pl, st)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.S, pl, st)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.W, pl, st)) != MSKF_OK) return rc;
-    { double *tmp = nullptr; if ((rc = dev_alloc(&tmp, (size_t)E.ld, st)) != MSKF_OK) return rc; E.act = (int *)tmp; }   // ld ints fit
-    if ((rc = dev_alloc(&E.gate_S, (size_t)EKF_SLOTS * E.nmax * E.nmax, st)) != MSKF_OK) return rc;
-    if ((rc = dev_alloc(&E.chi2, 128, st)) != MSKF_OK) return rc;
+    // one allocation and one fill for the stream's fixed-size filter buffers (eight of each per stream showed up as
+    // thousands of fill kernels in the profile of a 1536-stream run)
     EkfExtra *X = new EkfExtra();
     s->ekf_extra = X;
-    if ((rc = dev_alloc(&X->P_alt, pl, st)) != MSKF_OK) return rc;
+    {
+        auto pad = [](size_t n) { return (n + 31) / 32 * 32; };      // 256-byte aligned sub-buffers
+        const size_t n_gate = pad((size_t)EKF_SLOTS * E.nmax * E.nmax), n_act = pad((size_t)E.ld), n_chi = pad(128), n_pl = pad(pl);
+        if ((rc = dev_alloc(&E.pool, 5 * n_pl + n_act + n_gate + n_chi, st)) != MSKF_OK) return rc;
+        double *q = E.pool;
+        E.P = q; q += n_pl; E.T = q; q += n_pl; E.S = q; q += n_pl; E.W = q; q += n_pl; X->P_alt = q; q += n_pl;
+        E.act = (int *)q; q += n_act;           // ld ints fit
+        E.gate_S = q; q += n_gate;
+        E.chi2 = q;
+    }
     MSKF_HIPCHK(hipStreamSynchronize(st));
     double tab[100];
     tab[0] = 0.0;
@@ -98,14 +102,13 @@ int mskf_ekf_stream_init(mskf_stream *s) {
 
 void mskf_ekf_stream_free(mskf_stream *s) {
     EkfStreamState &E = s->ekf_state;
-    double *ptrs[] = {E.P, E.T, E.S, E.W, (double *)E.act, E.gate_S, E.chi2, E.Hs, E.rs};
-    for (double *p : ptrs) if (p) (void)hipFree(p);
+    if (E.pool) (void)hipFree(E.pool);          // P, T, S, W, P_alt, act, gate_S, chi2
+    if (E.Hs) (void)hipFree(E.Hs);              // Hs + rowmask
     if (E.h_arena) (void)hipHostFree(E.h_arena);
     if (E.d_arena) (void)hipFree(E.d_arena);
     if (E.h_out) (void)hipHostFree(E.h_out);
     if (E.d_out) (void)hipFree(E.d_out);
     if (EkfExtra *X = extra_of(s)) {
-        if (X->P_alt) (void)hipFree(X->P_alt);
         if (X->h_small) (void)hipHostFree(X->h_small);
         if (X->d_small) (void)hipFree(X->d_small);
         if (X->small_done) (void)hipEventDestroy(X->small_done);
@@ -526,12 +529,11 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         out_bytes = align_up(L.o_status + (size_t)a.n_feat, 64);
         if (m_total > E.max_rows) {
             MSKF_HIPCHK(hipStreamSynchronize(st));
-            if (E.Hs) (void)hipFree(E.Hs);
-            if (E.rs) (void)hipFree(E.rs);
+            if (E.Hs) (void)hipFree(E.Hs);      // (rs lives behind Hs in the same allocation)
             E.Hs = E.rs = nullptr;
             const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
-            if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld, st)) != MSKF_OK) return rc;
-            if ((rc = dev_alloc(&E.rs, (size_t)cap, st)) != MSKF_OK) return rc;
+            if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld + (size_t)cap, st)) != MSKF_OK) return rc;
+            E.rs = E.Hs + (size_t)cap * E.ld;
             E.max_rows = cap;
         }
         max_na_bound = std::max(max_na_bound, 6 * __builtin_popcountll(clone_mask));
