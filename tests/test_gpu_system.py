@@ -178,6 +178,36 @@ def test_pipelined_run_is_identical_to_lockstep(oracle):
         r.close()
 
 
+def test_half_batches_on_a_shared_stream_are_identical(oracle, monkeypatch):
+    """MSKF_HALVES=2: a group drives two staggered half-batches per stage, each on its own context sharing the stage's
+    HIP stream (mskf_ctx_create_shared), through the *_batch_begin / *_batch_end halves of the C-ABI.  Front-end results
+    (integer arithmetic) must be bit-identical to the one-batch run; the filter's agree to rounding only, because the
+    update path is chosen per batch (pair kernel / fused small update / general path need EVERY stream of the batch to
+    qualify), so a different batch composition may take a different, algebraically equal route."""
+    w, h, n_frames = 376, 240, 60
+    fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
+    syns = [oracle.Synth(seed=0x5EED0060 + i, width=w, height=h) for i in range(4)]
+    keep, runs = [], []
+    for halves in ("1", "2"):
+        monkeypatch.setenv("MSKF_HALVES", halves)
+        run = R.Runner(syns[0].calib, fe, ekf, 1, 4, host_threads=1)
+        _attach_sequences(oracle, run, syns, n_frames, keep)
+        run.run(0, n_frames, threaded=True, pipelined=True)
+        runs.append(run)
+    a, b = runs
+    for i in range(4):
+        for x, y in zip(a.dump(i)[:4], b.dump(i)[:4]):
+            assert np.array_equal(x, y)
+        pa, pb = a.poses(i), b.poses(i)
+        assert len(pa) == len(pb) > 15
+        assert np.abs(pa["p"] - pb["p"]).max() < 1e-9 and np.abs(pa["q"] - pb["q"]).max() < 1e-9
+        ca, cb = a.cov(i), b.cov(i)
+        assert np.abs(ca - cb).max() / np.abs(ca).max() < 1e-9
+        assert a.num_updates(i) == b.num_updates(i) > 0
+    for r in runs:
+        r.close()
+
+
 def _lockstep(oracle, syn, fe, ekf, n_frames, frame_hook=None, check_every=1, after_frame=None):
     """Run oracle and GPU path in lockstep on (possibly modified) frames of `syn`; returns (osys, run)."""
     osys = oracle.OracleSystem(syn.calib, fe, ekf)
