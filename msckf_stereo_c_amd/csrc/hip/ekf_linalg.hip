@@ -51,7 +51,10 @@ template <> struct GemmTraits<GM_PUPD> { static constexpr bool TA = true,  SYM =
 #define GT 32      // output tile edge
 #define GK 32      // K per LDS stage
 
-// One 32x32 output tile per workgroup (one 16x16 MFMA sub-tile per wave).  The K loop is software pipelined:
+// One 32x32 output tile per workgroup (one 16x16 MFMA sub-tile per wave).  (Tried in round 2: 64x64 tiles with a 2x2 block
+// of sub-tiles per wave, i.e. half the LDS reads per MFMA.  2.6 x SLOWER at the C2 shapes, 109 vs 42 us per launch: with
+// na = 100..175 a stream has 3..6 such tiles, the launch no longer fills the CUs, and a workgroup is bound by the latency of
+// its ~22 K stages, not by feeding the matrix pipe.)  The K loop is software pipelined:
 // the global loads of stage s+1 are issued into registers before the MFMAs of stage s, so a stage costs an LDS
 // round trip instead of an HBM/L2 round trip.
 template <int MODE>
