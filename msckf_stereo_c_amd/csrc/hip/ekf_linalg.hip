@@ -49,7 +49,10 @@ template <> struct GemmTraits<GM_S2>   { static constexpr bool TA = false, SYM =
 template <> struct GemmTraits<GM_PUPD> { static constexpr bool TA = true,  SYM = true,  KMIN_I = false, KMIN_J = false; };
 
 #define GT 32      // output tile edge
-#define GK 32      // K per LDS stage
+#ifndef GK
+#define GK 32      // K per LDS stage (64 measured slower: 49 vs 41 us per launch, the LDS footprint halves the workgroups per CU)
+#endif
+#define GNE (GK / 8)   // elements of each operand per thread and stage
 
 // One 32x32 output tile per workgroup (one 16x16 MFMA sub-tile per wave).  (Tried in round 2: 64x64 tiles with a 2x2 block
 // of sub-tiles per wave, i.e. half the LDS reads per MFMA.  2.6 x SLOWER at the C2 shapes, 109 vs 42 us per launch: with
@@ -123,10 +126,10 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     const int cloneA = MODE == GM_GRAM ? (colA < d ? (colA - EKF_IMU_DIM) / 6 : -1) : 0;
     const int cloneB = MODE == GM_GRAM ? (colB < d ? (colB - EKF_IMU_DIM) / 6 : -1) : 0;
     const unsigned long long *__restrict__ rowmask = S.rowmask;
-    double ra[4], rb[4];
+    double ra[GNE], rb[GNE];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < GNE; ++e) {
             if (MODE == GM_GRAM) {
                 // both operands are (column = lo, row = hi + 8 e) of [H | r]
                 const int gk = k0 + hi + 8 * e;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
                 continue;
             }
             // A: TA -> (i = lo, k = hi + 8e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + 8e) reads A[i*ld + k]
-            const int ii = TR::TA ? lo : hi + 8 * e, kk = TR::TA ? hi + 8 * e : lo;
+            const int ii = TR::TA ? lo : hi + 8 * (e / (GK / 32)), kk = TR::TA ? hi + 8 * e : lo + 32 * (e % (GK / 32));
             const int gi = i0 + ii, gk = k0 + kk;
             double v = 0.0;
             if (gi < M && gk < K && !(TR::KMIN_I && !direct && gk < gi)) {
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     for (int k0 = k_begin; k0 < k_end; k0 += GK) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (TR::TA) sA[hi + 8 * e][lo] = ra[e]; else sA[lo][hi + 8 * e] = ra[e];
+        for (int e = 0; e < GNE; ++e) {
+            if (TR::TA) sA[hi + 8 * e][lo] = ra[e]; else sA[lo + 32 * (e % (GK / 32))][hi + 8 * (e / (GK / 32))] = ra[e];
             sB[hi + 8 * e][lo] = rb[e];
         }
         __syncthreads();
