@@ -625,26 +625,59 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
         GSYNC();
         TDBG();
         // ---- 4. coefficients c_k of every compact column (6M Jacobian columns + the residual)
-        for (int cc = gt; cc <= 6 * M; cc += GS) {
-            double s1 = 0, s2 = 0, s3 = 0;
-            if (cc < 6 * M) {
-                const int blk = cc / 6, c6 = cc - 6 * blk;
-                for (int rr = 0; rr < 4; ++rr) {
-                    const double v = sHx[4 * blk + rr][c6];
-                    s1 += sV[0][4 * blk + rr] * v; s2 += sV[1][4 * blk + rr] * v; s3 += sV[2][4 * blk + rr] * v;
-                }
-            } else {
-                for (int i = 0; i < rows; ++i) { s1 += sV[0][i] * sr[i]; s2 += sV[1][i] * sr[i]; s3 += sV[2][i] * sr[i]; }
+        {
+            // the residual column is a dot product over all rows: reduced across the group (one thread walking the rows was
+            // 10 us of a 29-observation feature)
+            double r1 = 0, r2 = 0, r3 = 0;
+            for (int i = gt; i < rows; i += GS) { const double rv = sr[i]; r1 += sV[0][i] * rv; r2 += sV[1][i] * rv; r3 += sV[2][i] * rv; }
+            r1 = gsum(r1); r2 = gsum(r2); r3 = gsum(r3);
+            for (int cc = gt; cc <= 6 * M; cc += GS) {
+                double s1 = 0, s2 = 0, s3 = 0;
+                if (cc < 6 * M) {
+                    const int blk = cc / 6, c6 = cc - 6 * blk;
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const double v = sHx[4 * blk + rr][c6];
+                        s1 += sV[0][4 * blk + rr] * v; s2 += sV[1][4 * blk + rr] * v; s3 += sV[2][4 * blk + rr] * v;
+                    }
+                } else { s1 = r1; s2 = r2; s3 = r3; }
+                const double c1 = sBeta[0] * s1;
+                const double c2 = sBeta[1] * (s2 - c1 * sVV[0]);
+                const double c3 = sBeta[2] * (s3 - c1 * sVV[1] - c2 * sVV[2]);
+                sCoef[cc][0] = c1; sCoef[cc][1] = c2; sCoef[cc][2] = c3;
             }
-            const double c1 = sBeta[0] * s1;
-            const double c2 = sBeta[1] * (s2 - c1 * sVV[0]);
-            const double c3 = sBeta[2] * (s3 - c1 * sVV[1] - c2 * sVV[2]);
-            sCoef[cc][0] = c1; sCoef[cc][1] = c2; sCoef[cc][2] = c3;
         }
         GSYNC();
         TDBG();
         // ---- 5. write the projected block: rows 3..4M-1 of Q^T [H_xj | r_j], only the 6 M columns of the observed
         //         clones and the residual column (the rest of a row is never read: rowmask, k_ekf_cap)
+        if constexpr (MAXC <= 32) {
+            // a lane's columns (cc = lane, lane + 64, ...) do not depend on the row: their coefficients, clone column and
+            // block position are taken into registers once, a row then costs three broadcast reads and one store per column
+            constexpr int NCH = (6 * MAXC + 63) / 64;
+            double q0[NCH], q1[NCH], q2[NCH];
+            int qcol[NCH], qob[NCH], qc6[NCH];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int cc = (gt & 63) + 64 * q;
+                qob[q] = -1; qcol[q] = 0; qc6[q] = 0; q0[q] = q1[q] = q2[q] = 0.0;
+                if (cc < 6 * M) {
+                    const int ob = cc / 6, c6 = cc - 6 * ob;
+                    qob[q] = ob; qc6[q] = c6; qcol[q] = EKF_IMU_DIM + 6 * sCloneOfObs[ob] + c6;
+                    q0[q] = sCoef[cc][0]; q1[q] = sCoef[cc][1]; q2[q] = sCoef[cc][2];
+                }
+            }
+            for (int i = 3 + (gt >> 6); i < rows; i += GS / 64) {       // one output row per wave pass
+                const double v0 = sV[0][i], v1 = sV[1][i], v2 = sV[2][i];
+                double *out = Hrow0 + (size_t)(i - 3) * ld;
+                const int ob_i = i >> 2;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    if (qob[q] < 0) continue;
+                    const double base = (ob_i == qob[q]) ? sHx[i][qc6[q]] : 0.0;
+                    out[qcol[q]] = base - q0[q] * v0 - q1[q] * v1 - q2[q] * v2;
+                }
+            }
+        } else
         for (int i = 3 + (gt >> 6); i < rows; i += GS / 64) {       // one output row per wave pass, compact columns across lanes
             const double v0 = sV[0][i], v1 = sV[1][i], v2 = sV[2][i];
             double *out = Hrow0 + (size_t)(i - 3) * ld;
@@ -665,7 +698,10 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
         // ---- 6. gating test: gamma = r^T (H P H^T + sigma^2 I)^-1 r    (msckf_vio.cpp:909-935)
         // H = A^T H_xj with H_xj block diagonal (4x6 per observation), so H P H^T = A^T Mm A with
         // Mm[a][b] = H_a P_ab H_b^T (4x4 blocks from 6x6 blocks of P), and A^T . A = rows/cols 3.. of Q^T . Q.
-        double *Mm = (rows <= lds_rows) ? s_arena : (S.gate_S + (size_t)w_slot * S.nmax * S.nmax);   // packed lower
+        // Everything that touches the gate matrix is instantiated twice, once with the LDS arena and once with the global
+        // scratch: through ONE pointer that may be either, every access is a flat instruction, and a flat access to LDS
+        // costs several times a ds_read (the W pass, the rank-6 update and the factorisation all wait on it).
+        auto gate_steps = [&](double *Mm) __attribute__((always_inline)) {
         const double *P = S.P;
         for (int pr = gt; pr < M * M; pr += GS) {
             const int a = pr / M, b = pr - a * M;
@@ -699,12 +735,14 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
                 const int i = gt;
                 double w0 = 0, w1 = 0, w2 = 0;
                 const double *mi = Mm + pk(i, 0);
+#pragma unroll 4
                 for (int c = 0; c <= i; ++c) { const double m = mi[c]; w0 += m * sV[0][c]; w1 += m * sV[1][c]; w2 += m * sV[2][c]; }
-                size_t o = pk(i + 1, i);
-                for (int c = i + 1; c < rows; ++c) { const double m = Mm[o]; w0 += m * sV[0][c]; w1 += m * sV[1][c]; w2 += m * sV[2][c]; o += c + 1; }
+#pragma unroll 4
+                for (int c = i + 1; c < rows; ++c) { const double m = Mm[pk(c, i)]; w0 += m * sV[0][c]; w1 += m * sV[1][c]; w2 += m * sV[2][c]; }
                 sWm[i][0] = w0; sWm[i][1] = w1; sWm[i][2] = w2;
             }
             GSYNC();
+            TDBG();
             double g[6] = {0, 0, 0, 0, 0, 0};       // G: 00 01 02 11 12 22
             for (int i = gt; i < rows; i += GS) {
                 const double a0 = sV[0][i], a1 = sV[1][i], a2 = sV[2][i];
@@ -734,12 +772,19 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
                 sZ[i][2] = w0 * T02 + w1 * T12 + w2 * b3 - 0.5 * (a0 * U02 + a1 * U12 + a2 * U22);
             }
             GSYNC();
-            for (int i = gt >> 6; i < rows; i += GS / 64) {
-                const double z0 = sZ[i][0], z1 = sZ[i][1], z2 = sZ[i][2];
-                const double a0 = sV[0][i], a1 = sV[1][i], a2 = sV[2][i];
-                double *mi = Mm + pk(i, 0);
-                for (int c = gt & 63; c <= i; c += 64)
-                    mi[c] -= z0 * sV[0][c] + z1 * sV[1][c] + z2 * sV[2][c] + a0 * sZ[c][0] + a1 * sZ[c][1] + a2 * sZ[c][2];
+            TDBG();
+            // Mm -= Z V^T + V Z^T over a flat index of the packed lower triangle: every element is independent, so the
+            // LDS latencies of consecutive iterations overlap (a wave walking one row per pass was 16 us at 16 observations)
+            {
+                const int n_el = rows * (rows + 1) / 2;
+#pragma unroll 2
+                for (int e = gt; e < n_el; e += GS) {
+                    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    if ((i + 1) * (i + 2) / 2 <= e) ++i;                 // float rounding: at most one off
+                    if (i * (i + 1) / 2 > e) --i;
+                    const int c = e - i * (i + 1) / 2;
+                    Mm[e] -= sZ[i][0] * sV[0][c] + sZ[i][1] * sV[1][c] + sZ[i][2] * sV[2][c] + sV[0][i] * sZ[c][0] + sV[1][i] * sZ[c][1] + sV[2][i] * sZ[c][2];
+                }
             }
             GSYNC();
         }
@@ -786,8 +831,9 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
 #undef SG
         TDBG();
 #ifdef FEAT_DBG
-        if (item == 0 && gt == 0) printf("feat M=%d TPB=%d: tri %lld jac %lld hh %lld coef %lld write %lld gateM %lld reflect %lld chol %lld\n", M, TPB,
-            (tdbg[1]-tdbg[0])*10, (tdbg[2]-tdbg[1])*10, (tdbg[3]-tdbg[2])*10, (tdbg[4]-tdbg[3])*10, (tdbg[5]-tdbg[4])*10, (tdbg[6]-tdbg[5])*10, (tdbg[7]-tdbg[6])*10, (tdbg[8]-tdbg[7])*10);
+        if (item == 0 && gt == 0) printf("feat M=%d TPB=%d: tri %lld jac %lld hh %lld coef %lld write %lld gateM %lld reflect W %lld GZ %lld upd %lld chol %lld\n", M, TPB,
+            (tdbg[1]-tdbg[0])*10, (tdbg[2]-tdbg[1])*10, (tdbg[3]-tdbg[2])*10, (tdbg[4]-tdbg[3])*10, (tdbg[5]-tdbg[4])*10, (tdbg[6]-tdbg[5])*10, (tdbg[7]-tdbg[6])*10,
+            (tdbg[8]-tdbg[7])*10, (tdbg[9]-tdbg[8])*10, (tdbg[10]-tdbg[9])*10);
 #endif
         double gamma = 1e300;
         if (pd_ok) {
@@ -804,6 +850,9 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
             if (pass) for (int o = 0; o < M; ++o) cm |= 1ULL << sCloneOfObs[o];
             F.colmask = cm;
         }
+        };
+        if (rows <= lds_rows) gate_steps(s_arena);
+        else gate_steps(S.gate_S + (size_t)w_slot * S.nmax * S.nmax);       // packed lower, global
     }
 }
 
