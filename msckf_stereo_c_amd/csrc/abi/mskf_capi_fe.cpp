@@ -108,7 +108,23 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
         return MSKF_OK;
     }
     const unsigned int want = c->flag_seq[k];
-    while ((int)(__atomic_load_n((const unsigned int *)w, __ATOMIC_ACQUIRE) - want) < 0) __builtin_ia32_pause();
+    // a mark that never arrives (device fault, lost queue) must not hang the caller for ever: after MSKF_WAIT_TIMEOUT_S
+    // seconds (default 120) the stream is asked for its error state and the wait fails
+    static const double limit_s = [] { const char *e = std::getenv("MSKF_WAIT_TIMEOUT_S"); const double v = e ? std::atof(e) : 120.0; return v > 0 ? v : 120.0; }();
+    unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t0;
+    while ((int)(__atomic_load_n((const unsigned int *)w, __ATOMIC_ACQUIRE) - want) < 0) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFFULL) == 0) {                       // about every 10 ms
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0x100000ULL) t0 = now;
+            else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
+                const hipError_t e = hipStreamQuery(c->stream);
+                mskf_set_error(e != hipSuccess && e != hipErrorNotReady ? hipGetErrorString(e) : "completion mark not written within the wait limit");
+                return MSKF_ERR_HIP;
+            }
+        }
+    }
     return MSKF_OK;
 }
 int mskf_wait(mskf_ctx *c) {
