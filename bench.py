@@ -427,7 +427,7 @@ def main(argv=None):
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
         else:
-            per_unit = {"k_lk_points": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
+            per_unit = {"k_lk_points4": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
             achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
@@ -435,7 +435,7 @@ def main(argv=None):
         # separately); only comparable when a launch covers the same number of streams
         try:
             pmc_all = json.load(open(PMC_TRAFFIC_FILE))
-            pmc = pmc_all["kernels"].get({"k_lk_points": "k_lk_points4"}.get(dom, dom)) or pmc_all["kernels"].get(dom)
+            pmc = pmc_all["kernels"].get(dom)
             spl = pmc_all.get("streams_per_launch", 96)
             if pmc and args.config == pmc_all.get("config", "c2"):
                 # every stream of a launch reads its own images: traffic per launch is proportional to the streams in it

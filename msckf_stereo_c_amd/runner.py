@@ -128,7 +128,7 @@ class Runner:
     def keep_trajectory(self, keep):
         self.L.mskfh_runner_keep_trajectory(self.h, int(keep))
 
-    KERNELS = ["k_pyr_down", "k_detect_cells", "k_lk_points", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
+    KERNELS = ["k_pyr_down", "k_detect_cells", "k_lk_points4", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
                "k_ekf_cap", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_small", "k_ekf_remove_clone", "k_pt_geom"]
 
     def set_timing(self, enable):
