@@ -115,7 +115,7 @@ class ImageProcessor {
     // twoPointRansac (image_processor.cpp:911-1135; dead code in the reference, runs when MSKF_COMPAT_Q5_NO_RANSAC is
     // cleared).  pts1 / pts2: previous / current points ALREADY undistorted to normalised coordinates (the device
     // returns them with every track, :929-930 happen there).  Host code: a few hundred points, seven sequential
-    // hypotheses, index-order sums — see DESIGN.md section 7.
+    // hypotheses, index-order sums — see DESIGN.md, "Out of scope".
     void twoPointRansac(const std::vector<cg::Point2f> &pts1_undistorted, const std::vector<cg::Point2f> &pts2_undistorted,
                         const hm::Mat3 &R_p_c, const double intrinsics[4], double inlier_error, double success_probability,
                         std::vector<int> &inlier_markers);
