@@ -186,7 +186,32 @@ def cpu_info():
     return model, len(phys) or None, os.cpu_count()
 
 
-def cpu_baseline(oracle_py, args, fe, ekf, total_gpu_frames, gpu_dump):
+def quat_angle(qa, qb):
+    """Rotation angle (rad) between unit quaternions given as rows [x y z w]; sign-insensitive."""
+    import numpy as np
+    d = np.abs(np.sum(qa * qb, axis=1))
+    return 2.0 * np.arccos(np.clip(d, 0.0, 1.0))
+
+
+def pose_compare(o_poses, g_poses):
+    """GPU trajectory of a stream against the CPU oracle's over their common frames: max position / rotation difference
+    and ATE RMSE (tools/ate_rmse.py: stamp association + Horn alignment, the reference README's evaluation)."""
+    import numpy as np
+    from tools.ate_rmse import ate_rmse
+    m = min(len(o_poses), len(g_poses))
+    if m < 3:
+        return None
+    o, g = o_poses[:m], g_poses[:m]
+    if not np.array_equal(o["t"], g["t"]):
+        return {"frames": int(m), "stamps_equal": False}
+    dp = np.linalg.norm(o["p"] - g["p"], axis=1)
+    dq = quat_angle(o["q"], g["q"])
+    ate = ate_rmse(g["t"], g["p"], o["t"], o["p"])
+    return {"frames": int(m), "stamps_equal": True, "max_dp_m": float(dp.max()), "max_dq_rad": float(dq.max()),
+            "ate_rmse_m": float(ate["rmse"]), "path_length_m": float(np.linalg.norm(np.diff(o["p"], axis=0), axis=1).sum())}
+
+
+def cpu_baseline(oracle_py, args, fe, ekf, total_gpu_frames, gpu_dump, gpu_poses=None):
     """The CPU oracle (kind "port": the reference itself cannot be built here) timed on this box's host
     cores, compiled like the reference (-O3, one thread per stream, headless).  Leg (i): one stream on one core (the
     reference's execution model).  Leg (ii): one stream per usable core, all at once.  Frames are rendered before the
@@ -214,6 +239,11 @@ def cpu_baseline(oracle_py, args, fe, ekf, total_gpu_frames, gpu_dump):
         id_check = {"frame": check_at, "features": int(len(o_ids)),
                     "ids_equal": bool(np.array_equal(o_ids, g_ids)), "lifetimes_equal": bool(np.array_equal(o_life, g_life)),
                     "pixels_equal": bool(np.array_equal(o_c0, g_c0) and np.array_equal(o_c1, g_c1))}
+        if gpu_poses:
+            # the metric's second half: trajectory of stream 0 of the timed batch against the oracle's, every frame up to here
+            pc = pose_compare(osys.poses(), gpu_poses[0][:len(osys.poses())])
+            if pc:
+                id_check["pose_stream0"] = pc
         syns[0].feed(osys, args.prime + args.cpu_frames - check_at, start=check_at)
     else:
         syns[0].feed(osys, args.cpu_frames, start=args.prime)
@@ -232,6 +262,19 @@ def cpu_baseline(oracle_py, args, fe, ekf, total_gpu_frames, gpu_dump):
             dt = time.perf_counter() - t0
         out["all_cores"] = {"value": n_all * args.cpu_all_frames / dt, "unit": "stereo frames/s", "cores": n_all,
                             "sample": "%d streams x %d frames at once, one oracle thread per usable core, %.1f s" % (n_all, args.cpu_all_frames, dt)}
+        if gpu_poses and id_check is not None:
+            # these oracle streams replay sequences 0 .. n_all-1, which streams 0 .. n_all-1 of the GPU batch ran inside the
+            # timed launches: compare the trajectories over the frames both have (filter state of the batch vs the oracle)
+            worst = {"streams": 0, "frames": 0, "max_dp_m": 0.0, "max_dq_rad": 0.0, "ate_rmse_m": 0.0}
+            for i in range(min(n_all, len(gpu_poses))):
+                pc = pose_compare(systems[i].poses(), gpu_poses[i])
+                if not pc or not pc.get("stamps_equal"):
+                    continue
+                worst["streams"] += 1
+                worst["frames"] = max(worst["frames"], pc["frames"])
+                for k in ("max_dp_m", "max_dq_rad", "ate_rmse_m"):
+                    worst[k] = max(worst[k], pc[k])
+            id_check["pose_batch"] = worst
     return out, id_check
 
 
@@ -361,10 +404,16 @@ def main(argv=None):
         del frames                                            # the host copy (GBs per rank) is not needed any more
     calib = syns[0].calib
     run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads)
+    # pose_out.txt / path_ / points3d_ growth (msckf_vio.cpp:1296-1302, Q20) is off for the batch; the streams whose
+    # trajectories are compared with the CPU oracle after the run keep theirs
     run.keep_trajectory(False)
+    n_pose_streams = min(per_group, max(1, int(host_cores_available()))) if (rank == 0 and not args.no_cpu) else 1
+    for s_ in range(n_pose_streams):
+        run.keep_trajectory(True, s_)
+    cooldown = 8 if n_groups > 1 else 0
     if max_offset:
         run.set_stagger(args.stagger)
-    imus = [imu_array(s, (total_frames + max_offset + 3) * 10 + 20) for s in syns]
+    imus = [imu_array(s, (total_frames + max_offset + cooldown + 3) * 10 + 20) for s in syns]
     for s in range(n_streams):
         u = s % args.unique
         cam0 = base + (u * 2 + 0) * n_keys * frame_bytes
@@ -380,34 +429,57 @@ def main(argv=None):
 
     pipe = not args.no_pipeline
     run.run(0, args.prime, pipelined=pipe)                       # untimed: gravity/bias init, clone window fills, group offsets
-    run.run(args.prime, args.warmup, pipelined=pipe)             # W untimed warmup steps
     # per-kernel HIP events on every 5th launch of a kind (5 is coprime to the launches per step of every kind, so all of a
     # step's launches are sampled in turn); MSKF_BENCH_TIMING_PERIOD=1 times every launch, MSKF_BENCH_NO_KERNEL_TIMING=1 none
     timing_period = 0 if os.environ.get("MSKF_BENCH_NO_KERNEL_TIMING") else int(os.environ.get("MSKF_BENCH_TIMING_PERIOD", "5"))
-    run.set_timing(timing_period)
-    run.get_timing(reset=True)
-    run.get_phases(reset=True)
-    run.get_abi_host_time(reset=True)
-    barrier()
     cpu_quota, thr0 = cgroup_cpu()
-    t0 = time.perf_counter()
-    run.get_hostprof(reset=True)
-    run.run(args.prime + args.warmup, args.steps, pipelined=pipe)   # EXACTLY K timed steps
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if pipe:
+        # W warm-up + K timed steps in ONE pipelined run: the group pipelines (front-end | filter threads) are not torn
+        # down and refilled at the warm-up / timed boundary, every stage opens its accounting when it reaches step W and
+        # closes it after step W + K - 1; groups that are through keep stepping untimed cool-down frames until the last
+        # one is, so all K steps see the steady-state load.  elapsed = first stage to reach step W .. last stage to finish
+        # step W + K - 1: every one of the K x streams frames is processed entirely inside it (and nothing is skipped).
+        run.set_timing(timing_period)
+        run.get_timing(reset=True)
+        run.get_abi_host_time(reset=True)
+        run.get_hostprof(reset=True)
+        barrier()
+        t_wall0 = time.perf_counter()
+        elapsed = run.run_timed(args.prime, args.warmup, args.steps, max_extra=cooldown)
+        barrier()
+        wall_run = time.perf_counter() - t_wall0
+        phases = run.get_window_phases()
+    else:
+        run.run(args.prime, args.warmup, pipelined=False)        # W untimed warmup steps
+        run.set_timing(timing_period)
+        run.get_timing(reset=True)
+        run.get_phases(reset=True)
+        run.get_abi_host_time(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        run.get_hostprof(reset=True)
+        run.run(args.prime + args.warmup, args.steps, pipelined=False)   # EXACTLY K timed steps
+        barrier()
+        elapsed = wall_run = time.perf_counter() - t0
+        phases = run.get_phases(reset=True)
     hostprof = run.get_hostprof()
     _, thr1 = cgroup_cpu()
     timing = run.get_timing(reset=True)
-    phases = run.get_phases(reset=True)
     abi_host = run.get_abi_host_time(reset=True)
     run.set_timing(False)
+    windows = [run.window(g) for g in range(n_groups)] if pipe else []
 
     from msckf_stereo_c_amd.dist_util import aggregate_throughput
     elapsed, frames_total = aggregate_throughput(elapsed, n_streams * args.steps, world, device=red_dev)
 
-    # what stream 0 (the sentinel sequence, group 0: no offset) has computed; identical on every rank by construction
-    s_ids, s_life, s_c0, s_c1, _ = run.dump(0)
-    hashes = gather_hashes(state_hash(s_ids, s_life, s_c0, s_c1, run.imu_state(0)), world, red_dev)
+    # what stream 0 (the sentinel sequence, group 0: no offset) had computed when its stages closed the timed window, i.e.
+    # after frame prime + W + K - 1; identical on every rank by construction
+    if pipe:
+        s_ids, s_life, s_c0, s_c1, s_imu = run.mark_dump(0)
+    else:
+        s_ids, s_life, s_c0, s_c1, _ = run.dump(0)
+        s_imu = run.imu_state(0)
+    hashes = gather_hashes(state_hash(s_ids, s_life, s_c0, s_c1, s_imu), world, red_dev)
     id_mismatch = sum(1 for h in hashes if h != hashes[0])
 
     # sanity of the workload actually processed (steady state reached, filter alive)
@@ -457,8 +529,25 @@ def main(argv=None):
                     + ("" if not max_offset else "; the %d groups replay them %d frames apart (never the same stereo pair at the same time)"
                        % (n_groups, args.stagger))
                     + ("; SHARED inside a launch" if shared_in_group else ""))
+        # where a step's wall time goes on the two threads of a group (averages over groups, ms per step): each thread's items
+        # add up to its own window (open -> close), which is ms_per_step up to the skew between the groups
+        per = lambda names: {k: round(phases[k] * 1e3 / args.steps / n_groups, 3) for k in names}
+        if pipe:
+            fe_items, ekf_items = per(R.Runner.FE_THREAD_PHASES), per(R.Runner.EKF_THREAD_PHASES)
+            host_phases = {
+                "front_end_thread": dict(fe_items, sum=round(sum(fe_items.values()), 3),
+                                         window=round(sum(w["fe_close"] - w["fe_open"] for w in windows) * 1e3 / args.steps / n_groups, 3)),
+                "filter_thread": dict(ekf_items, sum=round(sum(ekf_items.values()), 3),
+                                      window=round(sum(w["ekf_close"] - w["ekf_open"] for w in windows) * 1e3 / args.steps / n_groups, 3)),
+                "group_skew_ms": {"first_open_to_last_open": round((max(w["fe_open"] for w in windows) - min(w["fe_open"] for w in windows)) * 1e3, 3),
+                                  "first_close_to_last_close": round((max(w["ekf_close"] for w in windows) - min(w["ekf_close"] for w in windows)) * 1e3, 3)},
+                "run_wall_ms": round(wall_run * 1e3, 1),
+                "cooldown_frames_max": max(run.frames_done(g) - run.group_offset(g) for g in range(n_groups)) - total_frames,
+            }
+        else:
+            host_phases = per([k for k in phases if phases[k] > 0])
         out = {
-            "metric": "stereo frames/sec/node on EuRoC-shape input", "value": value, "unit": "stereo frames/s",
+            "metric": "stereo frames/sec/node on EuRoC-shape input; ATE RMSE vs CPU ref", "value": value, "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (host-resident images, PCIe-inclusive)" if args.host_images else ""),
             "config": {"workload": "%s [%s]: %dx%d stereo, %d cam clones, grid %s (%d features/frame realised), 200 Hz IMU; "
@@ -476,14 +565,25 @@ def main(argv=None):
             "id_mismatch": id_mismatch,
             "roofline": roof, "mfma": mfma, "kernels": kernels,
             "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
-            "host_phases_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in phases.items()},
+            "host_phases_ms_per_step": host_phases,
             "abi_host_ms_per_step": {k: round(v * 1e3 / args.steps / n_groups, 3) for k, v in abi_host.items()},
         }
         if not args.no_cpu and world == 1 and args.cpu_frames > 0:
             for s in syns:
                 s._cache.clear()
             del syns
-            out["cpu_baseline"], out["id_check_vs_oracle"] = cpu_baseline(oracle_py, args, fe, ekf, total_frames, (s_ids, s_life, s_c0, s_c1))
+            gpu_poses = [run.poses(s_) for s_ in range(n_pose_streams)]
+            out["cpu_baseline"], out["id_check_vs_oracle"] = cpu_baseline(oracle_py, args, fe, ekf, total_frames, (s_ids, s_life, s_c0, s_c1), gpu_poses)
+            chk = out["id_check_vs_oracle"] or {}
+            pcs = [chk[k] for k in ("pose_stream0", "pose_batch") if k in chk and chk[k].get("stamps_equal", True)]
+            if pcs:
+                # BASELINE.json north_star: poses within 1e-4 m / 1e-4 rad of the CPU reference path
+                out["ate_rmse_vs_cpu_ref_m"] = max(p_["ate_rmse_m"] for p_ in pcs)
+                out["pose_err_vs_cpu_ref"] = {"max_dp_m": max(p_["max_dp_m"] for p_ in pcs), "max_dq_rad": max(p_["max_dq_rad"] for p_ in pcs),
+                                              "streams": max(p_.get("streams", 1) for p_ in pcs), "tolerance": 1e-4}
+                out["pose_within_tolerance"] = bool(out["pose_err_vs_cpu_ref"]["max_dp_m"] <= 1e-4 and out["pose_err_vs_cpu_ref"]["max_dq_rad"] <= 1e-4)
+                if not out["pose_within_tolerance"]:
+                    sys.stderr.write("bench.py: POSE CHECK FAILED against the CPU oracle: %s\n" % json.dumps(out["pose_err_vs_cpu_ref"]))
         print(json.dumps(out), flush=True)
     run.close()
     if world > 1:

@@ -54,7 +54,8 @@ int mskf_ctx_sync(mskf_ctx *ctx);
 void *mskf_ctx_hip_stream(mskf_ctx *ctx);
 
 /* Optional per-kernel timing with HIP events recorded on the context's own stream (bench / roofline).
- * `units` are the algorithmic work units of a launch (LK: point tracks, one launch per temporal / stereo track; point geometry: points; pyramid: output pixels;
+ * `units` are the algorithmic work units of a launch (LK: point tracks, temporal + stereo of one track call in one launch — MSKF_K_PT_GEOM
+ * is kept for ABI stability and stays empty since the per-point geometry moved into that launch; pyramid: output pixels;
  * EKF feature / GEMM / Cholesky / TRSM kernels: algorithmic FP64 flops; others: streams).  Disabled by default.
  * `enable` = n > 1 times every n-th launch of each kind only and scales the sums to all launches: two event records per launch cost
  * 7 % of the throughput at the C2 bench shape and 36 % at C5 (one stream per launch), measured. */
@@ -63,6 +64,10 @@ enum {
     MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_COUNT
 };
 int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
+/* Accounting gate (default on): while it is off, launches are not timed and host seconds not accumulated.  Unlike
+ * mskf_ctx_set_timing it does not synchronise, so the thread that drives the context can open and close a measurement
+ * window in the middle of a running pipeline; launches already begun keep the state they were begun with. */
+int mskf_ctx_timing_gate(mskf_ctx *ctx, int on);
 /* host seconds spent inside the batched entry points of this context, outside the device waits: [0] mskf_ekf_update_batch
  * packing, [1] its unpacking, [2] mskf_fe_track_batch packing, [3] its unpacking */
 int mskf_ctx_get_host_time(mskf_ctx *ctx, double out[4], int reset);

@@ -63,9 +63,11 @@ typedef struct mskf_ekf_cfg {
     double cov_velocity, cov_gyro_bias, cov_acc_bias, cov_ext_rot, cov_ext_trans;
     int32_t max_stack_rows;      /* 1500, msckf_vio.cpp:1009 */
     int32_t compression_mode;    /* QR compression of the stacked Jacobian (msckf_vio.cpp:795-817): 0 = auto (Gram + regularised
-                                    Cholesky; Householder TSQR when the stack has no more rows than active columns or the
-                                    factorisation reports more near-zero pivots than the gauge explains), 1 = Gram only,
-                                    2 = Householder TSQR always */
+                                    Cholesky; Householder TSQR when the stack has no more STACKED rows than active columns, or
+                                    when the factorisation finds that its lambda prior would move the posterior covariance by
+                                    more than 1e-6 relative: lambda max(P_aa) / sigma^2; the count of near-zero pivots is
+                                    reported in diag_out[1] but decides nothing), 1 = Gram only, 2 = Householder TSQR always.
+                                    Any other value is refused by mskf_stream_create */
 } mskf_ekf_cfg;
 
 typedef struct mskf_feature_meas {  /* == cg::FeatureMeasurement */

@@ -47,7 +47,7 @@ EXPORTS = [
     "mskf_ekf_update_batch", "mskf_ekf_remove_clone", "mskf_ekf_remove_clones_batch", "mskf_ekf_predict_batch", "mskf_ekf_propagate_imu",
     "mskf_ekf_get_pos_var", "mskf_ekf_get_pos_var_batch", "mskf_ctx_set_timing", "mskf_ctx_get_timing", "mskf_stream_ctx",
     "mskf_ekf_get_dim", "mskf_ekf_get_cov", "mskf_ekf_set_cov", "mskf_ekf_debug_read", "mskf_ctx_get_host_time", "mskf_fe_track_batch_begin", "mskf_fe_track_batch_end",
-    "mskf_ekf_update_batch_begin", "mskf_ekf_update_batch_end", "mskf_ekf_get_pos_var_batch_begin", "mskf_ekf_get_pos_var_batch_end",
+    "mskf_ekf_update_batch_begin", "mskf_ekf_update_batch_end", "mskf_ekf_get_pos_var_batch_begin", "mskf_ekf_get_pos_var_batch_end", "mskf_ctx_timing_gate",
 ]
 
 
@@ -112,6 +112,16 @@ class Context:
 
     def sync(self):
         _chk(self.L.mskf_ctx_sync(self.h))
+
+    def ekf_update_batch(self, streams, problems):
+        """One mskf_ekf_update_batch over several streams of this context; problems[i] = kwargs of Stream.ekf_update."""
+        n = len(streams)
+        built = [Stream._update_args(**pr) for pr in problems]
+        args = (EkfUpdateArgs * n)(*[b[0] for b in built])
+        hs = (C.c_void_p * n)(*[s.h for s in streams])
+        self.L.mskf_ekf_update_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(EkfUpdateArgs)]
+        _chk(self.L.mskf_ekf_update_batch(self.h, n, hs, args))
+        return [b[2]() for b in built]
 
     def __del__(self):
         try:
@@ -224,9 +234,9 @@ class Stream:
     def ekf_remove_clone(self, idx):
         _chk(self.L.mskf_ekf_remove_clone(self.h, idx))
 
-    def ekf_update(self, gravity, clones, positions, obs_start, obs_clone, obs_z, dof_offset, apply_row_cap,
-                   needs_init=None, init_ranges=None):
-        """clones: (n,14) [q p q_null p_null]; obs_start: n_feat+1 offsets; returns dict."""
+    @staticmethod
+    def _update_args(gravity, clones, positions, obs_start, obs_clone, obs_z, dof_offset, apply_row_cap, needs_init=None, init_ranges=None):
+        """(mskf_ekf_update_args, buffers it points into, result builder) for one stream."""
         clones = np.ascontiguousarray(clones, dtype=np.float64).reshape(-1, 14)
         n_clones = len(clones)
         obs_start = np.asarray(obs_start, dtype=np.int32)
@@ -259,6 +269,16 @@ class Stream:
         a.clones, a.features, a.obs_clone, a.obs_z = clones.ctypes.data, feats.ctypes.data, obs_clone.ctypes.data, obs_z.ctypes.data
         a.delta_x, a.feat_status, a.gamma, a.rows_out = dx.ctypes.data, status.ctypes.data, gamma.ctypes.data, rows.ctypes.data
         a.diag_out = diag.ctypes.data
+        keep = (clones, feats, obs_clone, obs_z, dx, status, gamma, rows, diag)
+
+        def result():
+            return dict(delta_x=dx, status=status[:n_feat], gamma=gamma[:n_feat], rows=int(rows[0]),
+                        positions=feats["position"].copy(), used_qr=int(diag[0]), tiny_pivots=int(diag[1]))
+        return a, keep, result
+
+    def ekf_update(self, gravity, clones, positions, obs_start, obs_clone, obs_z, dof_offset, apply_row_cap,
+                   needs_init=None, init_ranges=None):
+        """clones: (n,14) [q p q_null p_null]; obs_start: n_feat+1 offsets; returns dict."""
+        a, keep, result = self._update_args(gravity, clones, positions, obs_start, obs_clone, obs_z, dof_offset, apply_row_cap, needs_init, init_ranges)
         _chk(self.L.mskf_ekf_update(self.h, C.byref(a)))
-        return dict(delta_x=dx, status=status[:n_feat], gamma=gamma[:n_feat], rows=int(rows[0]),
-                    positions=feats["position"].copy(), used_qr=int(diag[0]), tiny_pivots=int(diag[1]))
+        return result()

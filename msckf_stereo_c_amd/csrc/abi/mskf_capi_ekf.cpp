@@ -12,7 +12,7 @@ void ekf_launch_phiq(const EkfStreamDev *d, int n, int max_steps, hipStream_t st
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave, const int *work_small, int n_small, const int *work_big, int n_big,
-                         int max_rows, int max_rows_small, int wave_per_feature, hipStream_t st);
+                         int max_rows, int max_rows_small, int big_clones, hipStream_t st);
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
@@ -20,7 +20,6 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
-void ekf_launch_qr(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 int ekf_small_update_max_na(void);
 }
 
@@ -70,6 +69,11 @@ int mskf_ekf_stream_init(mskf_stream *s) {
     if (E.max_clones < 4 || E.max_clones > kMaxClonesDev) {
         mskf_set_error("max_cam_state_size must be in [4, 64]");
         return MSKF_ERR_UNSUPPORTED;
+    }
+    if (s->ekf.compression_mode < 0 || s->ekf.compression_mode > 2) {
+        // (the field took the place of padding in ABI v1: a caller that never initialised it must hear about it)
+        mskf_set_error("mskf_ekf_cfg.compression_mode must be 0 (auto), 1 (Gram only) or 2 (Householder TSQR)");
+        return MSKF_ERR_INVALID;
     }
     E.ld = (int)align_up((size_t)(EKF_IMU_DIM + 6 * E.max_clones), 8);
     E.d = EKF_IMU_DIM;
@@ -463,13 +467,19 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     hipStream_t st = ctx->stream;
     int rc = ctx->ekf_desc.ensure(n);
     if (rc != MSKF_OK) return rc;
-    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0, max_na_bound = 0, max_tri = 0;
-    // size classes of the feature kernel and their work lists: [1] at most FEAT_SMALL_CLONES = 16 observations, [2] more;
-    // [0] is the whole batch when every feature has <= 4 observations (wave-per-feature variant)
-    int max_frows_cls[3] = {0, 0, 0}, max_init = 0;
+    int max_feat = 0, max_m = 0, max_d = 0, max_frows = 0, max_tri = 0, max_clones_cfg = 0;
+    // Which kernels handle a stream is decided per STREAM, from that stream's features alone (EkfStreamDev::route): the same
+    // stream takes the same route, and therefore runs the same arithmetic, whatever else is in the batch.
+    //   pairs : every feature has exactly two Jacobian observations, all of the same ordered clone pair (the pruning update)
+    //   wave  : every feature has <= 4 Jacobian observations and a triangulation over <= 32 clones: class [0] of the
+    //           feature kernel, one wavefront per feature; otherwise a feature is in class [1] (<= 16 observations) or [2]
+    //   small : the stream touches at most four clones (<= 24 active columns): whole update in k_ekf_small_update
+    int max_frows_cls[3] = {0, 0, 0};
     std::vector<int> &cnt_cls = ctx->pend_upd.cnt_cls;          // [3][n]
     cnt_cls.assign((size_t)3 * n, 0);
-    bool all_pairs = true;     // every feature of the batch has exactly two Jacobian observations of ONE clone pair per stream
+    std::vector<int> route(n, 0);
+    bool any_pairs = false, any_small = false, any_general = false;
+    int max_feat_pairs = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, tri; int n_tri; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
     std::vector<Lay> lay(n);
@@ -486,18 +496,27 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         int m_total = 0;
         unsigned long long clone_mask = 0ULL;          // clones any Jacobian block of this stream touches: bounds the active columns
         int n_tri = 0;
+        bool pairs = a.n_feat > 0, wave = a.n_feat > 0;
+        int pair_a = -1, pair_b = -1, s_frows_cls[3] = {0, 0, 0};
         for (int j = 0; j < a.n_feat; ++j) {
             const mskf_ekf_feature &f = a.features[j];
             n_tri += f.needs_init ? 1 : 0;
-            if (f.n_obs != 2) all_pairs = false;
             if (f.n_obs < 2 || f.n_obs > E.max_clones || f.obs_start < 0 || f.obs_start + f.n_obs > a.n_obs) return MSKF_ERR_INVALID;
             if (f.needs_init && (f.n_init < 1 || f.n_init > E.max_clones || f.init_start < 0 || f.init_start + f.n_init > a.n_obs)) return MSKF_ERR_INVALID;
+            if (f.n_obs != 2) pairs = false;
+            else if (pairs) {
+                // the pair kernel keeps the two clones' blocks in the order (lower, higher) and shares their covariance
+                // block among the features: both observations distinct, ascending, and the same pair for every feature
+                const int c0 = a.obs_clone[f.obs_start], c1 = a.obs_clone[f.obs_start + 1];
+                if (j == 0) { pair_a = c0; pair_b = c1; }
+                if (!(c0 < c1) || c0 != pair_a || c1 != pair_b) pairs = false;
+            }
+            if (4 * f.n_obs > 16 || (f.needs_init && f.n_init > 32)) wave = false;      // (TRI_SMALL_CLONES)
             m_total += 4 * f.n_obs - 3;
             max_frows = std::max(max_frows, 4 * f.n_obs);
-            if (f.needs_init) max_init = std::max(max_init, f.n_init);
             {
                 const int cls_n = std::max(f.n_obs, f.needs_init ? f.n_init : 0), cls = cls_n <= 16 ? 1 : 2;
-                max_frows_cls[cls] = std::max(max_frows_cls[cls], 4 * f.n_obs);
+                s_frows_cls[cls] = std::max(s_frows_cls[cls], 4 * f.n_obs);
                 ++cnt_cls[(size_t)cls * n + i];
             }
             for (int o = 0; o < f.n_obs; ++o) {
@@ -536,19 +555,29 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             E.rs = E.Hs + (size_t)cap * E.ld;
             E.max_rows = cap;
         }
-        max_na_bound = std::max(max_na_bound, 6 * __builtin_popcountll(clone_mask));
-        if (a.n_feat > 0 && __builtin_popcountll(clone_mask) != 2) all_pairs = false;
+        if (a.n_feat > 0) {
+            if (pairs) wave = false;
+            const bool small = 6 * __builtin_popcountll(clone_mask) <= ekf_small_update_max_na();
+            route[i] = (pairs ? 1 : 0) | (wave ? 2 : 0) | (small ? 4 : 0);
+            any_pairs |= pairs; any_small |= small; any_general |= !small;
+            if (pairs) { max_feat_pairs = std::max(max_feat_pairs, a.n_feat); max_tri = std::max(max_tri, n_tri); }
+            if (pairs || wave) {
+                // the whole stream is class [0] (wave) or handled by the pair kernels: none of its features in [1] / [2]
+                cnt_cls[i] = pairs ? 0 : cnt_cls[(size_t)n + i] + cnt_cls[(size_t)2 * n + i];
+                cnt_cls[(size_t)n + i] = 0; cnt_cls[(size_t)2 * n + i] = 0;
+            } else {
+                for (int c = 1; c < 3; ++c) max_frows_cls[c] = std::max(max_frows_cls[c], s_frows_cls[c]);
+            }
+        }
+        max_clones_cfg = std::max(max_clones_cfg, E.max_clones);
         L.n_tri = n_tri;
-        max_tri = std::max(max_tri, n_tri);
         max_feat = std::max(max_feat, a.n_feat);
         max_m = std::max(max_m, m_total);
         max_d = std::max(max_d, E.d);
     }
     // work lists: stream << 16 | slot << 8 | n_slots per feature group in flight
-    const bool wave_per_feature = max_frows <= 16 && max_init <= 32;      // (TRI_SMALL_CLONES)
     if (n > 0xffff) { mskf_set_error("too many streams in one update batch"); return MSKF_ERR_CAPACITY; }
     int n_work[3] = {0, 0, 0};
-    if (wave_per_feature) for (int i = 0; i < n; ++i) { cnt_cls[i] += cnt_cls[(size_t)n + i] + cnt_cls[(size_t)2 * n + i]; cnt_cls[(size_t)n + i] = 0; cnt_cls[(size_t)2 * n + i] = 0; }
     for (int c = 0; c < 3; ++c) for (int i = 0; i < n; ++i) n_work[c] += std::min(cnt_cls[(size_t)c * n + i], EKF_SLOTS);
     const size_t work_off = in_bytes;
     in_bytes = align_up(in_bytes + sizeof(int) * (size_t)(n_work[0] + n_work[1] + n_work[2]), 64);
@@ -592,6 +621,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         EkfStreamDev &D = ctx->ekf_desc.h[i];
         base_desc(s, D);
         D.n_clones = a.n_clones; D.n_feat = a.n_feat; D.n_obs = a.n_obs;
+        D.route = route[i];
         D.dof_offset = a.dof_offset; D.apply_row_cap = a.apply_row_cap;
         D.m_total = L.m_total;
         for (int k = 0; k < 3; ++k) D.gravity[k] = a.gravity[k];
@@ -611,41 +641,34 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         MSKF_HIPCHK(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
         MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
-        if (all_pairs) ekf_launch_pair_features(ctx->ekf_desc.d, n, max_feat, max_tri, st);      // the pruning update
-        else {
+        if (any_pairs) ekf_launch_pair_features(ctx->ekf_desc.d, n, max_feat_pairs, max_tri, st);      // the pruning update
+        if (n_work[0] + n_work[1] + n_work[2] > 0) {
             const int *w0 = (const int *)(din + work_off);
             ekf_launch_features(ctx->ekf_desc.d, w0, n_work[0], w0 + n_work[0], n_work[1], w0 + n_work[0] + n_work[1], n_work[2], max_frows,
-                                max_frows_cls[1], wave_per_feature ? 1 : 0, st);
+                                max_frows_cls[1], max_clones_cfg, st);
         }
         mskf_t_end(ctx, ts, (long long)fl_feat);
         ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
         ekf_launch_cap(ctx->ekf_desc.d, n, st);
         mskf_t_end(ctx, ts, n);
-        if (max_na_bound <= ekf_small_update_max_na()) {
-            // every stream of the batch stacks blocks of at most four clones (the pruning update: the two clones being
-            // removed): compression, gain and downdate in one launch (k_ekf_small_update)
+        enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
+        const double d3 = fl_upd / (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0);     // sum of d^3 over the launch
+        if (any_small) {
+            // streams that stack blocks of at most four clones (the pruning update: the two clones being removed):
+            // compression, gain and Y in one launch (k_ekf_small_update); the other streams leave it at once
             ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
             ekf_launch_small_update(ctx->ekf_desc.d, n, max_d, st);
-            mskf_t_end(ctx, ts, (long long)(fl_qr + fl_upd));
-            enum { GM_PUPD = 3 };
-            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
-            mskf_t_end(ctx, ts, 0);
-        } else {
-            // QR compression as Gram + semidefinite Cholesky, then the Kalman update (ekf_linalg.hip)
-            enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
-            const double d3 = fl_upd / (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0);     // sum of d^3 over the launch
+            mskf_t_end(ctx, ts, any_general ? 0 : (long long)(fl_qr + fl_upd));
+        }
+        if (any_general) {
+            // QR compression as Gram + semidefinite Cholesky (Householder TSQR inside the factorisation kernel for the
+            // streams that need it), then the Kalman update (ekf_linalg.hip); small-route streams leave these at once
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
             mskf_t_end(ctx, ts, (long long)fl_qr);
             ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
             ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
             mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
-            // Householder TSQR instead, for the streams that need it (no more rows than columns, near-zero pivots beyond
-            // the gauge, or compression_mode = 2): the others leave the launch at once
-            ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
-            ekf_launch_qr(ctx->ekf_desc.d, n, max_d, st);
-            mskf_t_end(ctx, ts, 0);
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
@@ -658,10 +681,11 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
             ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
-            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
-            mskf_t_end(ctx, ts, (long long)(4.0 * d3));
         }
+        // P <- P - Y^T Y and delta_x = Y^T w for every stream, whichever route produced Y
+        ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+        ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
+        mskf_t_end(ctx, ts, any_general ? (long long)(4.0 * d3) : 0);
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
@@ -676,7 +700,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             U.lay[5 * i + 3] = lay[i].o_status; U.lay[5 * i + 4] = lay[i].o_pos;
         }
     }
-    ctx->host_s[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
+    if (ctx->t_gate) ctx->host_s[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
     return MSKF_OK;
 }
 
@@ -721,7 +745,7 @@ extern "C" int mskf_ekf_update_batch_end(mskf_ctx *ctx) {
         for (int j = 0; j < a.n_feat; ++j)
             for (int k = 0; k < 3; ++k) a.features[j].position[k] = po[3 * j + k];
     }
-    ctx->host_s[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
+    if (ctx->t_gate) ctx->host_s[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
     return MSKF_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <atomic>
 #include <mutex>
 #include "mskf_internal.h"
 
@@ -90,18 +91,19 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
     int k = 0;
     while (k < 8 && c->flag_slot[k] && c->flag_slot[k] != ev_slot) ++k;
     if (k == 8) { mskf_set_error("too many completion marks"); return MSKF_ERR_INVALID; }
-    c->flag_slot[k] = ev_slot;
+    if (record) c->flag_slot[k] = ev_slot;       // a slot is claimed when its first mark is recorded; waiting only reads the context
+    else if (c->flag_slot[k] != ev_slot) { mskf_set_error("waiting for a completion mark that was never recorded"); return MSKF_ERR_INVALID; }
     volatile unsigned int *w = c->flag_h + 16 * k;
     if (record) {
         // the mark is a stream write-value command (no dispatch: a one-thread kernel waits 37 us for a CU slot on a busy
         // device, profiles/r02_kernel_stats.csv of the kernel-mark build); MSKF_MARK=kernel, or a runtime that refuses the
         // command on pinned host memory, falls back to the one-thread kernel k_mark
-        static bool use_write = [] { const char *e = std::getenv("MSKF_MARK"); return !(e && e[0] == 'k'); }();
+        static std::atomic<bool> use_write{[] { const char *e = std::getenv("MSKF_MARK"); return !(e && e[0] == 'k'); }()};   // (contexts are driven from several host threads)
         ++c->flag_seq[k];
-        if (use_write) {
+        if (use_write.load(std::memory_order_relaxed)) {
             if (hipStreamWriteValue32(c->stream, (void *)w, c->flag_seq[k], 0) == hipSuccess) return MSKF_OK;
             (void)hipGetLastError();
-            use_write = false;
+            use_write.store(false, std::memory_order_relaxed);
         }
         fe_launch_mark(w, c->flag_seq[k], c->stream);
         MSKF_HIPCHK(hipGetLastError());
@@ -141,7 +143,7 @@ extern "C" int mskf_ctx_sync(mskf_ctx *c) {
 }
 
 int mskf_t_begin(mskf_ctx *c, int kind) {
-    if (!c->timing) return -1;
+    if (!c->timing || !c->t_gate) return -1;
     if ((c->t_all[kind]++ % c->timing_period) != 0) return -1;      // sampled: the events themselves cost device and host time
     TimingSlot t;
     if (!c->t_pool.empty()) { t.a = c->t_pool.back().first; t.b = c->t_pool.back().second; c->t_pool.pop_back(); }
@@ -176,6 +178,12 @@ extern "C" int mskf_ctx_set_timing(mskf_ctx *c, int enable) {
     mskf_t_collect(c);
     c->timing = enable != 0;
     c->timing_period = enable > 1 ? enable : 1;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_ctx_timing_gate(mskf_ctx *c, int on) {
+    if (!c) return MSKF_ERR_INVALID;
+    c->t_gate = on != 0;          // no synchronisation: launches already begun keep the state they were begun with
     return MSKF_OK;
 }
 
@@ -541,30 +549,16 @@ extern "C" int mskf_fe_track_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
     }
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_in.d, ctx->trk_in.h, in_bytes, hipMemcpyHostToDevice, st));
     MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-    // temporal track -> per-point gates + stereo guess -> stereo track -> per-point gates + undistortion
-    bool any_temporal = false;
-    for (int i = 0; i < n; ++i) any_temporal |= args[i].do_temporal && args[i].n > 0;
-    int ts_t = -1;
-    if (any_temporal) {
-        ts_t = mskf_t_begin(ctx, MSKF_K_LK);
-        fe_launch_lk(ctx->desc[1].d, n, max_pts, 0, st);
-        mskf_t_end(ctx, ts_t, 0);
-    }
-    const int ts_g0 = mskf_t_begin(ctx, MSKF_K_PT_GEOM);
-    fe_launch_pt_geom(ctx->desc[1].d, n, max_pts, 0, st);
-    mskf_t_end(ctx, ts_g0, 0);
-    const int ts_s = mskf_t_begin(ctx, MSKF_K_LK);
-    fe_launch_lk(ctx->desc[1].d, n, max_pts, 1, st);
-    mskf_t_end(ctx, ts_s, 0);
-    const int ts_g1 = mskf_t_begin(ctx, MSKF_K_PT_GEOM);
-    fe_launch_pt_geom(ctx->desc[1].d, n, max_pts, 1, st);
-    mskf_t_end(ctx, ts_g1, 0);
+    // temporal track -> bounds gate + stereo guess -> stereo track -> gates + undistortion: one launch (k_track4)
+    const int ts = mskf_t_begin(ctx, MSKF_K_LK);
+    fe_launch_track(ctx->desc[1].d, n, max_pts, st);
+    mskf_t_end(ctx, ts, 0);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
     MSKF_HIPCHK(hipGetLastError());
     if ((rc = mskf_wait_event(ctx, &ctx->pend_trk.done, true)) != MSKF_OK) return rc;
     ctx->pend_trk.active = true; ctx->pend_trk.n = n; ctx->pend_trk.args = args;
-    ctx->pend_trk.ts_t = ts_t; ctx->pend_trk.ts_s = ts_s; ctx->pend_trk.ts_g0 = ts_g0; ctx->pend_trk.ts_g1 = ts_g1;
-    ctx->host_s[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
+    ctx->pend_trk.ts = ts;
+    if (ctx->t_gate) ctx->host_s[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
     return MSKF_OK;
 }
 
@@ -575,12 +569,12 @@ extern "C" int mskf_fe_track_batch_end(mskf_ctx *ctx) {
     if (!ctx->pend_trk.active) return MSKF_OK;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     int rc;
+    ctx->pend_trk.active = false;      // also when the wait fails (timeout, stream error): the context must stay usable for a retry or a teardown
     if ((rc = mskf_wait_event(ctx, &ctx->pend_trk.done, false)) != MSKF_OK) return rc;
-    ctx->pend_trk.active = false;
     const int n = ctx->pend_trk.n;
     const mskf_fe_track_args *args = ctx->pend_trk.args;
     const std::vector<size_t> &out_off = ctx->pend_trk.out_off;
-    const int ts_t = ctx->pend_trk.ts_t, ts_s = ctx->pend_trk.ts_s, ts_g0 = ctx->pend_trk.ts_g0, ts_g1 = ctx->pend_trk.ts_g1;
+    const int ts = ctx->pend_trk.ts;
     const auto t_h1 = std::chrono::steady_clock::now();
     long long tracks_t = 0, tracks_s = 0, pts = 0;
     for (int i = 0; i < n; ++i) {
@@ -599,12 +593,10 @@ extern "C" int mskf_fe_track_batch_end(mskf_ctx *ctx) {
         if (a.do_temporal) { tracks_t += (long long)np; for (size_t k = 0; k < np; ++k) tracks_s += (a.status[k] & 1); }
         else tracks_s += (long long)np;
     }
-    if (ts_t >= 0) ctx->t_pending[ts_t].units = tracks_t;
-    if (ts_s >= 0) ctx->t_pending[ts_s].units = tracks_s;
-    if (ts_g0 >= 0) ctx->t_pending[ts_g0].units = pts;
-    if (ts_g1 >= 0) ctx->t_pending[ts_g1].units = pts;
+    if (ts >= 0) ctx->t_pending[ts].units = tracks_t + tracks_s;      // point tracks of the launch: temporal + stereo
+    (void)pts;
     mskf_t_collect(ctx);
-    ctx->host_s[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
+    if (ctx->t_gate) ctx->host_s[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
     return MSKF_OK;
 }
 

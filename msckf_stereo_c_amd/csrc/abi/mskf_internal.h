@@ -17,8 +17,7 @@ void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_
 // spinning in hipStreamSynchronize, leaving the core to the other groups' host phases.
 int mskf_wait(mskf_ctx *c);
 void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st);
-void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st);
-void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st);
+void fe_launch_track(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st);
 }
 
 void mskf_set_error(const std::string &s);
@@ -56,6 +55,7 @@ struct TimingSlot { hipEvent_t a, b; int kind; long long units; };
 
 struct mskf_ctx {
     bool timing = false;
+    bool t_gate = true;                          // mskf_ctx_timing_gate: launches begun (and host seconds spent) while it is off are not accounted
     int timing_period = 1;                       // every n-th launch of a kind is timed (mskf_ctx_set_timing)
     long long t_all[MSKF_K_COUNT] = {0};         // launches of a kind since the last reset, timed or not
     double host_s[4] = {0, 0, 0, 0};   // host seconds inside the batched entry points: [0] update pack, [1] update unpack, [2] track pack, [3] track unpack
@@ -87,7 +87,7 @@ struct mskf_ctx {
     // a batch between its *_begin and *_end call (one of each kind per context)
     struct PendingTrack {
         bool active = false; int n = 0; const mskf_fe_track_args *args = nullptr;
-        std::vector<size_t> out_off; int ts_t = -1, ts_s = -1, ts_g0 = -1, ts_g1 = -1;
+        std::vector<size_t> out_off; int ts = -1;
         hipEvent_t done = nullptr;
     } pend_trk;
     struct PendingUpdate {

@@ -49,13 +49,18 @@ struct EkfStreamDev {
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
     double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
+    int route;                // which kernels handle this stream's update, decided per STREAM from its own features (never from
+                              // the rest of the batch, so a stream's arithmetic does not depend on its neighbours): bit 0 pair
+                              // kernels (every feature has exactly the same two Jacobian clones), bit 1 wave-per-feature class
+                              // (every feature <= 4 observations), bit 2 fused small update (at most 4 clones touched)
     int qr_mode;              // mskf_ekf_cfg.compression_mode: 0 auto (Gram + Cholesky, Householder TSQR when flagged), 1 Gram only, 2 TSQR always
     const int *tri_idx;       // features that need triangulation (pair path: k_ekf_triangulate), n_tri of them
     int n_tri;
     int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns,
                               // [3] compression diagnostics: bit 0 = Householder TSQR used, bit 1 = the lambda prior of the Gram path
-                              //     would bias P by more than QR_BIAS_LIMIT, bit 2 = no compression (rows <= active columns: the
-                              //     stacked rows themselves are the measurement), bits 8.. = pivots of the Gram factor below 100 lambda
+                              //     would bias P by more than QR_BIAS_LIMIT (auto mode then re-does the compression as TSQR), bit 2 = no
+                              //     compression (last stacked row <= active columns: the stacked rows themselves are the measurement),
+                              //     bits 8.. = pivots of the Gram factor below 100 lambda (reported only)
                               // [4] nk = rows of the compressed measurement = dimension of S: na, or rows_out[1] without compression
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)

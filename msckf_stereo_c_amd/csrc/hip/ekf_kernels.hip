@@ -867,6 +867,7 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
 // gamma = r_o^T (H_o P_cc H_o^T + sigma^2 I)^-1 r_o against chi2[2 + dof_offset].
 __global__ __launch_bounds__(64) void k_ekf_triangulate(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
+    if (!(S.route & 1)) return;        // not a pair-route stream (the route is a property of the stream, ekf_device.h)
     __shared__ TriScratch sTri;
     for (int t = blockIdx.x; t < S.n_tri; t += gridDim.x) {
         const int j = S.tri_idx[t];
@@ -884,6 +885,7 @@ __global__ __launch_bounds__(64) void k_ekf_triangulate(const EkfStreamDev *stre
 #define PAIR_SLAB 153          // doubles per thread: X 8 x 13 (104) + H_f 8 x 3 (24) + V 3 x 8 (24) + 1 (odd stride: no bank conflicts)
 __global__ __launch_bounds__(64) void k_ekf_pair_blocks(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
+    if (!(S.route & 1)) return;
     const int d = S.d, ld = S.ld;
     extern __shared__ double s_pair[];
     __shared__ double sPcc[12 * 12];
@@ -1168,10 +1170,10 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunc
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);
 }
-// work_small / work_big: the work lists of the two size classes (see the kernel); with wave_per_feature every feature of
-// the batch has <= 4 Jacobian observations and all of them are in work_wave
+// work_wave / work_small / work_big: the work lists of the three size classes (see the kernel); work_wave holds the
+// features of the streams whose features all have <= 4 Jacobian observations (route bit 1)
 void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave, const int *work_small, int n_small, const int *work_big, int n_big,
-                         int max_rows, int max_rows_small, int wave_per_feature, hipStream_t st) {
+                         int max_rows, int max_rows_small, int big_clones, hipStream_t st) {
     const int packed_max = ((GATE_LDS_ROWS + 1) * (GATE_LDS_ROWS + 2) / 2 + 16) * (int)sizeof(double);   // + the r_o row + slack
     const int tri_doubles = (int)((sizeof(TriScratchT<2 * TRI_SMALL_CLONES>) + 7) / 8);
     static std::once_flag attr_once;
@@ -1181,12 +1183,11 @@ void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_feature_blocks<4, true, WG>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * tri_doubles * 8);
     });
     const int ALL = 1 << 30;
-    if (wave_per_feature) {
-        // every feature has <= 4 Jacobian observations (and its triangulation fits the small scratch): one wavefront per feature, four per workgroup
-        if (n_wave > 0)
-            hipLaunchKernelGGL((k_ekf_feature_blocks<4, true, WG>), dim3((n_wave + 3) / 4), dim3(WG), (size_t)4 * tri_doubles * 8, st, d, work_wave, n_wave, 16, tri_doubles, 0, ALL);
-        return;
-    }
+    // streams whose features ALL have <= 4 Jacobian observations (and triangulations that fit the small scratch): one
+    // wavefront per feature, four per workgroup.  The class is a property of the stream (route bit 1), so its work list
+    // holds whole streams and the other two lists none of their features.
+    if (n_wave > 0)
+        hipLaunchKernelGGL((k_ekf_feature_blocks<4, true, WG>), dim3((n_wave + 3) / 4), dim3(WG), (size_t)4 * tri_doubles * 8, st, d, work_wave, n_wave, 16, tri_doubles, 0, ALL);
     // small class: features of at most FEAT_SMALL_CLONES observations (Jacobian and triangulation), one wavefront each.
     // (A third class of <= 8 observations, 12 KiB of LDS and eight features per CU, was measured and dropped: every class
     // launch is a single latency-bound round, so a further split only adds another round to the chain.)
@@ -1202,7 +1203,8 @@ void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave
     if (lds < sizeof(TriScratch)) lds = sizeof(TriScratch);
     // (The two class launches are independent, but an any-order launch of the second one, hipExtAnyOrderLaunch, is not
     // honoured on gfx9: the trace shows it starting when the first ends.)
-    if (max_rows <= 4 * 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
+    // (instantiation by the streams' configured window, not by the largest feature that happens to be in the batch)
+    if (big_clones <= 32) hipLaunchKernelGGL((k_ekf_feature_blocks<32, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
     else hipLaunchKernelGGL((k_ekf_feature_blocks<MAX_CLONES_DEV, false, WG>), dim3(n_big), dim3(WG), lds, st, d, work_big, n_big, lds_rows, 0, FEAT_SMALL_CLONES + 1, ALL);
 }
 // pruning update: every feature of every stream has exactly two Jacobian observations (the host checked)

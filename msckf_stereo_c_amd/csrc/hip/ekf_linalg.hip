@@ -1,8 +1,8 @@
 // ekf_linalg.hip — batched dense FP64 building blocks of the Kalman update (msckf_vio.cpp:795-904),
 // one job per VIO stream, blockIdx.y = stream of the batch:
 //
-//  k_ekf_gemm   : 32x32 output tile per workgroup, v_mfma_f64_16x16x4_f64 (one 16x16 sub-tile per wave,
-//                 K staged through LDS 32 at a time, next stage prefetched into registers).  Modes:
+//  k_ekf_gemm   : 32x32 output tile per wavefront (64-thread workgroup), v_mfma_f64_16x16x4_f64, 2 x 2 sub-tiles = four
+//                 accumulators, K staged through LDS 32 at a time, next stage prefetched into registers.  Modes:
 //                   GRAM  G  = [Hs|rs]^T [Hs|rs]          ((d+1)x(d+1), replaces the QR: G = R^T R, last row = (Q^T r)^T R)
 //                   T     T  = R P,  R = L^T upper        (skips the zero half of R)
 //                   S2    S  = T R^T + sigma^2 I          (symmetric, lower computed and mirrored)
@@ -30,13 +30,25 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Gram + regularised Cholesky adds a prior lambda I to the stacked information H^T H / sigma^2: the posterior covariance
 // moves by about lambda max(P_aa) / sigma^2 relative.  Above this limit (or when the stack has no more rows than active
-// columns) the compression runs as Householder TSQR instead (k_ekf_qr), which has no such term.
+// columns) the compression runs as Householder TSQR instead (tsqr16), which has no such term.
 #define QR_BIAS_LIMIT 1e-6
-// auto mode, stack with no more rows than active columns (the reference compresses nothing there, msckf_vio.cpp:818-821):
-// the Gram pass and its factorisation are skipped, k_ekf_qr triangularises the few rows directly
-__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[1] <= S.rows_out[2]); }
-// the stream's stacked rows are used uncompressed (decided by k_ekf_qr): R = H_act (rows_out[1] x na, dense, rowmask-gathered)
+// How a stream's stack is compressed is decided from ONE pair of numbers everywhere (the GRAM pass, the factorisation
+// kernels, the fused small update): st = rows_out[0], the rows actually stacked, and na = rows_out[2], the active columns.
+//   * st <= na (auto mode): the reference compresses nothing there (msckf_vio.cpp:818-821) and H^T H would be singular by
+//     construction, so the Gram path is never taken.  When also me = rows_out[1] (last stacked row + 1, i.e. with the gaps
+//     that gated-out blocks leave) <= na, the rows themselves are the measurement ("direct": R = H_act, me x na, zero rows
+//     in the gaps); with gaps beyond that (st <= na < me) the rows would not fit the na-row work buffers and the stack is
+//     triangularised by the Householder TSQR instead, which is the same measurement rotated.
+//   * otherwise Gram + regularised Cholesky, re-done as TSQR when the factorisation raises the bias flag (bit 1).
+__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]); }
+__device__ __forceinline__ bool ekf_direct_wanted(const EkfStreamDev &S) { return S.qr_mode == 0 && S.rows_out[1] <= S.rows_out[2]; }
+// the stream's stacked rows are used uncompressed (set by the factorisation kernel): R = H_act (rows_out[1] x na, dense, rowmask-gathered)
 __device__ __forceinline__ bool ekf_direct(const EkfStreamDev &S) { return (S.rows_out[3] & 4) != 0; }
+// streams whose whole update runs in k_ekf_small_update (route bit, set per STREAM by the host: at most SU_MAX_NA active
+// columns possible); the general kernels leave them alone and vice versa
+#define EKF_ROUTE_PAIRS 1
+#define EKF_ROUTE_WAVE 2
+#define EKF_ROUTE_SMALL 4
 
 enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
 
@@ -50,21 +62,28 @@ template <> struct GemmTraits<GM_PUPD> { static constexpr bool TA = true,  SYM =
 
 #define GT 32      // output tile edge
 #ifndef GK
-#define GK 32      // K per LDS stage (64 measured slower: 49 vs 41 us per launch, the LDS footprint halves the workgroups per CU)
+#define GK 32      // K per LDS stage
 #endif
-#define GNE (GK / 8)   // elements of each operand per thread and stage
+#define GWG 64     // threads per workgroup: ONE wavefront owns a whole 32 x 32 output tile
+#define GHI (GWG / 32)
+#define GNE (GK / GHI)   // elements of each operand per thread and stage
 
-// One 32x32 output tile per workgroup (one 16x16 MFMA sub-tile per wave).  (Tried in round 2: 64x64 tiles with a 2x2 block
-// of sub-tiles per wave, i.e. half the LDS reads per MFMA.  2.6 x SLOWER at the C2 shapes, 109 vs 42 us per launch: with
-// na = 100..175 a stream has 3..6 such tiles, the launch no longer fills the CUs, and a workgroup is bound by the latency of
-// its ~22 K stages, not by feeding the matrix pipe.)  The K loop is software pipelined:
-// the global loads of stage s+1 are issued into registers before the MFMAs of stage s, so a stage costs an LDS
-// round trip instead of an HBM/L2 round trip.
+// One 32 x 32 output tile per WAVEFRONT (a 64-thread workgroup): a 2 x 2 block of 16 x 16 MFMA sub-tiles, i.e. four
+// independent accumulators, fed from two A and two B values per k-step, so every LDS read feeds two
+// v_mfma_f64_16x16x4_f64 (round 2: one sub-tile per wave of a 256-thread workgroup, two LDS reads per MFMA, two
+// workgroup barriers per K stage; counters: matrix pipes busy 20 % of the time).  A one-wave workgroup needs no barrier
+// at all: its LDS operations execute in program order (the next stage is written over the tile the MFMA operands were
+// just read from), and the global loads of stage s + 1 are in flight (registers) while the 32 MFMAs of stage s — 2048
+// cycles of matrix-pipe time, about one L2 round trip — issue.  17 KiB of LDS per wave: nine tiles in flight per CU.
+// The tile count per stream is what it was
+// (the 64 x 64-per-workgroup variant of round 2 lost on occupancy, not on this).  Diagonal tiles of the symmetric modes
+// skip the upper-right sub-tile.  Sums over k run in the same order as before: results are bit-identical to round 2.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
+__global__ __launch_bounds__(GWG) void k_ekf_gemm(const EkfStreamDev *streams) {
     using TR = GemmTraits<MODE>;
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
+    if (MODE != GM_PUPD && (S.route & EKF_ROUTE_SMALL)) return;
     if (MODE == GM_GRAM && ekf_skip_gram(S)) return;
     const int d = S.d, ld = S.ld;
     const int na = S.rows_out[2];                  // active columns (compact index i <-> column act[i])
@@ -80,24 +99,27 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     else if (MODE == GM_PUPD) { A = S.T;  B = S.T;  C = S.P; M = N = d; K = nk; alpha = -1.0; beta = 1.0; }   // P -= Y^T Y
     const int tiles_n = (N + GT - 1) / GT, tiles_m = (M + GT - 1) / GT;
     const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid;
     if (MODE == GM_PUPD && tile >= tiles_m * tiles_n) {
         // tiles_n extra workgroups: delta_x = Y^T w, w = column d of Y (msckf_vio.cpp:860); 32 columns each,
-        // the K range split over the 8 thread rows and reduced through LDS
+        // the K range split over the two thread rows and added in a fixed order
         const int c0 = (tile - tiles_m * tiles_n) * GT;
         if (c0 >= d) return;
         const double *Y = S.T;
-        __shared__ double s_part[8][GT + 1];
-        const int cl = threadIdx.x & 31, ks = threadIdx.x >> 5;
+        const int cl = tid & 31, ks = tid >> 5;
         const int c = c0 + cl;
-        double s2 = 0;
+        // (eight interleaved partial sums, as the 256-thread version had: the result keeps its bits)
+        double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (c < d)
-            for (int k = ks; k < nk; k += 8) s2 += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
-        s_part[ks][cl] = s2;
+            for (int k = ks; k < nk; k += GHI) p8[k & 7] += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
+        __shared__ double s_p8[GHI][8][GT + 1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_p8[ks][q][cl] = p8[q];
         __syncthreads();
         if (ks == 0 && c < d) {
             double t = 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t += s_part[q][cl];
+            for (int q = 0; q < 8; ++q) t += s_p8[0][q][cl] + s_p8[1][q][cl];     // one of the two is an exact zero (k & 7 has k's parity)
             S.delta_x[c] = t;
         }
         return;
@@ -106,11 +128,10 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     const int ti = tile / tiles_n, tj = tile - ti * tiles_n;
     if (TR::SYM && tj > ti) return;
     const int i0 = ti * GT, j0 = tj * GT;
+    const bool diag_tile = TR::SYM && ti == tj;
     __shared__ double sA[GK][GT + 1];   // sA[k][i]
     __shared__ double sB[GK][GT + 1];   // sB[k][j]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
-    const int lo = tid & 31, hi = tid >> 5;          // hi in [0,8)
+    const int lo = tid & 31, hi = tid >> 5;          // hi in [0, GHI)
     int k_begin = 0;
     if (TR::KMIN_I && !direct) k_begin = (i0 / GK) * GK;
     if (TR::KMIN_J && !direct) k_begin = (j0 / GK) * GK;
@@ -131,21 +152,23 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
 #pragma unroll
         for (int e = 0; e < GNE; ++e) {
             if (MODE == GM_GRAM) {
-                // both operands are (column = lo, row = hi + 8 e) of [H | r]
-                const int gk = k0 + hi + 8 * e;
+                // both operands are (column = lo, row = hi + GHI e) of [H | r]
+                const int gk = k0 + hi + GHI * e;
                 double v = 0.0, w = 0.0;
                 if (gk < K) {
                     const unsigned long long rm = rowmask[gk];
                     const bool onA = cloneA < 0 ? rm != 0ULL : ((rm >> cloneA) & 1ULL) != 0ULL;
                     const bool onB = cloneB < 0 ? rm != 0ULL : ((rm >> cloneB) & 1ULL) != 0ULL;
                     if (onA && i0 + lo < M) v = A[(size_t)gk * ld + colA];
-                    if (onB && j0 + lo < N) w = B[(size_t)gk * ld + colB];
+                    if (onB && j0 + lo < N && !diag_tile) w = B[(size_t)gk * ld + colB];
+                    if (diag_tile) w = v;                 // the same column of the same row
                 }
                 ra[e] = v; rb[e] = w;
                 continue;
             }
-            // A: TA -> (i = lo, k = hi + 8e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + 8e) reads A[i*ld + k]
-            const int ii = TR::TA ? lo : hi + 8 * (e / (GK / 32)), kk = TR::TA ? hi + 8 * e : lo + 32 * (e % (GK / 32));
+            // A: TA -> (i = lo, k = hi + GHI e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + GHI e) reads A[i*ld + k]
+            // (GK == 32: one 32-wide k range per stage)
+            const int ii = TR::TA ? lo : hi + GHI * e, kk = TR::TA ? hi + GHI * e : lo;
             const int gi = i0 + ii, gk = k0 + kk;
             double v = 0.0;
             if (gi < M && gk < K && !(TR::KMIN_I && !direct && gk < gi)) {
@@ -154,10 +177,10 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
                     const int col = act[gk];
                     if ((rowmask[gi] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) v = A[(size_t)gi * ld + col];
                 }
-                else v = A[(size_t)gk * ld + (MODE == GM_GRAM ? colA : gi)];
+                else v = A[(size_t)gk * ld + gi];
             }
             ra[e] = v;
-            const int gj = j0 + lo, gkb = k0 + hi + 8 * e;
+            const int gj = j0 + lo, gkb = k0 + hi + GHI * e;
             double w = 0.0;
             if (gj < N && gkb < K && !(TR::KMIN_J && !direct && gkb < gj)) {
                 if (MODE == GM_T) w = B[(size_t)act[gkb] * ld + gj];             // P[act, :]
@@ -165,43 +188,159 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
                     const int col = act[gkb];
                     if ((rowmask[gj] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) w = B[(size_t)gj * ld + col];
                 }
-                else w = B[(size_t)gkb * ld + (MODE == GM_GRAM ? colB : gj)];
+                else w = B[(size_t)gkb * ld + gj];
             }
             rb[e] = w;
         }
     };
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    if (k_begin < k_end) fetch(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += GK) {
-        __syncthreads();
+    static_assert(GK == 32, "the non-transposed A loader covers one 32-wide k range per stage");
+    auto stash = [&]() {
 #pragma unroll
         for (int e = 0; e < GNE; ++e) {
-            if (TR::TA) sA[hi + 8 * e][lo] = ra[e]; else sA[lo + 32 * (e % (GK / 32))][hi + 8 * (e / (GK / 32))] = ra[e];
-            sB[hi + 8 * e][lo] = rb[e];
+            if (TR::TA) sA[hi + GHI * e][lo] = ra[e]; else sA[lo][hi + GHI * e] = ra[e];
+            sB[hi + GHI * e][lo] = rb[e];
         }
-        __syncthreads();
-        if (k0 + GK < k_end) fetch(k0 + GK);
+    };
+    v4f64 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += GK) {
+        // one wavefront: the reads of the previous stage were issued before these writes and LDS executes a wave's
+        // operations in order, so the tile can be overwritten in place
+        stash();
+        if (k0 + GK < k_end) fetch(k0 + GK);          // global loads of the next stage fly during this stage's MFMAs
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             const int kk = 4 * s + (lane >> 4);
-            const double a = sA[kk][wi + (lane & 15)];
-            const double b = sB[kk][wj + (lane & 15)];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            const double a0 = sA[kk][lane & 15], a1 = sA[kk][16 + (lane & 15)];
+            const double b0 = sB[kk][lane & 15], b1 = sB[kk][16 + (lane & 15)];
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
+            if (!diag_tile) acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // epilogue: lane holds D[row = (lane>>4) + 4 r][col = lane & 15] of each sub-tile
+    auto store = [&](const v4f64 &acc, int wi, int wj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wi + (lane >> 4) + 4 * r;
+            const int j = j0 + wj + (lane & 15);
+            if (i >= M || j >= N) continue;
+            if (TR::SYM && j > i) continue;             // diagonal tiles: lower part only, mirrored below
+            double v = alpha * acc[r];
+            if (MODE == GM_PUPD) v += beta * C[(size_t)i * ld + j];
+            if (i == j) v += diag_add;
+            C[(size_t)i * ld + j] = v;
+            if (TR::SYM && i != j) C[(size_t)j * ld + i] = v;
+        }
+    };
+    store(acc00, 0, 0); store(acc10, 16, 0); store(acc11, 16, 16);
+    if (!diag_tile) store(acc01, 0, 16);
+}
+
+// ------------------------------------------------------------------------------------ Householder TSQR
+// The reference compresses the stacked Jacobian with a Householder QR (SPQR / Eigen HouseholderQR, msckf_vio.cpp:795-817).
+// The default here is the Gram matrix + a regularised Cholesky (one MFMA pass, fully parallel), which squares the
+// condition number of H and adds the prior lambda I.  The Kalman update itself is regularised by P, so what that costs is
+// bounded by lambda max(P_aa) / sigma^2 whatever cond(H) is (measured: tests/test_gpu_kernels.py, condition sweep); the
+// factorisation evaluates that bound and this path takes over when it exceeds QR_BIAS_LIMIT, when the stack has no more
+// rows than active columns (the reference's m <= d case: nothing is compressed there, :818-821; H^T H would be singular
+// by construction), or always with compression_mode = 2.
+// Row-block TSQR: the upper-triangular R of [H_act | r] (n1 = na + 1 columns, the residual rides along as the last one)
+// stays resident (LDS, packed by rows, when it fits; the stream's W buffer otherwise); the stacked rows are
+// streamed through LDS sixteen at a time and annihilated column by column against R's diagonal with Householder
+// reflectors of length 17.  Called by every thread of the workgroup; thread j owns column j of the block during a step.
+// colOf(c, col, clone): source column of compact column c in [H | r] and the clone whose rowmask bit guards it (-1: residual).
+// (Round 2 ran this as a kernel of its own, launched after the Gram factorisation of EVERY update just to find that nothing
+// was to do: 1.6 % of the kernel time of the bench and one more link in the update's dependency chain.  The factorisation
+// kernels call it now, with their own LDS: the packed factor's space holds R, the panel's the row block.)
+#define QR_BR 16
+template <class ColOf, class RAt>
+__device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, ColOf colOf, RAt Rat, double *sB) {
+    const int tid = threadIdx.x, nth = blockDim.x, ld = S.ld;
+    for (int k0 = 0; k0 < K; k0 += QR_BR) {
+        __syncthreads();
+        for (int e = tid; e < QR_BR * n1; e += nth) {
+            const int r = e / n1, c = e - r * n1, gk = k0 + r;
+            double v = 0.0;
+            if (gk < K) {
+                int col, clone;
+                colOf(c, col, clone);
+                const unsigned long long rm = S.rowmask[gk];
+                const bool on = clone < 0 ? rm != 0ULL : ((rm >> clone) & 1ULL) != 0ULL;
+                if (on) v = S.Hs[(size_t)gk * ld + col];
+            }
+            sB[e] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < n1; ++k) {
+            double bk[QR_BR];
+            double ss = 0.0;
+#pragma unroll
+            for (int i = 0; i < QR_BR; ++i) { bk[i] = sB[i * n1 + k]; ss += bk[i] * bk[i]; }
+            // Nothing (left) in this column of the block: structurally zero, or what earlier reflectors of this block left
+            // of it.  Rounding residue shrinks by ~1e-16 per generation of 16 reflectors; once its square leaves the
+            // normal range 2 / (v0^2 + ss) overflows, and far above that it is already meaningless: below 1e-40 of
+            // R_kk^2 (or 1e-200 absolute) the column counts as annihilated.  Uniform: every thread reads the same values.
+            const double x0 = Rat(k, k);
+            if (ss < 1e-200 || ss < 1e-40 * (x0 * x0)) continue;
+            const double nrm = sqrt(x0 * x0 + ss);
+            const double alpha = x0 > 0.0 ? -nrm : nrm;
+            const double v0 = x0 - alpha;
+            const double beta = 2.0 / (v0 * v0 + ss);
+            for (int j = k + 1 + tid; j < n1; j += nth) {
+                double dot = v0 * Rat(k, j);
+#pragma unroll
+                for (int i = 0; i < QR_BR; ++i) dot += bk[i] * sB[i * n1 + j];
+                const double t = beta * dot;
+                Rat(k, j) -= t * v0;
+#pragma unroll
+                for (int i = 0; i < QR_BR; ++i) sB[i * n1 + j] -= t * bk[i];
+            }
+            __syncthreads();
+            if (tid == 0) Rat(k, k) = alpha;
         }
     }
-    // epilogue: lane holds D[row = (lane>>4) + 4 r][col = lane & 15]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wi + (lane >> 4) + 4 * r;
-        const int j = j0 + wj + (lane & 15);
-        if (i >= M || j >= N) continue;
-        if (TR::SYM && j > i) continue;             // diagonal tiles: lower part only, mirrored below
-        double v = alpha * acc[r];
-        if (MODE == GM_PUPD) v += beta * C[(size_t)i * ld + j];
-        if (i == j) v += diag_add;
-        C[(size_t)i * ld + j] = v;
-        if (TR::SYM && i != j) C[(size_t)j * ld + i] = v;
+    __syncthreads();
+}
+
+// What the Gram factorisation kernels do for a stream BEFORE factoring (which == 0 only).  Returns 0: factor the Gram
+// matrix; 1: the stack is used uncompressed and everything is set up (the kernel returns); 2: no Gram matrix was formed,
+// go straight to the TSQR.
+__device__ __forceinline__ int ekf_compress_entry(const EkfStreamDev &S) {
+    const int na = S.rows_out[2], me = S.rows_out[1], d = S.d, ld = S.ld;
+    if (na <= 0) { if (threadIdx.x == 0) S.rows_out[3] = 0; return 1; }
+    if (ekf_direct_wanted(S)) {
+        // The reference's m <= d case (msckf_vio.cpp:818-821): no more stacked rows than active columns, nothing to
+        // compress.  The rows themselves are the measurement: R = H_act (me x na, read through the rowmask by the T and
+        // S GEMMs), Q^T r = r, S is me x me.  (Rows of blocks that were not stacked are zero rows: sigma^2 on S's diagonal.)
+        for (int i = threadIdx.x; i < me; i += blockDim.x) S.T[(size_t)i * ld + d] = S.rowmask[i] ? S.Hs[(size_t)i * ld + d] : 0.0;
+        if (threadIdx.x == 0) { S.rows_out[3] = 4; S.rows_out[4] = me; }
+        return 1;
     }
+    return ekf_skip_gram(S) ? 2 : 0;
+}
+// ... and AFTER it: Householder TSQR instead, for the streams that need it (forced, no Gram matrix formed, or the bias flag
+// of the factorisation just done), handed over in the layout the update expects: S.S = L = R^T (lower, ld-wide rows),
+// column d of T = Q^T r.  Rat(k, j): the resident R (zeroed here); sB: QR_BR x n1 doubles.
+template <class RAt>
+__device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gram_done, int diag, RAt Rat, double *sB) {
+    const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], d = S.d, ld = S.ld;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && (!gram_done || (diag & 2)));
+    if (!need) { if (tid == 0) S.rows_out[3] = diag; return; }
+    __syncthreads();
+    for (int e = tid; e < n1 * n1; e += nth) { const int k = e / n1, j = e - k * n1; if (j >= k) Rat(k, j) = 0.0; }
+    const int *act = S.act;
+    tsqr16(S, n1, K, [=](int c, int &col, int &clone) { col = c < na ? act[c] : d; clone = c < na ? (col - EKF_IMU_DIM) / 6 : -1; }, Rat, sB);
+    for (int e = tid; e < na * na; e += nth) {
+        const int i = e / na, j = e - i * na;
+        if (j <= i) S.S[(size_t)i * ld + j] = Rat(j, i);
+    }
+    for (int k = tid; k < na; k += nth) S.T[(size_t)k * ld + d] = Rat(k, na);
+    if (tid == 0) S.rows_out[3] = diag | 1;
 }
 
 // ------------------------------------------------------------------------------------ Cholesky
@@ -213,8 +352,9 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
 #define CHOLG_THREADS 512
 __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *streams, int which, int pan_rs) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_feat <= 0) return;
-    if (which == 0 && ekf_skip_gram(S)) { if (threadIdx.x == 0) S.rows_out[3] = 0; return; }
+    if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
+    int entry = 0;
+    if (which == 0) { entry = ekf_compress_entry(S); if (entry == 1) return; }
     const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
     const int nt = n + (which == 0 ? 1 : 0);              // + the extra Q^T r row of the Gram factorisation
     const int lda = S.ld;
@@ -222,8 +362,15 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     extern __shared__ double s_dyn[];
     double *sPanT = s_dyn;                                // [LNB][pan_rs]
     __shared__ double s_tol, s_mx[CHOLG_THREADS / 64];
+    __shared__ int s_diag;
     __shared__ CholBlockShared s_cb;
     const int tid = threadIdx.x;
+    if (tid == 0) s_diag = 0;
+    if (entry == 2) {   // no Gram matrix: Householder TSQR, R in the stream's W buffer (ld-wide rows), the row block in the panel's space
+        double *Rg = S.W;
+        ekf_compress_exit(S, false, 0, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT);
+        return;
+    }
     for (int e = tid; e < LNB * pan_rs; e += CHOLG_THREADS) sPanT[e] = 0.0;
     if (which == 0) {
         // regularised factorisation G + lambda I, lambda = 1e-14 d max(diag G) (see k_ekf_chol_lds)
@@ -240,7 +387,7 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     __syncthreads();
     chol_blocked_lds<CHOLG_THREADS / 64>(A, [lda](int i, int j) { return i * lda + j; }, n, nt, 0.0, sPanT, pan_rs, s_cb);
     if (which == 0) {
-        // pivots (L_kk^2) that end within 100 lambda of the regularisation floor: what k_ekf_qr decides on
+        // pivots (L_kk^2) that end within 100 lambda of the regularisation floor (reported in the diagnostics only)
         int tiny = 0;
         for (int i = tid; i < n; i += CHOLG_THREADS) { const double l = A[(size_t)i * lda + i]; tiny += (l * l < 100.0 * s_tol) ? 1 : 0; }
         for (int o = 32; o > 0; o >>= 1) tiny += __shfl_xor(tiny, o);
@@ -257,10 +404,13 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
         if (tid == 0) {
             int t = 0; for (int i = 0; i < CHOLG_THREADS / 64; ++i) t += s_tiny[i];
             double p = 0; for (int i = 0; i < CHOLG_THREADS / 64; ++i) p = fmax(p, s_mx[i]);
-            S.rows_out[3] = (t << 8) | ((s_tol * p > QR_BIAS_LIMIT * S.sigma2) ? 2 : 0);
+            s_diag = (t << 8) | ((s_tol * p > QR_BIAS_LIMIT * S.sigma2) ? 2 : 0);
         }
         // column d of T <- (Q^T r) = the extra row of L, so the TRSM carries w = L2^-1 Q^T r along
         for (int k = tid; k < n; k += CHOLG_THREADS) S.T[(size_t)k * lda + S.d] = A[(size_t)n * lda + k];
+        __syncthreads();
+        double *Rg = S.W;
+        ekf_compress_exit(S, true, s_diag, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT);
     }
 }
 
@@ -288,8 +438,9 @@ __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 
 __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_feat <= 0) return;
-    if (which == 0 && ekf_skip_gram(S)) { if (threadIdx.x == 0) S.rows_out[3] = 0; return; }
+    if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
+    int entry = 0;
+    if (which == 0) { entry = ekf_compress_entry(S); if (entry == 1) return; }
     double *A = which == 0 ? S.S : S.W;
     const int off = 0, lda = S.ld;                 // compact storage: index i <-> column act[i]
     const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
@@ -299,8 +450,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     double *sM = s_dyn;                            // packed lower, nt rows
     double *sPanT = s_dyn + nt * (nt + 1) / 2;     // [LNB][CHOL_PAN_RS]
     __shared__ double s_tol, s_mx[CHOL_WAVES];
+    __shared__ int s_diag;
     __shared__ CholBlockShared s_cb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_diag = 0;
+    // R of the TSQR lives where the packed factor does (packed upper by rows: the same n1 (n1 + 1) / 2 doubles), the row block in the panel's space
+    auto Rl = [=](int k, int j) -> double & { return sM[k * nt - k * (k - 1) / 2 + (j - k)]; };
+    if (entry == 2) { ekf_compress_exit(S, false, 0, Rl, sPanT); return; }
     // load: one matrix row per wave pass, coalesced along j
     // (8 rows x 3 column chunks = up to 24 loads in flight per lane: the copy is latency bound otherwise)
     for (int i0 = wave * 8; i0 < nt; i0 += CHOL_WAVES * 8) {
@@ -343,7 +499,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     const double tol = 0.0;      // a pivot <= 0 (cannot happen for G + lambda I or for S >= sigma^2 I) zeroes its column
     chol_blocked_lds<CHOL_WAVES>(sM, [](int i, int j) { return pk(i, j); }, n, nt, tol, sPanT, CHOL_PAN_RS, s_cb);
     if (which == 0) {
-        // pivots (L_kk^2) that end within 100 lambda of the regularisation floor: what k_ekf_qr decides on
+        // pivots (L_kk^2) that end within 100 lambda of the regularisation floor (reported in the diagnostics only)
         int tiny = 0;
         for (int i = tid; i < n; i += CHOL_THREADS) { const double l = sM[pk(i, i)]; tiny += (l * l < 100.0 * s_tol) ? 1 : 0; }
         for (int o = 32; o > 0; o >>= 1) tiny += __shfl_xor(tiny, o);
@@ -360,7 +516,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
         if (tid == 0) {
             int t = 0; for (int i = 0; i < CHOL_WAVES; ++i) t += s_tiny[i];
             double p = 0; for (int i = 0; i < CHOL_WAVES; ++i) p = fmax(p, s_mx[i]);
-            S.rows_out[3] = (t << 8) | ((s_tol * p > QR_BIAS_LIMIT * S.sigma2) ? 2 : 0);
+            s_diag = (t << 8) | ((s_tol * p > QR_BIAS_LIMIT * S.sigma2) ? 2 : 0);
         }
     }
     // store back
@@ -373,6 +529,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     if (which == 0) {
         // column d of T <- (Q^T r) = the extra row of L, so the TRSM carries w = L2^-1 Q^T r along
         for (int k = tid; k < n; k += CHOL_THREADS) S.T[(size_t)k * lda + S.d] = sM[pk(n, k)];
+        __syncthreads();
+        ekf_compress_exit(S, true, s_diag, Rl, sPanT);
     }
 }
 
@@ -384,7 +542,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
 #define TS_RB 16
 __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_feat <= 0) return;
+    if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     const int n = S.rows_out[4], ld = S.ld, ncols = S.d + 1;      // rows of the compressed measurement, all d+1 columns
     const int c0 = blockIdx.x * TS_COLS;
     if (c0 >= ncols) return;
@@ -466,108 +624,6 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
     }
 }
 
-// ------------------------------------------------------------------------------------ Householder TSQR
-// The reference compresses the stacked Jacobian with a Householder QR (SPQR / Eigen HouseholderQR, msckf_vio.cpp:795-817).
-// The default here is the Gram matrix + a regularised Cholesky (one MFMA pass, fully parallel), which squares the
-// condition number of H and adds the prior lambda I.  The Kalman update itself is regularised by P, so what that costs is
-// bounded by lambda max(P_aa) / sigma^2 whatever cond(H) is (measured: tests/test_gpu_kernels.py, condition sweep); the
-// factorisation evaluates that bound and this path takes over when it exceeds QR_BIAS_LIMIT, when the stack has no more
-// rows than active columns (the reference's m <= d case: nothing is compressed there, :818-821; H^T H would be singular
-// by construction), or always with compression_mode = 2.
-// Row-block TSQR: the upper-triangular R of [H_act | r] (n1 = na + 1 columns, the residual rides along as the last one)
-// stays resident (LDS, packed by rows, when it fits: na <= 174; the stream's W buffer otherwise); the stacked rows are
-// streamed through LDS sixteen at a time and annihilated column by column against R's diagonal with Householder
-// reflectors of length 17.  One 256-thread workgroup per stream: thread j owns column j of the block during a step.
-#define QR_BR 16
-template <class RAt>
-__device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, const int *s_col, const int *s_clone, RAt Rat, double *sB) {
-    const int tid = threadIdx.x, nth = blockDim.x, ld = S.ld;
-    for (int k0 = 0; k0 < K; k0 += QR_BR) {
-        __syncthreads();
-        for (int e = tid; e < QR_BR * n1; e += nth) {
-            const int r = e / n1, c = e - r * n1, gk = k0 + r;
-            double v = 0.0;
-            if (gk < K) {
-                const unsigned long long rm = S.rowmask[gk];
-                const bool on = s_clone[c] < 0 ? rm != 0ULL : ((rm >> s_clone[c]) & 1ULL) != 0ULL;
-                if (on) v = S.Hs[(size_t)gk * ld + s_col[c]];
-            }
-            sB[e] = v;
-        }
-        __syncthreads();
-        for (int k = 0; k < n1; ++k) {
-            double bk[QR_BR];
-            double ss = 0.0;
-#pragma unroll
-            for (int i = 0; i < QR_BR; ++i) { bk[i] = sB[i * n1 + k]; ss += bk[i] * bk[i]; }
-            // Nothing (left) in this column of the block: structurally zero, or what earlier reflectors of this block left
-            // of it.  Rounding residue shrinks by ~1e-16 per generation of 16 reflectors; once its square leaves the
-            // normal range 2 / (v0^2 + ss) overflows, and far above that it is already meaningless: below 1e-40 of
-            // R_kk^2 (or 1e-200 absolute) the column counts as annihilated.  Uniform: every thread reads the same values.
-            const double x0 = Rat(k, k);
-            if (ss < 1e-200 || ss < 1e-40 * (x0 * x0)) continue;
-            const double nrm = sqrt(x0 * x0 + ss);
-            const double alpha = x0 > 0.0 ? -nrm : nrm;
-            const double v0 = x0 - alpha;
-            const double beta = 2.0 / (v0 * v0 + ss);
-            for (int j = k + 1 + tid; j < n1; j += nth) {
-                double dot = v0 * Rat(k, j);
-#pragma unroll
-                for (int i = 0; i < QR_BR; ++i) dot += bk[i] * sB[i * n1 + j];
-                const double t = beta * dot;
-                Rat(k, j) -= t * v0;
-#pragma unroll
-                for (int i = 0; i < QR_BR; ++i) sB[i * n1 + j] -= t * bk[i];
-            }
-            __syncthreads();
-            if (tid == 0) Rat(k, k) = alpha;
-        }
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_ekf_qr(const EkfStreamDev *streams, int r_in_lds) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_feat <= 0) return;
-    const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], d = S.d, ld = S.ld;
-    const int diag = S.rows_out[3];
-    if (na <= 0) return;
-    if (S.qr_mode == 0 && K <= na) {
-        // The reference's m <= d case (msckf_vio.cpp:818-821): no more stacked rows than active columns, nothing to
-        // compress.  The rows themselves are the measurement: R = H_act (K x na, read through the rowmask by the T and
-        // S GEMMs), Q^T r = r, S is K x K.  (Rows of blocks that were not stacked are zero rows: sigma^2 on S's diagonal.)
-        for (int i = threadIdx.x; i < K; i += 256) S.T[(size_t)i * ld + d] = S.rowmask[i] ? S.Hs[(size_t)i * ld + d] : 0.0;
-        if (threadIdx.x == 0) { S.rows_out[3] = diag | 4; S.rows_out[4] = K; }
-        return;
-    }
-    const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && (diag & 2));
-    if (!need) return;
-    extern __shared__ double s_dyn[];
-    __shared__ int s_col[QR_MAX_N1], s_clone[QR_MAX_N1];
-    const int tid = threadIdx.x;
-    for (int c = tid; c < n1; c += 256) {
-        const int col = c < na ? S.act[c] : d;
-        s_col[c] = col;
-        s_clone[c] = c < na ? (col - EKF_IMU_DIM) / 6 : -1;
-    }
-    double *sB = s_dyn;                                  // QR_BR x n1
-    double *Rl = s_dyn + QR_BR * n1;                     // packed upper by rows (r_in_lds)
-    double *Rg = S.W;                                    // or the stream's W buffer, ld-wide rows
-    if (r_in_lds) { for (int e = tid; e < n1 * (n1 + 1) / 2; e += 256) Rl[e] = 0.0; }
-    else { for (int e = tid; e < n1 * ld; e += 256) Rg[e] = 0.0; }
-    __syncthreads();
-    if (r_in_lds) tsqr16(S, n1, K, s_col, s_clone, [=](int k, int j) -> double & { return Rl[k * n1 - k * (k - 1) / 2 + (j - k)]; }, sB);
-    else tsqr16(S, n1, K, s_col, s_clone, [=](int k, int j) -> double & { return Rg[(size_t)k * ld + j]; }, sB);
-    // hand over in the layout the update expects: S.S = L = R^T (lower, ld-wide rows), column d of T = Q^T r
-    auto Rv = [&](int k, int j) { return r_in_lds ? Rl[k * n1 - k * (k - 1) / 2 + (j - k)] : Rg[(size_t)k * ld + j]; };
-    for (int e = tid; e < na * na; e += 256) {
-        const int i = e / na, j = e - i * na;
-        if (j <= i) S.S[(size_t)i * ld + j] = Rv(j, i);
-    }
-    for (int k = tid; k < na; k += 256) S.T[(size_t)k * ld + d] = Rv(k, na);
-    if (tid == 0) S.rows_out[3] = diag | 1;
-}
-
 // ------------------------------------------------------------------------------------ small update, fused
 // The whole measurement update of a stream in ONE workgroup when the stack touches few clones (na <= SU_MAX_NA active
 // columns): the pruning update (msckf_vio.cpp:1073-1184) stacks hundreds of 2-observation features but only the two
@@ -580,7 +636,7 @@ __global__ __launch_bounds__(256) void k_ekf_qr(const EkfStreamDev *streams, int
 #define SU_CH 128         // stacked rows per Gram chunk
 __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
-    if (S.n_feat <= 0) return;
+    if (S.n_feat <= 0 || !(S.route & EKF_ROUTE_SMALL)) return;
     const int d = S.d, ld = S.ld, na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1];
     const int tid = threadIdx.x;
     if (na <= 0 || na > SU_MAX_NA) {            // nothing stacked (or a caller error): no correction, P unchanged
@@ -668,7 +724,7 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
         __syncthreads();
     }
-    // ---- 2b. the same decision as k_ekf_qr: near-zero pivots beyond the gauge, no more rows than columns, or forced ->
+    // ---- 2b. the same decision as ekf_compress_exit: bias flag, no more stacked rows than columns, or forced ->
     //          Householder TSQR of the stacked rows, R in sG (full rows), then L = R^T back in place
     {
         __shared__ int s_tiny, s_bias;
@@ -689,7 +745,7 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         if (need_qr) {
             for (int e = tid; e < n1 * n1; e += 256) sG[e] = 0.0;
             __syncthreads();
-            tsqr16(S, n1, K, s_col, s_clone, [=](int k, int j) -> double & { return sG[k * n1 + j]; }, sC);
+            tsqr16(S, n1, K, [&](int c, int &col, int &clone) { col = s_col[c]; clone = s_clone[c]; }, [=](int k, int j) -> double & { return sG[k * n1 + j]; }, sC);
             for (int e = tid; e < n1 * n1; e += 256) { const int i = e / n1, j = e - i * n1; if (j < i) sG[e] = sG[j * n1 + i]; }
             __syncthreads();
         }
@@ -765,10 +821,10 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
     const int t = (max_mn + GT - 1) / GT;
     const dim3 grid(t * t + (mode == GM_PUPD ? t : 0), n);
     switch (mode) {
-        case GM_GRAM: hipLaunchKernelGGL(k_ekf_gemm<GM_GRAM>, grid, dim3(256), 0, st, d); break;
-        case GM_T:    hipLaunchKernelGGL(k_ekf_gemm<GM_T>, grid, dim3(256), 0, st, d); break;
-        case GM_S2:   hipLaunchKernelGGL(k_ekf_gemm<GM_S2>, grid, dim3(256), 0, st, d); break;
-        default:      hipLaunchKernelGGL(k_ekf_gemm<GM_PUPD>, grid, dim3(256), 0, st, d); break;
+        case GM_GRAM: hipLaunchKernelGGL(k_ekf_gemm<GM_GRAM>, grid, dim3(GWG), 0, st, d); break;
+        case GM_T:    hipLaunchKernelGGL(k_ekf_gemm<GM_T>, grid, dim3(GWG), 0, st, d); break;
+        case GM_S2:   hipLaunchKernelGGL(k_ekf_gemm<GM_S2>, grid, dim3(GWG), 0, st, d); break;
+        default:      hipLaunchKernelGGL(k_ekf_gemm<GM_PUPD>, grid, dim3(GWG), 0, st, d); break;
     }
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
@@ -791,14 +847,6 @@ void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_
     hipLaunchKernelGGL(k_ekf_small_update, dim3(1, n), dim3(256), lds, st, d);
 }
 int ekf_small_update_max_na(void) { return SU_MAX_NA; }
-void ekf_launch_qr(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
-    const int n1 = max_d - EKF_IMU_DIM + 1;
-    const size_t blk = (size_t)QR_BR * n1 * sizeof(double), packed = (size_t)n1 * (n1 + 1) / 2 * sizeof(double);
-    const int r_in_lds = blk + packed <= 150 * 1024 ? 1 : 0;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_qr), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-    hipLaunchKernelGGL(k_ekf_qr, dim3(1, n), dim3(256), blk + (r_in_lds ? packed : 0), st, d, r_in_lds);
-}
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int strips = (max_d + 1 + TS_COLS - 1) / TS_COLS;
     // the solve runs over the active rows only: n <= max_d - 21 (the IMU columns are never active).  A full 64-clone

@@ -594,46 +594,14 @@ __device__ __forceinline__ void l4_weights(float fa, float fb, int &wtop, int &w
     wbot = (w10 & 0xffff) | (w11 << 16);
 }
 
-// Block -> (stream, point group): the blocks b and b + 8 share an XCD (round-robin dispatch, speed only), so the point
-// groups of ONE stream are given ids that are congruent modulo 8: a stream's pyramid levels then travel through one L2.
-__global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, int stereo, int n_streams, int groups_per_stream) {
-    const int x = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int si = x + 8 * (qb / groups_per_stream), gi = qb - (qb / groups_per_stream) * groups_per_stream;
-    if (si >= n_streams) return;
-    const FeStreamDev &S = streams[si];
-    if (4 * gi >= S.n_pts) return;
-    if (!stereo && !S.do_temporal) return;
-    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
-    const int pt = 4 * gi + g;
-    __shared__ uint32_t s_T[4][L4_TROWS * L4_DW + 2];
-    __shared__ uint32_t s_S[4][L4_SROWS * L4_DW + 4];
-    uint32_t *sT = s_T[g], *sS = s_S[g];
-
-    bool alive = pt < S.n_pts;
-    float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
-    if (alive) {
-        if (!stereo) {
-            const mskf_point2f pin = S.in_pts[pt];
-            // predictFeatureTracking (:342-347): p2 = H p1, normalise, round to float
-            const double *Hm = S.Hpred;
-            const double px = (double)pin.x, py = (double)pin.y;
-            const double X = Hm[0] * px + Hm[1] * py + Hm[2] * 1.0;
-            const double Y = Hm[3] * px + Hm[4] * py + Hm[5] * 1.0;
-            const double Z = Hm[6] * px + Hm[7] * py + Hm[8] * 1.0;
-            ax = pin.x; ay = pin.y; bx = (float)(X / Z); by = (float)(Y / Z);
-        } else {
-            alive = (S.status[pt] & 1) != 0;
-            if (alive) { const mskf_point2f c0 = S.out0[pt], gsp = S.out1[pt]; ax = c0.x; ay = c0.y; bx = gsp.x; by = gsp.y; }
-        }
-    }
-    if (!__any(alive)) return;
-    const PyrDev &A = stereo ? S.curr0 : S.prev0;
-    const PyrDev &B = stereo ? S.curr1 : S.curr0;
+// Pyramidal LK of the four points of a wavefront (see above): templates around (ax, ay) in pyramid A, search in pyramid B
+// from the initial guess (bx, by), both in level-0 pixels.  Every lane of the wavefront calls it (it stages through LDS and
+// uses the workgroup barrier of the one-wave workgroup); `alive` marks the 16-lane rows that carry a point.  Returns the
+// tracked position and the OpenCV status (0: lost).
+__device__ __forceinline__ void l4_track(const PyrDev &A, const PyrDev &B, bool alive, float ax, float ay, float bx, float by,
+                                         uint32_t *sT, uint32_t *sS, int r, float &out_x, float &out_y, int &out_status, unsigned int &dbg_iters) {
     int status = 1;
     float ncx = 0.f, ncy = 0.f;
-#ifdef LK_ITER_DBG
-    unsigned int dbg_iters = 0;
-#endif
     const bool winrow = r < LK_WIN;                       // lane 15 only feeds the row below window row 14
     for (int l = MSKF_LEVELS - 1; l >= 0; --l) {
         const uint8_t *imA = A.lvl[l];
@@ -800,80 +768,112 @@ __global__ __launch_bounds__(64) void k_lk_points4(const FeStreamDev *streams, i
         }
         if (solved) { ncx = wx + (float)LK_HALF; ncy = wy + (float)LK_HALF; }
     }
-#ifdef LK_ITER_DBG
-    if (pt < S.n_pts && r == 0) { if (!stereo) ((unsigned int *)S.und1)[2 * pt] = dbg_iters; else ((unsigned int *)S.und1)[2 * pt + 1] = dbg_iters; }
-#endif
-    if (alive && r == 0) {
-        if (!stereo) {
-            S.out0[pt] = mskf_point2f{ncx, ncy};
-            S.status[pt] = (uint8_t)(status ? 1 : 0);
-        } else {
-            S.out1[pt] = mskf_point2f{ncx, ncy};
-            S.status[pt] = (uint8_t)(1 | (status ? 2 : 0));
-        }
-    }
+    out_x = ncx; out_y = ncy; out_status = status;
 }
 
-// Per-point geometry of a track call, one thread per point.
-//   phase 0 (between the tracks): bounds gate of the temporal result (:416-424), stereo initial guess
-//            undistort(cam0, R01) -> distort(cam1) (:542-548); status bit 0 = the point goes on to the stereo track
-//   phase 1 (after the stereo track): bounds gate (:575-583), undistorted points (:601-604, also what publish()
-//            sends, :1154-1155), epipolar gate (:605-617); status bit 1 = stereo match accepted
-__global__ __launch_bounds__(64) void k_pt_geom(const FeStreamDev *streams, int phase) {
-    const FeStreamDev &S = streams[blockIdx.y];
-    const int pt = blockIdx.x * 64 + threadIdx.x;
-    if (pt >= S.n_pts) return;
-    if (phase == 0) {
-        const int W = S.curr0.w[0], H = S.curr0.h[0];
-        float c0x, c0y;
-        bool ok = true;
-        if (S.do_temporal) {
-            const mskf_point2f c0 = S.out0[pt];
-            c0x = c0.x; c0y = c0.y;
-            int st = S.status[pt] & 1;
-            if (st && (c0y < 0 || c0y > (float)(H - 1) || c0x < 0 || c0x > (float)(W - 1))) st = 0;
-            ok = st != 0;
-        } else {
-            const mskf_point2f pin = S.in_pts[pt];
-            c0x = pin.x; c0y = pin.y;
-            S.out0[pt] = pin;
+// One launch per track call (mskf_fe_track*): for the four points of a wavefront, with the point state in registers,
+//   temporal LK prev cam0 -> curr cam0 from the predicted position (:321-350, :410)      [do_temporal streams only]
+//   -> image-bounds gate (:416-424) -> stereo initial guess undistort(cam0, R01) . distort(cam1) (:542-548)
+//   -> stereo LK curr cam0 -> curr cam1 (:569) -> image-bounds gate (:575-583), undistorted points (:601-604, also what
+//   publish() sends, :1154-1155) and the epipolar gate (:605-617).
+// Round 2 ran this chain as five launches (k_lk_points4 x 2 + k_pt_geom x 3, one thread per point for the geometry) with
+// out0 / out1 / status making a round trip through global memory between each; the per-point double-precision geometry is
+// a few hundred instructions, issued here once per wavefront for its four points (the sixteen lanes of a row compute the
+// same values).  The two tracks run through ONE copy of the LK code (a two-trip loop), so the kernel is no larger.
+// Outputs per point: out0 = cam0 point in the current image (tracked, or the input of a stereo-only stream), out1 = matched
+// cam1 point, und0 / und1 = their undistorted normalised coordinates, status bit 0 = survived the temporal half, bit 1 =
+// stereo match accepted; a point that fails the temporal half gets out1 = und0 = und1 = 0 and status 0.
+// Block -> (stream, point group): the blocks b and b + 8 share an XCD (round-robin dispatch, speed only), so the point
+// groups of ONE stream are given ids that are congruent modulo 8: a stream's pyramid levels then travel through one L2.
+__global__ __launch_bounds__(64) void k_track4(const FeStreamDev *streams, int n_streams, int groups_per_stream) {
+    const int x = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int si = x + 8 * (qb / groups_per_stream), gi = qb - (qb / groups_per_stream) * groups_per_stream;
+    if (si >= n_streams) return;
+    const FeStreamDev &S = streams[si];
+    if (4 * gi >= S.n_pts) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int pt = 4 * gi + g;
+    __shared__ uint32_t s_T[4][L4_TROWS * L4_DW + 2];
+    __shared__ uint32_t s_S[4][L4_SROWS * L4_DW + 4];
+    uint32_t *sT = s_T[g], *sS = s_S[g];
+    const bool in_range = pt < S.n_pts;
+    mskf_point2f pin = {0.f, 0.f};
+    if (in_range) pin = S.in_pts[pt];
+    unsigned int dbg_iters = 0, dbg_t = 0;
+    // state of the point between the tracks
+    float c0x = pin.x, c0y = pin.y;           // cam0 point in the current image
+    bool ok = in_range;                        // survived the temporal half
+    float tx = 0.f, ty = 0.f, gx = 0.f, gy = 0.f;
+    bool alive = false;
+    int ph = 1;
+    if (S.do_temporal) {
+        // predictFeatureTracking (:342-347): p2 = H p1, normalise, round to float
+        const double *Hm = S.Hpred;
+        const double px = (double)pin.x, py = (double)pin.y;
+        const double X = Hm[0] * px + Hm[1] * py + Hm[2] * 1.0;
+        const double Y = Hm[3] * px + Hm[4] * py + Hm[5] * 1.0;
+        const double Z = Hm[6] * px + Hm[7] * py + Hm[8] * 1.0;
+        tx = pin.x; ty = pin.y; gx = (float)(X / Z); gy = (float)(Y / Z);
+        alive = in_range;
+        ph = 0;
+    }
+    float c1x = 0.f, c1y = 0.f;
+    int st1 = 0;
+#pragma nounroll
+    for (; ph < 2; ++ph) {
+        if (ph == 1) {
+            // stereo initial guess (:542-548) of the points that are still there
+            gx = 0.f; gy = 0.f;
+            if (ok) {
+                float rx, ry;
+                undistort_pt(S.cam0, S.R01, c0x, c0y, rx, ry);
+                distort_pt(S.cam1, rx, ry, gx, gy);
+            }
+            tx = c0x; ty = c0y; alive = ok;
         }
-        float c1x = 0.f, c1y = 0.f;
-        if (ok) {
-            float rx, ry;
-            undistort_pt(S.cam0, S.R01, c0x, c0y, rx, ry);
-            distort_pt(S.cam1, rx, ry, c1x, c1y);
+        float nx = 0.f, ny = 0.f;
+        int st = 0;
+        if (__any(alive)) l4_track(ph ? S.curr0 : S.prev0, ph ? S.curr1 : S.curr0, alive, tx, ty, gx, gy, sT, sS, r, nx, ny, st, dbg_iters);
+        if (ph == 0) {
+            // temporal result and its image-bounds gate (:416-424)
+            const int W = S.curr0.w[0], H = S.curr0.h[0];
+            c0x = nx; c0y = ny;
+            ok = alive && st != 0 && !(c0y < 0 || c0y > (float)(H - 1) || c0x < 0 || c0x > (float)(W - 1));
+            dbg_t = dbg_iters; dbg_iters = 0;
         } else {
-            S.und0[pt] = mskf_point2f{0.f, 0.f};
-            S.und1[pt] = mskf_point2f{0.f, 0.f};
+            c1x = alive ? nx : 0.f; c1y = alive ? ny : 0.f; st1 = alive ? st : 0;
         }
+    }
+    // stereo result: image-bounds gate (:575-583), undistorted points (:601-604), epipolar gate (:605-617)
+    float u0x = 0.f, u0y = 0.f, u1x = 0.f, u1y = 0.f;
+    int sst = st1;
+    if (ok) {
+        const int W1 = S.curr1.w[0], H1 = S.curr1.h[0];
+        if (sst && (c1y < 0 || c1y > (float)(H1 - 1) || c1x < 0 || c1x > (float)(W1 - 1))) sst = 0;
+        undistort_pt(S.cam0, nullptr, c0x, c0y, u0x, u0y);
+        undistort_pt(S.cam1, nullptr, c1x, c1y, u1x, u1y);
+        if (sst) {
+            const double *E = S.E;
+            const double x0 = (double)u0x, y0 = (double)u0y, x1 = (double)u1x, y1 = (double)u1y;
+            const double l0 = (E[0] * x0 + E[1] * y0) + E[2];
+            const double l1 = (E[3] * x0 + E[4] * y0) + E[5];
+            const double l2 = (E[6] * x0 + E[7] * y0) + E[8];
+            const double err = fabs((x1 * l0 + y1 * l1) + l2) / sqrt(l0 * l0 + l1 * l1);
+            if (err > S.epi_thresh) sst = 0;
+        }
+    }
+    if (in_range && r == 0) {
+        S.out0[pt] = mskf_point2f{c0x, c0y};
         S.out1[pt] = mskf_point2f{c1x, c1y};
-        S.status[pt] = (uint8_t)(ok ? 1 : 0);
-        return;
-    }
-    const int bits = S.status[pt];
-    if (!(bits & 1)) return;
-    int st = bits & 2;
-    const mskf_point2f c0 = S.out0[pt], c1 = S.out1[pt];
-    const int W1 = S.curr1.w[0], H1 = S.curr1.h[0];
-    if (st && (c1.y < 0 || c1.y > (float)(H1 - 1) || c1.x < 0 || c1.x > (float)(W1 - 1))) st = 0;
-    float u0x, u0y, u1x, u1y;
-    undistort_pt(S.cam0, nullptr, c0.x, c0.y, u0x, u0y);
-    undistort_pt(S.cam1, nullptr, c1.x, c1.y, u1x, u1y);
-    if (st) {
-        const double *E = S.E;
-        const double x0 = (double)u0x, y0 = (double)u0y, x1 = (double)u1x, y1 = (double)u1y;
-        const double l0 = (E[0] * x0 + E[1] * y0) + E[2];
-        const double l1 = (E[3] * x0 + E[4] * y0) + E[5];
-        const double l2 = (E[6] * x0 + E[7] * y0) + E[8];
-        const double err = fabs((x1 * l0 + y1 * l1) + l2) / sqrt(l0 * l0 + l1 * l1);
-        if (err > S.epi_thresh) st = 0;
-    }
-    S.und0[pt] = mskf_point2f{u0x, u0y};
-#ifndef LK_ITER_DBG
-    S.und1[pt] = mskf_point2f{u1x, u1y};
+        S.und0[pt] = mskf_point2f{u0x, u0y};
+#ifdef LK_ITER_DBG
+        ((unsigned int *)S.und1)[2 * pt] = dbg_t; ((unsigned int *)S.und1)[2 * pt + 1] = dbg_iters;
+#else
+        S.und1[pt] = mskf_point2f{u1x, u1y};
+        (void)dbg_t;
 #endif
-    S.status[pt] = (uint8_t)(1 | (st ? 2 : 0));
+        S.status[pt] = (uint8_t)(ok ? (1 | (sst ? 2 : 0)) : 0);
+    }
 }
 
 // completion mark of the spinning wait (mskf_wait_event): one thread stores a sequence number into pinned host memory
@@ -886,12 +886,8 @@ extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hi
     hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, st, flag, seq);
 }
 
-extern "C" void fe_launch_lk(const FeStreamDev *streams_dev, int n_streams, int max_pts, int stereo, hipStream_t st) {
+extern "C" void fe_launch_track(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st) {
     if (max_pts <= 0) return;
     const int gps = (max_pts + 3) / 4;
-    hipLaunchKernelGGL(k_lk_points4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), 0, st, streams_dev, stereo, n_streams, gps);
-}
-extern "C" void fe_launch_pt_geom(const FeStreamDev *streams_dev, int n_streams, int max_pts, int phase, hipStream_t st) {
-    if (max_pts <= 0) return;
-    hipLaunchKernelGGL(k_pt_geom, dim3((max_pts + 63) / 64, n_streams), dim3(64), 0, st, streams_dev, phase);
+    hipLaunchKernelGGL(k_track4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), 0, st, streams_dev, n_streams, gps);
 }

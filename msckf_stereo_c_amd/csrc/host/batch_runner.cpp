@@ -1,5 +1,6 @@
 // batch_runner.cpp — see batch_runner.h.
 #include "batch_runner.h"
+#include "host_prof.h"
 #include <algorithm>
 #include <cstdlib>
 #include <chrono>
@@ -27,6 +28,7 @@ void ForkJoin::worker(int) {
             seen = gen_;
             if (stop_) return;
             fn = fn_; n = n_;
+            hostprof::enabled() = prof_on_;
         }
         for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*fn)(i);
         done_.fetch_add(1);
@@ -35,7 +37,7 @@ void ForkJoin::worker(int) {
 void ForkJoin::run(int n, const std::function<void(int)> &fn) {
     if (nt_ <= 1 || n <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
     next_.store(0); done_.store(0);
-    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; n_ = n; ++gen_; }
+    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; n_ = n; prof_on_ = hostprof::enabled(); ++gen_; }
     cv_.notify_all();
     for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) fn(i);
     while (done_.load() < nt_ - 1) std::this_thread::yield();
@@ -290,7 +292,13 @@ int BatchGroup::run(int first, int n_frames) {
     return MSKF_OK;
 }
 
-int BatchGroup::run_pipelined(int first, int n_frames) {
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void BatchGroup::set_gates(bool on) {
+    for (Half &H : half_) { mskf_ctx_timing_gate(H.ctx, on ? 1 : 0); mskf_ctx_timing_gate(H.ctx_ekf, on ? 1 : 0); }
+}
+
+int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *pacer, int pacer_slot) {
     const int n = size();
     std::mutex mu;
     std::condition_variable cv;
@@ -299,32 +307,91 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
     bool producer_done = false;
     std::atomic<int> ekf_rc{MSKF_OK};
     std::string ekf_err;
+    static const int fe_phases[] = {PH_PUSH, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_IMU, PH_HANDOFF, PH_FE_QWAIT, PH_FE_PACE};
+    static const int ekf_phases[] = {PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_EKF_QWAIT, PH_IMU_EKF};
+    // a stage opens / closes its own accounting: kernel timing of its contexts, the host-profile slots of its thread, and the
+    // phase times it owns (difference between the two marks)
+    auto gate = [&](bool fe, bool on) {
+        for (Half &H : half_) mskf_ctx_timing_gate(fe ? H.ctx : H.ctx_ekf, on ? 1 : 0);
+        hostprof::enabled() = on;
+        const int *ph = fe ? fe_phases : ekf_phases;
+        const int cnt = fe ? (int)(sizeof(fe_phases) / sizeof(int)) : (int)(sizeof(ekf_phases) / sizeof(int));
+        for (int k = 0; k < cnt; ++k) window_phase_s[ph[k]] = on ? -phase_s[ph[k]] : window_phase_s[ph[k]] + phase_s[ph[k]];
+    };
+    if (win) { mark_dump.fe_valid = mark_dump.ekf_valid = false; }
     std::thread consumer([&]() {
+        if (win) hostprof::enabled() = false;
         for (;;) {
             std::unique_ptr<FrameBatch> fb;
             {
+                const double tq = now_s();
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&]() { return !queue.empty() || producer_done; });
                 if (queue.empty()) return;
                 fb = std::move(queue.front());
                 queue.pop_front();
+                phase_s[PH_EKF_QWAIT] += now_s() - tq;
             }
             cv.notify_all();
             if (ekf_rc.load() != MSKF_OK) continue;   // drain
+            if (win && fb->frame == win->mark_begin) {
+                // (the wait for this very batch belongs to the frame before the window)
+                win->t_ekf_begin = now_s();
+                gate(false, true);
+            }
+            const double ti = now_s();
             int rc = feed_imu(fb->frame, false, true);
+            phase_s[PH_IMU_EKF] += now_s() - ti;
             if (rc == MSKF_OK) rc = step_ekf(fb.get());
             if (rc != MSKF_OK) ekf_rc.store(rc);
+            if (win && fb->frame == win->mark_end - 1) {
+                win->t_ekf_end = now_s();
+                gate(false, false);
+                if (rc == MSKF_OK) {
+                    const IMUState &st = systems_[0]->msckfvio_ptr()->imuState();
+                    int k = 0;
+                    for (int i = 0; i < 4; ++i) mark_dump.imu[k++] = st.orientation.q[i];
+                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.position[i];
+                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.velocity[i];
+                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.gyro_bias[i];
+                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.acc_bias[i];
+                    for (int i = 0; i < 9; ++i) mark_dump.imu[k++] = st.R_imu_cam0.m[i];
+                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.t_cam0_imu[i];
+                    mark_dump.ekf_valid = true;
+                }
+                if (win->groups_done) win->groups_done->fetch_add(1);
+            }
             { std::lock_guard<std::mutex> lk(mu); pool.push_back(std::move(fb)); }
         }
     });
+    if (win) hostprof::enabled() = false;
     int rc = MSKF_OK;
-    for (int k = first; k < first + n_frames && rc == MSKF_OK && ekf_rc.load() == MSKF_OK; ++k) {
+    int k = first;
+    for (;; ++k) {
+        if (rc != MSKF_OK || ekf_rc.load() != MSKF_OK) break;
+        if (k >= first + n_frames) {
+            // cool-down: keep the device loaded until every group has closed its window
+            if (!win || !win->groups_done || win->groups_done->load() >= win->n_groups || k >= first + n_frames + win->max_extra) break;
+        }
+        if (win && k == win->mark_begin) { win->t_fe_begin = now_s(); gate(true, true); }
+        if (pacer && k < first + n_frames) {
+            // not more than `slack` frames ahead of the slowest group (cool-down frames are not paced: the others are finishing)
+            const double tp = now_s();
+            unsigned spins = 0;
+            while ((k - first) - pacer->slowest() > pacer->slack && ekf_rc.load() == MSKF_OK) {
+                if ((++spins & 63u) == 0) std::this_thread::yield(); else __builtin_ia32_pause();
+            }
+            phase_s[PH_FE_PACE] += now_s() - tp;
+        }
+        const double ti = now_s();
         rc = feed_imu(k, true, false);
+        phase_s[PH_IMU] += now_s() - ti;
         if (rc == MSKF_OK) rc = step_fe(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
         if (rc != MSKF_OK) break;
         // hand-off = a snapshot of every stream's message (live + stale entries + the first tail record).  The batches and
         // their per-stream messages are recycled through `pool` (at most 2 queued + 1 in the filter stage + 1 being
         // filled), so the steady state allocates nothing
+        const double th = now_s();
         std::unique_ptr<FrameBatch> fb;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -343,23 +410,38 @@ int BatchGroup::run_pipelined(int first, int n_frames) {
             fb->msg[i]->features.assign(live.features.begin(), live.features.begin() + keep);
             fb->tail_start[i] = start; fb->total[i] = total;
         }
+        const double tw = now_s();
+        phase_s[PH_HANDOFF] += tw - th;
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&]() { return queue.size() < 2; });
             queue.push_back(std::move(fb));
         }
         cv.notify_all();
+        phase_s[PH_FE_QWAIT] += now_s() - tw;
+        if (pacer) pacer->done[pacer_slot].store(k + 1 >= first + n_frames ? 0x7fffffff : k + 1 - first, std::memory_order_relaxed);
+        if (win && k == win->mark_end - 1) {
+            win->t_fe_end = now_s();
+            gate(true, false);
+            std::vector<ImageProcessor::FeatureIDType> ids;
+            systems_[0]->imgproc_ptr_->dumpCurrent(ids, mark_dump.life, mark_dump.c0, mark_dump.c1);
+            mark_dump.ids.assign(ids.begin(), ids.end());
+            mark_dump.fe_valid = true;
+        }
     }
+    if (pacer) pacer->done[pacer_slot].store(0x7fffffff);      // (also on an error exit: nobody waits for this group any more)
     { std::lock_guard<std::mutex> lk(mu); producer_done = true; }
     cv.notify_all();
     consumer.join();
+    hostprof::enabled() = true;
+    if (win) win->frames_done = k - first;
     if (rc == MSKF_OK) rc = ekf_rc.load();
     return rc;
 }
 
 MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
                          int host_threads)
-    : n_groups_(n_groups), per_group_(per_group), off_(n_groups, 0), next_(n_groups, 0) {
+    : n_groups_(n_groups), per_group_(per_group), off_(n_groups, 0), next_(n_groups, 0), win_(n_groups) {
     for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads));
 }
 
@@ -394,10 +476,66 @@ int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
         for (int g = 0; g < n_groups_; ++g) { rcs[g] = one(g); if (rcs[g] != MSKF_OK) return rcs[g]; }
         return MSKF_OK;
     }
+    // pipelined groups are paced against each other (MSKF_PACE = slack in frames, 0 = off); catch-up runs of staggered
+    // groups have different lengths and are not
+    std::unique_ptr<Pacer> pacer;
+    {
+        bool same = pipelined;
+        std::vector<int> from(n_groups_), cnt(n_groups_);
+        for (int g = 0; g < n_groups_; ++g) { from[g] = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first; cnt[g] = first + off_[g] + n - from[g]; same = same && cnt[g] == cnt[0]; }
+        if (same && pace_slack() > 0) pacer.reset(new Pacer(n_groups_, pace_slack()));
+        if (pacer) {
+            std::vector<std::thread> th;
+            for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { next_[g] = from[g] + cnt[g]; rcs[g] = groups_[g]->run_pipelined(from[g], cnt[g], nullptr, pacer.get(), g); });
+            for (auto &t : th) t.join();
+            for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
+            return MSKF_OK;
+        }
+    }
     std::vector<std::thread> th;
     for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = one(g); });
     for (auto &t : th) t.join();
     for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
+    return MSKF_OK;
+}
+
+int MultiRunner::pace_slack() {
+    static const int v = [] { const char *e = std::getenv("MSKF_PACE"); const int x = e ? std::atoi(e) : 2; return x < 0 ? 0 : x; }();
+    return v;
+}
+
+int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s) {
+    std::vector<int> rcs(n_groups_, MSKF_OK);
+    std::atomic<int> done{0};
+    std::vector<int> from(n_groups_), cnt(n_groups_);
+    for (int g = 0; g < n_groups_; ++g) {
+        from[g] = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
+        cnt[g] = first + off_[g] + warmup + steps - from[g];
+        TimedWindow &w = win_[g];
+        w = TimedWindow();
+        w.mark_begin = first + off_[g] + warmup; w.mark_end = w.mark_begin + steps;
+        w.max_extra = max_extra; w.groups_done = &done; w.n_groups = n_groups_;
+        groups_[g]->set_gates(false);
+    }
+    std::unique_ptr<Pacer> pacer;
+    {
+        bool same = true;
+        for (int g = 0; g < n_groups_; ++g) same = same && cnt[g] == cnt[0];
+        if (same && n_groups_ > 1 && pace_slack() > 0) pacer.reset(new Pacer(n_groups_, pace_slack()));
+    }
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = groups_[g]->run_pipelined(from[g], cnt[g], &win_[g], pacer.get(), g); });
+    for (auto &t : th) t.join();
+    double t0 = 0, t1 = 0;
+    for (int g = 0; g < n_groups_; ++g) {
+        next_[g] = from[g] + win_[g].frames_done;
+        groups_[g]->set_gates(true);
+        if (g == 0 || win_[g].t_fe_begin < t0) t0 = win_[g].t_fe_begin;
+        if (g == 0 || win_[g].t_ekf_end > t1) t1 = win_[g].t_ekf_end;
+    }
+    for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
+    for (int g = 0; g < n_groups_; ++g) if (win_[g].t_ekf_end <= 0 || win_[g].t_fe_begin <= 0) return MSKF_ERR_INVALID;   // a window never closed
+    if (elapsed_s) *elapsed_s = t1 - t0;
     return MSKF_OK;
 }
 

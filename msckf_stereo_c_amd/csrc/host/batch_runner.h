@@ -27,6 +27,32 @@ struct StreamSequence {   // a looping pre-rendered stereo sequence + IMU sample
     int imu_cursor_ekf = 0;   // next sample for the filter stage of the pipeline
 };
 
+// A measurement window inside one continuous pipelined run (bench.py): the stages of a group open it when they reach
+// frame `mark_begin` and close it after frame `mark_end - 1`; in between every accounting gate is open (kernel timing of the
+// stage's context, host bookkeeping slots, phase times).  A group that has finished keeps stepping untimed cool-down frames
+// (at most `max_extra`) until every group has closed its window, so the last frames of the window see the same load as the rest.
+struct TimedWindow {
+    int mark_begin = 0, mark_end = 0;        // absolute frame indices of this group
+    int max_extra = 0;
+    std::atomic<int> *groups_done = nullptr;
+    int n_groups = 1;
+    // results
+    double t_fe_begin = 0, t_fe_end = 0, t_ekf_begin = 0, t_ekf_end = 0;   // steady_clock seconds
+    int frames_done = 0;                     // frames the group processed in this run, cool-down included
+};
+
+// Pacing of the groups of a MultiRunner run: every group's front-end stage publishes how many frames of the run it has
+// finished, and no group starts a frame more than `slack` frames ahead of the slowest one.  The hardware queues of the
+// groups are not served evenly (measured: over 60 frames some groups finished 0.44 s before others, a third of the run,
+// and the last ones then had the device to themselves); a group that is held back leaves its share of the device to the
+// ones behind, so all of them finish together and the run takes the average pace instead of the slowest group's.
+struct Pacer {
+    explicit Pacer(int n, int slack_) : done(n), slack(slack_) { for (auto &d : done) d.store(0); }
+    std::vector<std::atomic<int>> done;      // frames of this run the group's front-end has finished (INT_MAX: out of the race)
+    int slack;
+    int slowest() const { int m = 0x7fffffff; for (const auto &d : done) { const int v = d.load(std::memory_order_relaxed); if (v < m) m = v; } return m; }
+};
+
 struct FrameBatch {           // what the front-end stage hands to the filter stage: one frame of every stream
     int frame = 0;
     std::vector<std::shared_ptr<CameraMeasurement>> msg;   // snapshot: live + stale entries + first tail record
@@ -40,6 +66,7 @@ class ForkJoin {
     explicit ForkJoin(int n_threads);
     ~ForkJoin();
     void run(int n, const std::function<void(int)> &fn);   // fn(i) for i in [0, n), returns when all are done
+    bool prof_on_ = true;      // the caller's host-profile gate, adopted by the workers for the batch
   private:
     void worker(int id);
     int nt_;
@@ -67,7 +94,7 @@ class BatchGroup {
     int run(int first, int n);
     // same frames as a two-stage pipeline: a front-end thread (context ctx()) and a filter thread (context
     // ekf_ctx()); the front-end never reads filter state, so the results are identical to run()
-    int run_pipelined(int first, int n);
+    int run_pipelined(int first, int n, TimedWindow *win = nullptr, Pacer *pacer = nullptr, int pacer_slot = 0);
     // device contexts: the streams of a group are driven as up to two half-batches, each with its own staging
     // context; the halves of a stage share one HIP stream (mskf_ctx_create_shared), so a group still uses two queues
     int n_halves() const { return (int)half_.size(); }
@@ -75,8 +102,15 @@ class BatchGroup {
     mskf_ctx *ekf_ctx(int h = 0) const { return half_[h].ctx_ekf; }
     std::vector<StreamSequence> seq;
     const std::string &error() const { return error_; }
-    enum { PH_PUSH = 0, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_IMU, PH_COUNT };
+    // phases of the front-end thread: PH_IMU .. PH_FE_QWAIT (without PH_EKF_*); of the filter thread: PH_EKF_QWAIT, PH_IMU_EKF, PH_EKF_A .. PH_POSVAR
+    enum { PH_PUSH = 0, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_IMU,
+           PH_HANDOFF, PH_FE_QWAIT, PH_EKF_QWAIT, PH_IMU_EKF, PH_FE_PACE, PH_COUNT };
     double phase_s[PH_COUNT] = {0};   // wall seconds per phase of step() (host bookkeeping vs device calls)
+    double window_phase_s[PH_COUNT] = {0};   // the same inside the last TimedWindow (each stage between its own marks)
+    // what local stream 0 had computed when the stages closed the window (the sentinel of bench.py): front-end state after
+    // frame mark_end - 1, filter state after the same frame
+    struct MarkDump { std::vector<unsigned long long> ids; std::vector<int> life; std::vector<Point2f> c0, c1; double imu[28] = {0}; bool fe_valid = false, ekf_valid = false; } mark_dump;
+    void set_gates(bool on);          // accounting gates of both contexts (call while no stage is running)
 
   private:
     int step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t, bool is_draw);
@@ -123,6 +157,13 @@ class MultiRunner {
     void imu(int stream, const mskf_imu_sample &s) { int l; BatchGroup &g = group_of(stream, l); g.imu(l, s); }
     int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t);
     int run(int first, int n, bool threaded, bool pipelined = false);
+    // `warmup` untimed + `steps` timed frames of every group in ONE pipelined run (no fill / drain at the boundary), then
+    // cool-down frames until every group has closed its window.  *elapsed_s = latest filter-stage close - earliest
+    // front-end open over the groups: every one of the steps x streams frames is processed entirely inside that span.
+    int run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s);
+    int frames_done(int g) const { return next_[g]; }          // next frame index of group g (absolute)
+    static int pace_slack();                                   // MSKF_PACE (default 2 frames; 0 = groups are not paced)
+    const TimedWindow &window(int g) const { return win_[g]; }
     // group g works `g * delta` frames ahead of the frame index passed to run(): replicas of one looping sequence in
     // different groups then never read the same stereo pair at the same time (no cache sharing across groups).  The
     // first run() after the call lets every group catch up through its own offset.
@@ -134,6 +175,7 @@ class MultiRunner {
     int n_groups_, per_group_;
     std::vector<std::unique_ptr<BatchGroup>> groups_;
     std::vector<int> off_, next_;   // per group: frame offset, next frame not yet processed
+    std::vector<TimedWindow> win_;
 };
 
 }  // namespace cg

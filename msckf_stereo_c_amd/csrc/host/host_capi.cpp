@@ -49,6 +49,37 @@ void mskfh_runner_set_sequence(void *h, int stream, const uint8_t *cam0_base, co
 }
 // threaded: one host thread per group; pipelined: front-end and filter of each group run as a two-stage pipeline
 int mskfh_runner_run(void *h, int first, int n, int threaded, int pipelined) { return ((MultiRunner *)h)->run(first, n, threaded != 0, pipelined != 0); }
+// `warmup` + `steps` frames of every group in one pipelined run; *elapsed_s covers exactly the `steps` frames (MultiRunner::run_timed)
+int mskfh_runner_run_timed(void *h, int first, int warmup, int steps, int max_extra, double *elapsed_s) {
+    return ((MultiRunner *)h)->run_timed(first, warmup, steps, max_extra, elapsed_s);
+}
+int mskfh_runner_frames_done(void *h, int g) { return ((MultiRunner *)h)->frames_done(g); }
+// marks of group g's last timed window: [0] front-end open, [1] front-end close, [2] filter open, [3] filter close (steady clock, s)
+void mskfh_runner_window(void *h, int g, double out[4]) {
+    const TimedWindow &w = ((MultiRunner *)h)->window(g);
+    out[0] = w.t_fe_begin; out[1] = w.t_fe_end; out[2] = w.t_ekf_begin; out[3] = w.t_ekf_end;
+}
+// wall seconds per phase inside the last timed window, summed over groups (each stage between its own marks)
+void mskfh_runner_get_window_phases(void *h, double *out) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int k = 0; k < BatchGroup::PH_COUNT; ++k) out[k] = 0;
+    for (int g = 0; g < r->n_groups(); ++g)
+        for (int k = 0; k < BatchGroup::PH_COUNT; ++k) out[k] += r->group(g).window_phase_s[k];
+}
+// state of local stream 0 of group g when its stages closed the window; returns the feature count (-1: no window closed)
+int mskfh_runner_mark_dump_size(void *h, int g) {
+    const BatchGroup::MarkDump &m = ((MultiRunner *)h)->group(g).mark_dump;
+    return (m.fe_valid && m.ekf_valid) ? (int)m.ids.size() : -1;
+}
+void mskfh_runner_mark_dump(void *h, int g, uint64_t *ids, int32_t *lifetime, mskf_point2f *cam0, mskf_point2f *cam1, double *imu28) {
+    const BatchGroup::MarkDump &m = ((MultiRunner *)h)->group(g).mark_dump;
+    for (size_t i = 0; i < m.ids.size(); ++i) {
+        ids[i] = m.ids[i]; lifetime[i] = m.life[i];
+        cam0[i] = mskf_point2f{m.c0[i].x, m.c0[i].y}; cam1[i] = mskf_point2f{m.c1[i].x, m.c1[i].y};
+    }
+    std::memcpy(imu28, m.imu, sizeof(m.imu));
+}
+void mskfh_runner_keep_trajectory_stream(void *h, int stream, int keep) { ((MultiRunner *)h)->system(stream).msckfvio_ptr()->keepTrajectory = keep != 0; }
 void mskfh_runner_set_stagger(void *h, int delta) { ((MultiRunner *)h)->set_stagger(delta); }
 int mskfh_runner_group_offset(void *h, int g) { return ((MultiRunner *)h)->group_offset(g); }
 void mskfh_runner_keep_trajectory(void *h, int keep) {

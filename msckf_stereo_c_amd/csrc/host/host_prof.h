@@ -19,10 +19,13 @@ inline const char *name(int s) {
     return (s >= 0 && s < N_SLOTS) ? n[s] : "";
 }
 inline std::atomic<uint64_t> *counters() { static std::atomic<uint64_t> c[N_SLOTS]; return c; }
+// per-thread accounting gate (default on): a pipeline stage opens and closes its own measurement window
+inline bool &enabled() { static thread_local bool e = true; return e; }
 struct Scope {
     int slot; std::chrono::steady_clock::time_point t0;
     explicit Scope(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
     ~Scope() {
+        if (!enabled()) return;
         const auto dt = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         counters()[slot].fetch_add((uint64_t)dt, std::memory_order_relaxed);
     }

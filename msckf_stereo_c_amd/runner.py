@@ -34,6 +34,13 @@ def lib():
                                                 C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
         L.mskfh_runner_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mskfh_runner_keep_trajectory.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_keep_trajectory_stream.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mskfh_runner_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.mskfh_runner_frames_done.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mskfh_runner_get_window_phases.argtypes = [C.c_void_p, C.c_void_p]
+        L.mskfh_runner_mark_dump_size.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_runner_mark_dump.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.mskfh_runner_set_stagger.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_runner_group_offset.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_runner_group_offset.restype = C.c_int
@@ -118,6 +125,36 @@ class Runner:
         as a two-stage pipeline on two HIP streams (identical results: the front-end never reads filter state)."""
         self._chk(self.L.mskfh_runner_run(self.h, first, n, int(threaded), int(pipelined)))
 
+    def run_timed(self, first, warmup, steps, max_extra=8):
+        """`warmup` untimed + `steps` timed frames of every group in ONE pipelined run (no fill / drain of the group pipelines
+        at the boundary), then untimed cool-down frames until every group is through.  Returns the seconds from the first
+        group's front-end reaching frame first + warmup to the last group's filter finishing frame first + warmup + steps - 1."""
+        el = C.c_double(0.0)
+        self._chk(self.L.mskfh_runner_run_timed(self.h, first, warmup, steps, max_extra, C.byref(el)))
+        return el.value
+
+    def frames_done(self, group=0):
+        """Next frame index of a group (absolute, its stagger offset included)."""
+        return self.L.mskfh_runner_frames_done(self.h, group)
+
+    def window(self, group=0):
+        out = np.zeros(4)
+        self.L.mskfh_runner_window(self.h, group, _p(out))
+        return dict(zip(("fe_open", "fe_close", "ekf_open", "ekf_close"), (float(x) for x in out)))
+
+    def mark_dump(self, group=0):
+        """(ids, lifetimes, cam0, cam1, imu_state[28]) of local stream 0 of a group at the close of its timed window."""
+        n = self.L.mskfh_runner_mark_dump_size(self.h, group)
+        if n < 0:
+            raise MskfError("no timed window has been closed")
+        ids = np.zeros(n, np.uint64)
+        life = np.zeros(n, np.int32)
+        c0 = np.zeros(n, POINT2F)
+        c1 = np.zeros(n, POINT2F)
+        imu = np.zeros(28)
+        self.L.mskfh_runner_mark_dump(self.h, group, _p(ids), _p(life), _p(c0), _p(c1), _p(imu))
+        return ids, life, c0, c1, imu
+
     def set_stagger(self, delta):
         """Group g works g * delta frames ahead of the index passed to run() (MultiRunner::set_stagger)."""
         self.L.mskfh_runner_set_stagger(self.h, int(delta))
@@ -125,8 +162,11 @@ class Runner:
     def group_offset(self, g):
         return self.L.mskfh_runner_group_offset(self.h, g)
 
-    def keep_trajectory(self, keep):
-        self.L.mskfh_runner_keep_trajectory(self.h, int(keep))
+    def keep_trajectory(self, keep, stream=None):
+        if stream is None:
+            self.L.mskfh_runner_keep_trajectory(self.h, int(keep))
+        else:
+            self.L.mskfh_runner_keep_trajectory_stream(self.h, int(stream), int(keep))
 
     KERNELS = ["k_pyr_down", "k_detect_cells", "k_lk_points4", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
                "k_ekf_cap", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_small", "k_ekf_remove_clone", "k_pt_geom"]
@@ -144,7 +184,15 @@ class Runner:
         return {n: (float(ms[i]), int(launches[i]), int(units[i])) for i, n in enumerate(self.KERNELS)}
 
     PHASES = ["push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "ekf_A", "update1", "ekf_B", "update2",
-              "ekf_C", "posvar", "imu_feed"]
+              "ekf_C", "posvar", "imu_feed", "handoff", "fe_queue_wait", "ekf_queue_wait", "imu_feed_ekf", "fe_pace_wait"]
+    FE_THREAD_PHASES = ["fe_pace_wait", "imu_feed", "push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "handoff", "fe_queue_wait"]
+    EKF_THREAD_PHASES = ["ekf_queue_wait", "imu_feed_ekf", "ekf_A", "update1", "ekf_B", "update2", "ekf_C", "posvar"]
+
+    def get_window_phases(self):
+        """Wall seconds per phase inside the last timed window, summed over groups."""
+        out = np.zeros(len(self.PHASES))
+        self.L.mskfh_runner_get_window_phases(self.h, _p(out))
+        return {n: float(out[i]) for i, n in enumerate(self.PHASES)}
 
     def get_phases(self, reset=True):
         """Wall seconds per BatchGroup::step phase, summed over groups (host bookkeeping vs device calls)."""

@@ -480,3 +480,105 @@ def test_track_capacity_and_errors(gpu_ctx, oracle):
     with pytest.raises(capi.MskfError):
         capi.Stream(gpu_ctx, bad, default_fe_cfg(), default_ekf_cfg())   # unknown distortion model
     s.close()
+
+
+def test_ekf_mixed_batch_takes_each_stream_its_own_route(gpu_ctx, oracle):
+    """One mskf_ekf_update_batch over streams of every route (EkfStreamDev::route): a pruning-shaped stream (pair kernels +
+    fused small update), a stream whose features all have <= 4 observations (wave class), a general stream with small and
+    large features, a stream with fewer stacked rows than active columns, an empty one.  Each stream's results are
+    bit-identical to the same update issued alone."""
+    calib = oracle.euroc_calib(376, 240)
+    cfg = default_ekf_cfg(max_cam_state_size=30)
+    specs = [dict(n_clones=30, n_feat=120, seed=41, pair=(3, 4)),             # pairs + small
+             dict(n_clones=30, n_feat=25, seed=42, min_obs=3, max_obs=4),     # wave class
+             dict(n_clones=30, n_feat=50, seed=43, min_obs=3),                # general: classes [1] and [2]
+             dict(n_clones=30, n_feat=2, seed=44, min_obs=3, max_obs=5),      # rows <= active columns
+             dict(n_clones=12, n_feat=40, seed=45, pair=(10, 11))]            # another pair, another window size
+    problems, kwargs = [], []
+    for sp in specs:
+        sp = dict(sp)
+        max_obs = sp.pop("max_obs", None)
+        pr = ekf_problems.make_problem(calib, **sp)
+        if max_obs is not None:      # trim every feature to at most max_obs observations
+            os_, oc, oz = [0], [], []
+            for j in range(len(pr["obs_start"]) - 1):
+                a, b = pr["obs_start"][j], min(pr["obs_start"][j + 1], pr["obs_start"][j] + max_obs)
+                oc += list(pr["obs_clone"][a:b]); oz += list(pr["obs_z"][a:b]); os_.append(len(oc))
+            pr["obs_start"], pr["obs_clone"], pr["obs_z"] = np.array(os_, np.int32), np.array(oc, np.int32), np.array(oz)
+        pair = "pair" in sp
+        problems.append(pr)
+        kwargs.append(dict(gravity=pr["gravity"], clones=pr["clones"], positions=pr["positions"], obs_start=pr["obs_start"],
+                           obs_clone=pr["obs_clone"], obs_z=pr["obs_z"], dof_offset=0 if pair else -1, apply_row_cap=not pair))
+    def fresh():
+        ss = [capi.Stream(gpu_ctx, calib, default_fe_cfg(), cfg) for _ in problems]
+        for s, pr in zip(ss, problems):
+            s.ekf_set_cov(pr["P"])
+        return ss
+    ss = fresh()
+    alone = [s.ekf_update(**kw) for s, kw in zip(ss, kwargs)]
+    P_alone = [s.ekf_get_cov() for s in ss]
+    for s in ss:
+        s.close()
+    ss = fresh()
+    together = gpu_ctx.ekf_update_batch(ss, kwargs)
+    P_together = [s.ekf_get_cov() for s in ss]
+    for s in ss:
+        s.close()
+    routes = set()
+    for a, b, Pa, Pb in zip(alone, together, P_alone, P_together):
+        assert a["rows"] == b["rows"] and a["used_qr"] == b["used_qr"]
+        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["gamma"], b["gamma"])
+        assert np.array_equal(a["delta_x"], b["delta_x"]) and np.array_equal(Pa, Pb)
+        routes.add(a["used_qr"])
+    assert all(r["rows"] > 0 for r in alone)
+    assert {0, 2} <= routes                 # the batch really mixed Gram-compressed and uncompressed updates
+    # ... and against the oracle, per stream
+    for pr, kw, got, Pg in zip(problems, kwargs, together, P_together):
+        ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"], pr["obs_clone"],
+                                        pr["obs_z"], kw["dof_offset"])
+        assert np.array_equal((got["status"] >> 1) & 1, ref["passed"]) and got["rows"] == ref["rows"]
+        assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 1e-8
+
+
+def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
+    """a stack with fewer STACKED rows than active columns whose last stacked row lies beyond them because a
+    gated-out block sits in the middle (st <= na < me).  H^T H is singular by construction there, and the reference does
+    not compress such a stack at all (msckf_vio.cpp:818-821): auto mode must not take the Gram path, and the rows do not
+    fit the uncompressed work buffers with their gap, so the Householder TSQR takes them (the same measurement, rotated).
+    The middle feature is made an outlier (its observations shifted), which the gate rejects."""
+    calib = oracle.euroc_calib(376, 240)
+    cfg = default_ekf_cfg(max_cam_state_size=30)
+    hit = 0
+    for seed in range(300, 340):
+        pr = ekf_problems.make_problem(calib, seed=seed, n_clones=30, n_feat=3, min_obs=9)
+        a, b = pr["obs_start"][1], pr["obs_start"][2]
+        pr["obs_z"][a:b] += 0.05                       # the middle feature becomes a gross outlier
+        ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"], pr["obs_clone"],
+                                        pr["obs_z"], -1)
+        if list(ref["passed"]) != [1, 0, 1]:
+            continue
+        n_obs = np.diff(pr["obs_start"])
+        st, me = int((4 * n_obs[[0, 2]] - 3).sum()), int((4 * n_obs - 3).sum())
+        used = sorted(set(int(c) for j in (0, 2) for c in pr["obs_clone"][pr["obs_start"][j]:pr["obs_start"][j + 1]]))
+        na = 6 * len(used)
+        if not (st <= na < me):
+            continue
+        hit += 1
+        s = capi.Stream(gpu_ctx, calib, default_fe_cfg(), cfg)
+        s.ekf_set_cov(pr["P"])
+        got = s.ekf_update(pr["gravity"], pr["clones"], pr["positions"], pr["obs_start"], pr["obs_clone"], pr["obs_z"], -1, True)
+        Pg = s.ekf_get_cov()
+        s.close()
+        assert got["rows"] == st == ref["rows"]
+        assert got["used_qr"] == 1, "st <= na < me must be triangularised by the TSQR, not squared into H^T H"
+        assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 1e-11
+        assert np.abs(got["delta_x"] - ref["delta_x"]).max() / np.abs(ref["delta_x"]).max() < 1e-9
+    assert hit >= 2, "the generator produced no st <= na < me case: widen the seed range"
+
+
+def test_compression_mode_is_validated(gpu_ctx, oracle):
+    """mskf_ekf_cfg.compression_mode took the place of padding: anything but 0, 1, 2 is refused at stream creation."""
+    calib = oracle.euroc_calib(376, 240)
+    for bad in (-1, 3, 0x7fffffff):
+        with pytest.raises(capi.MskfError):
+            capi.Stream(gpu_ctx, calib, default_fe_cfg(), default_ekf_cfg(compression_mode=bad))

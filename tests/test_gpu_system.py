@@ -180,10 +180,10 @@ def test_pipelined_run_is_identical_to_lockstep(oracle):
 
 def test_half_batches_on_a_shared_stream_are_identical(oracle, monkeypatch):
     """MSKF_HALVES=2: a group drives two staggered half-batches per stage, each on its own context sharing the stage's
-    HIP stream (mskf_ctx_create_shared), through the *_batch_begin / *_batch_end halves of the C-ABI.  Front-end results
-    (integer arithmetic) must be bit-identical to the one-batch run; the filter's agree to rounding only, because the
-    update path is chosen per batch (pair kernel / fused small update / general path need EVERY stream of the batch to
-    qualify), so a different batch composition may take a different, algebraically equal route."""
+    HIP stream (mskf_ctx_create_shared), through the *_batch_begin / *_batch_end halves of the C-ABI.  Everything must be
+    bit-identical to the one-batch run, the filter included: which kernels handle a stream's update is decided per
+    STREAM (EkfStreamDev::route), never from the rest of the batch, so a stream's arithmetic does not depend on which
+    streams share its launches.  (Round 2 chose the route per batch and this test had to be relaxed to 1e-9.)"""
     w, h, n_frames = 376, 240, 60
     fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
     syns = [oracle.Synth(seed=0x5EED0060 + i, width=w, height=h) for i in range(4)]
@@ -200,9 +200,8 @@ def test_half_batches_on_a_shared_stream_are_identical(oracle, monkeypatch):
             assert np.array_equal(x, y)
         pa, pb = a.poses(i), b.poses(i)
         assert len(pa) == len(pb) > 15
-        assert np.abs(pa["p"] - pb["p"]).max() < 1e-9 and np.abs(pa["q"] - pb["q"]).max() < 1e-9
-        ca, cb = a.cov(i), b.cov(i)
-        assert np.abs(ca - cb).max() / np.abs(ca).max() < 1e-9
+        assert np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])
+        assert np.array_equal(a.cov(i), b.cov(i))
         assert a.num_updates(i) == b.num_updates(i) > 0
     for r in runs:
         r.close()
@@ -521,3 +520,80 @@ def test_staggered_groups_run_ahead(oracle):
         op, gp = osys.poses(), run.poses(g)
         assert len(op) == len(gp) and np.abs(op["p"] - gp["p"]).max() < POS_TOL
     run.close()
+
+
+def test_timed_window_inside_one_pipelined_run(oracle):
+    """MultiRunner::run_timed (bench.py): warm-up + timed steps in ONE pipelined run with per-stage marks and untimed
+    cool-down frames.  The sentinel snapshot taken when the stages close the window equals the oracle at exactly that
+    frame (whatever the cool-down added), the window is non-empty and ordered, each thread's phase times add up to its
+    window, and the trajectory over all frames stays within tolerance."""
+    w, h, prime, warm, steps, delta = 376, 240, 26, 3, 9, 5
+    fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
+    syn = oracle.Synth(seed=0x5EED0061, width=w, height=h)
+    keep = []
+    run = R.Runner(syn.calib, fe, ekf, 3, 1, host_threads=1)
+    _attach_sequences(oracle, run, [syn, syn, syn], prime + warm + steps + 2 * delta + 8, keep)
+    run.set_stagger(delta)
+    run.run(0, prime, threaded=True, pipelined=True)
+    run.set_timing(1)
+    run.get_timing(reset=True)
+    elapsed = run.run_timed(prime, warm, steps, max_extra=6)
+    timing = run.get_timing(reset=True)
+    run.set_timing(False)
+    assert elapsed > 0
+    ph = run.get_window_phases()
+    for g in range(3):
+        wd = run.window(g)
+        assert wd["fe_open"] < wd["fe_close"] and wd["ekf_open"] < wd["ekf_close"] and wd["fe_open"] < wd["ekf_close"]
+        assert elapsed >= wd["ekf_close"] - wd["fe_open"] - 1e-9
+        done = run.frames_done(g) - run.group_offset(g)
+        assert prime + warm + steps <= done <= prime + warm + steps + 6
+        # the group's sentinel at the close of the window = the oracle after exactly prime + warm + steps (+ offset) frames
+        osys = oracle.OracleSystem(syn.calib, fe, ekf)
+        syn.feed(osys, prime + warm + steps + g * delta)
+        ids, life, c0, c1, imu = run.mark_dump(g)
+        o = osys.dump()
+        assert np.array_equal(o[0], ids) and np.array_equal(o[1], life) and np.array_equal(o[2], c0) and np.array_equal(o[3], c1)
+        assert np.abs(osys.imu_state() - imu).max() < POS_TOL
+        # ... and the live state has moved on by the cool-down frames, still equal to the oracle
+        syn.feed(osys, done - (prime + warm + steps), start=prime + warm + steps + g * delta)
+        for x, y in zip(osys.dump()[:4], run.dump(g)[:4]):
+            assert np.array_equal(x, y)
+        op, gp = osys.poses(), run.poses(g)
+        assert len(op) == len(gp) and np.abs(op["p"] - gp["p"]).max() < POS_TOL
+    fe_sum = sum(ph[k] for k in R.Runner.FE_THREAD_PHASES)
+    fe_win = sum(run.window(g)["fe_close"] - run.window(g)["fe_open"] for g in range(3))
+    ekf_sum = sum(ph[k] for k in R.Runner.EKF_THREAD_PHASES)
+    ekf_win = sum(run.window(g)["ekf_close"] - run.window(g)["ekf_open"] for g in range(3))
+    assert abs(fe_sum - fe_win) < 0.02 * fe_win + 1e-3 and abs(ekf_sum - ekf_win) < 0.02 * ekf_win + 1e-3
+    # kernels are timed only inside the window: exactly `steps` pyramid passes (3 levels) per group
+    assert timing["k_pyr_down"][1] == 3 * steps * 3
+    run.close()
+
+
+def test_stream_results_do_not_depend_on_the_batch(oracle):
+    """One stream (a) alone and (b) as a member of a batch of DIFFERENT streams — other scenes, another start phase, so
+    the batch mixes lost-feature updates of every size class with pruning updates and empty updates — over 300 frames:
+    identical feature ids / pixels, bit-identical poses in every frame and a bit-identical covariance, i.e. every gate
+    decision of every update fell the same way (a flipped gate changes the stacked rows and with them P)."""
+    w, h, n_frames = 376, 240, 300
+    fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
+    syn = oracle.Synth(seed=0x5EED0070, width=w, height=h)
+    others = [oracle.Synth(seed=0x5EED0071 + i, width=w, height=h, motion_scale=0.5 + 0.5 * i) for i in range(5)]
+    keep = []
+    alone = R.Runner(syn.calib, fe, ekf, 1, 1, host_threads=1)
+    _attach_sequences(oracle, alone, [syn], n_frames, keep)
+    batch = R.Runner(syn.calib, fe, ekf, 1, 6, host_threads=1)
+    _attach_sequences(oracle, batch, others[:2] + [syn] + others[2:], n_frames, keep)
+    alone.run(0, n_frames, threaded=True, pipelined=True)
+    batch.run(0, n_frames, threaded=True, pipelined=True)
+    for x, y in zip(alone.dump(0)[:4], batch.dump(2)[:4]):
+        assert np.array_equal(x, y)
+    pa, pb = alone.poses(0), batch.poses(2)
+    assert len(pa) == len(pb) > 250
+    assert np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])
+    assert np.array_equal(alone.cov(0), batch.cov(2))
+    assert alone.num_updates(0) == batch.num_updates(2) > 100
+    assert np.array_equal(alone.imu_state(0), batch.imu_state(2))
+    alone.close()
+    batch.close()
