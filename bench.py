@@ -410,7 +410,7 @@ def main(argv=None):
     n_pose_streams = min(per_group, max(1, int(host_cores_available()))) if (rank == 0 and not args.no_cpu) else 1
     for s_ in range(n_pose_streams):
         run.keep_trajectory(True, s_)
-    cooldown = 8 if n_groups > 1 else 0
+    cooldown = (args.steps + 8) if n_groups > 1 else 0      # frames a group may step beyond its own W + K while the window is open
     if max_offset:
         run.set_stagger(args.stagger)
     imus = [imu_array(s, (total_frames + max_offset + cooldown + 3) * 10 + 20) for s in syns]
@@ -435,10 +435,12 @@ def main(argv=None):
     cpu_quota, thr0 = cgroup_cpu()
     if pipe:
         # W warm-up + K timed steps in ONE pipelined run: the group pipelines (front-end | filter threads) are not torn
-        # down and refilled at the warm-up / timed boundary, every stage opens its accounting when it reaches step W and
-        # closes it after step W + K - 1; groups that are through keep stepping untimed cool-down frames until the last
-        # one is, so all K steps see the steady-state load.  elapsed = first stage to reach step W .. last stage to finish
-        # step W + K - 1: every one of the K x streams frames is processed entirely inside it (and nothing is skipped).
+        # down and refilled at the warm-up / timed boundary.  The groups' hardware queues are not served evenly (some
+        # groups run a quarter of the run ahead of others), so the timed window is defined on the WORK: it opens when the
+        # groups together have completed groups x W frames (front-end AND filter) and closes at groups x (W + K):
+        # exactly K steps' worth of stream-frames are completed inside it, nothing is skipped, and every group is busy
+        # from before it opens until after it closes (each runs at least W + K frames and keeps stepping until the
+        # window is closed; those extra frames are real frames, finished but not counted).
         run.set_timing(timing_period)
         run.get_timing(reset=True)
         run.get_abi_host_time(reset=True)
@@ -533,16 +535,19 @@ def main(argv=None):
         # add up to its own window (open -> close), which is ms_per_step up to the skew between the groups
         per = lambda names: {k: round(phases[k] * 1e3 / args.steps / n_groups, 3) for k in names}
         if pipe:
+            # (a thread's window = the span between its first frame boundary inside the timed window and the first one after
+            # it; summed over the groups and divided by K x groups it is that thread's wall time per group-step)
             fe_items, ekf_items = per(R.Runner.FE_THREAD_PHASES), per(R.Runner.EKF_THREAD_PHASES)
+            frames_by_group = [run.frames_done(g) - run.group_offset(g) - args.prime for g in range(n_groups)]
             host_phases = {
                 "front_end_thread": dict(fe_items, sum=round(sum(fe_items.values()), 3),
                                          window=round(sum(w["fe_close"] - w["fe_open"] for w in windows) * 1e3 / args.steps / n_groups, 3)),
                 "filter_thread": dict(ekf_items, sum=round(sum(ekf_items.values()), 3),
                                       window=round(sum(w["ekf_close"] - w["ekf_open"] for w in windows) * 1e3 / args.steps / n_groups, 3)),
-                "group_skew_ms": {"first_open_to_last_open": round((max(w["fe_open"] for w in windows) - min(w["fe_open"] for w in windows)) * 1e3, 3),
-                                  "first_close_to_last_close": round((max(w["ekf_close"] for w in windows) - min(w["ekf_close"] for w in windows)) * 1e3, 3)},
+                "frames_started_in_window": {"front_end": int(sum(w["fe_frames"] for w in windows)), "filter": int(sum(w["ekf_frames"] for w in windows)),
+                                             "counted": args.steps * n_groups},
+                "frames_run_by_group": frames_by_group,      # each >= W + K; the spread is how unevenly the groups' queues were served
                 "run_wall_ms": round(wall_run * 1e3, 1),
-                "cooldown_frames_max": max(run.frames_done(g) - run.group_offset(g) for g in range(n_groups)) - total_frames,
             }
         else:
             host_phases = per([k for k in phases if phases[k] > 0])

@@ -28,6 +28,7 @@ struct FeStreamDev {
     double Hpred[9];   // K R_p_c K^-1 (:335-340)
     double epi_thresh; // stereo_threshold * norm_pixel_unit (:606,:615)
     int n_pts;
+    const int *n_pts_dev;          // when set: the point count lives on the device (fe_book1's candidate count), n_pts is ignored
     int do_temporal;   // 1: prev0 -> curr0 LK first (trackFeatures), 0: stereo only (new candidates)
     const mskf_point2f *in_pts;   // prev cam0 points (temporal) or cam0 candidates (stereo only)
     mskf_point2f *out0;           // tracked cam0 point (temporal) / copy of the input

@@ -790,13 +790,17 @@ __global__ __launch_bounds__(64) void k_track4(const FeStreamDev *streams, int n
     const int si = x + 8 * (qb / groups_per_stream), gi = qb - (qb / groups_per_stream) * groups_per_stream;
     if (si >= n_streams) return;
     const FeStreamDev &S = streams[si];
-    if (4 * gi >= S.n_pts) return;
+    // the point count may live on the device (candidates chosen by fe_book1): the grid is then sized from an estimate and
+    // a block takes several point groups if there are more
+    const int n_pts = S.n_pts_dev ? *S.n_pts_dev : S.n_pts;
     const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
-    const int pt = 4 * gi + g;
     __shared__ uint32_t s_T[4][L4_TROWS * L4_DW + 2];
     __shared__ uint32_t s_S[4][L4_SROWS * L4_DW + 4];
     uint32_t *sT = s_T[g], *sS = s_S[g];
-    const bool in_range = pt < S.n_pts;
+#pragma nounroll
+    for (int gq = gi; 4 * gq < n_pts; gq += groups_per_stream) {
+    const int pt = 4 * gq + g;
+    const bool in_range = pt < n_pts;
     mskf_point2f pin = {0.f, 0.f};
     if (in_range) pin = S.in_pts[pt];
     unsigned int dbg_iters = 0, dbg_t = 0;
@@ -874,6 +878,21 @@ __global__ __launch_bounds__(64) void k_track4(const FeStreamDev *streams, int n
 #endif
         S.status[pt] = (uint8_t)(ok ? (1 | (sst ? 2 : 0)) : 0);
     }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bookkeeping (fe_book.h)
+#include "fe_book.h"
+// One workgroup per VIO stream: which = 0 after the first track call of the frame, 1 after the second.
+__global__ __launch_bounds__(256) void k_fe_book(const FeBookDev *books, int which) {
+    const FeBookDev &B = books[blockIdx.x];
+    extern __shared__ int s_book[];
+    FeBookScratch L;
+    fe_book_scratch_init(L, s_book, B.cap, B.det_cap, B.n_codes, B.det_rows * B.det_cols);
+    if (which == 0) fe_book1(B, L); else fe_book2(B, L);
+}
+extern "C" void fe_launch_book(const FeBookDev *books_dev, int n_streams, int which, size_t scratch_bytes, hipStream_t st) {
+    hipLaunchKernelGGL(k_fe_book, dim3(n_streams), dim3(256), scratch_bytes, st, books_dev, which);
 }
 
 // completion mark of the spinning wait (mskf_wait_event): one thread stores a sequence number into pinned host memory

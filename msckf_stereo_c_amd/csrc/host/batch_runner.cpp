@@ -319,6 +319,15 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
         for (int k = 0; k < cnt; ++k) window_phase_s[ph[k]] = on ? -phase_s[ph[k]] : window_phase_s[ph[k]] + phase_s[ph[k]];
     };
     if (win) { mark_dump.fe_valid = mark_dump.ekf_valid = false; }
+    TimedShared *sh = win ? win->shared : nullptr;
+    // a stage follows the shared window at its frame boundaries: 0 -> not opened yet, 1 -> open, 2 -> closed
+    auto follow = [&](bool fe, int &mine, double &t_begin, double &t_end) {
+        if (!sh) return;
+        const int ph = sh->phase.load(std::memory_order_acquire);
+        if (mine == 0 && ph >= 1) { t_begin = now_s(); gate(fe, true); mine = 1; }
+        if (mine == 1 && ph == 2) { t_end = now_s(); gate(fe, false); mine = 2; }
+    };
+    int ekf_mine = 0, fe_mine = 0;
     std::thread consumer([&]() {
         if (win) hostprof::enabled() = false;
         for (;;) {
@@ -334,19 +343,19 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
             }
             cv.notify_all();
             if (ekf_rc.load() != MSKF_OK) continue;   // drain
-            if (win && fb->frame == win->mark_begin) {
-                // (the wait for this very batch belongs to the frame before the window)
-                win->t_ekf_begin = now_s();
-                gate(false, true);
-            }
+            if (win) { follow(false, ekf_mine, win->t_ekf_begin, win->t_ekf_end); if (ekf_mine == 1) ++win->ekf_frames; }
             const double ti = now_s();
             int rc = feed_imu(fb->frame, false, true);
             phase_s[PH_IMU_EKF] += now_s() - ti;
             if (rc == MSKF_OK) rc = step_ekf(fb.get());
             if (rc != MSKF_OK) ekf_rc.store(rc);
+            if (sh && rc == MSKF_OK) {
+                // the frame is through both stages: it counts; the thread that completes the opening / closing frame stamps the window
+                const long c = sh->completed.fetch_add(1) + 1;
+                if (c == sh->target_open) { sh->t_open = now_s(); sh->phase.store(1, std::memory_order_release); }
+                if (c == sh->target_close) { sh->t_close = now_s(); sh->phase.store(2, std::memory_order_release); }
+            }
             if (win && fb->frame == win->mark_end - 1) {
-                win->t_ekf_end = now_s();
-                gate(false, false);
                 if (rc == MSKF_OK) {
                     const IMUState &st = systems_[0]->msckfvio_ptr()->imuState();
                     int k = 0;
@@ -359,7 +368,6 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
                     for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.t_cam0_imu[i];
                     mark_dump.ekf_valid = true;
                 }
-                if (win->groups_done) win->groups_done->fetch_add(1);
             }
             { std::lock_guard<std::mutex> lk(mu); pool.push_back(std::move(fb)); }
         }
@@ -370,10 +378,10 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
     for (;; ++k) {
         if (rc != MSKF_OK || ekf_rc.load() != MSKF_OK) break;
         if (k >= first + n_frames) {
-            // cool-down: keep the device loaded until every group has closed its window
-            if (!win || !win->groups_done || win->groups_done->load() >= win->n_groups || k >= first + n_frames + win->max_extra) break;
+            // past its own frames a group keeps the device loaded until the shared window is closed
+            if (!sh || sh->phase.load() == 2 || k >= first + n_frames + win->max_extra) break;
         }
-        if (win && k == win->mark_begin) { win->t_fe_begin = now_s(); gate(true, true); }
+        if (win) { follow(true, fe_mine, win->t_fe_begin, win->t_fe_end); if (fe_mine == 1) ++win->fe_frames; }
         if (pacer && k < first + n_frames) {
             // not more than `slack` frames ahead of the slowest group (cool-down frames are not paced: the others are finishing)
             const double tp = now_s();
@@ -421,8 +429,6 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
         phase_s[PH_FE_QWAIT] += now_s() - tw;
         if (pacer) pacer->done[pacer_slot].store(k + 1 >= first + n_frames ? 0x7fffffff : k + 1 - first, std::memory_order_relaxed);
         if (win && k == win->mark_end - 1) {
-            win->t_fe_end = now_s();
-            gate(true, false);
             std::vector<ImageProcessor::FeatureIDType> ids;
             systems_[0]->imgproc_ptr_->dumpCurrent(ids, mark_dump.life, mark_dump.c0, mark_dump.c1);
             mark_dump.ids.assign(ids.begin(), ids.end());
@@ -433,8 +439,13 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
     { std::lock_guard<std::mutex> lk(mu); producer_done = true; }
     cv.notify_all();
     consumer.join();
+    if (win) {
+        // a stage whose gates are still open closes them now (the window closed while it was inside its last frame)
+        if (fe_mine == 1) { win->t_fe_end = now_s(); gate(true, false); }
+        if (ekf_mine == 1) { win->t_ekf_end = now_s(); gate(false, false); }
+        win->frames_done = k - first;
+    }
     hostprof::enabled() = true;
-    if (win) win->frames_done = k - first;
     if (rc == MSKF_OK) rc = ekf_rc.load();
     return rc;
 }
@@ -500,21 +511,25 @@ int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
 }
 
 int MultiRunner::pace_slack() {
-    static const int v = [] { const char *e = std::getenv("MSKF_PACE"); const int x = e ? std::atoi(e) : 2; return x < 0 ? 0 : x; }();
+    static const int v = [] { const char *e = std::getenv("MSKF_PACE"); const int x = e ? std::atoi(e) : 0; return x < 0 ? 0 : x; }();
     return v;
 }
 
 int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s) {
     std::vector<int> rcs(n_groups_, MSKF_OK);
-    std::atomic<int> done{0};
+    TimedShared shared;
+    shared.target_open = (long)n_groups_ * warmup;
+    shared.target_close = (long)n_groups_ * (warmup + steps);
+    if (warmup <= 0) { shared.t_open = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); shared.phase.store(1); }
     std::vector<int> from(n_groups_), cnt(n_groups_);
     for (int g = 0; g < n_groups_; ++g) {
         from[g] = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
         cnt[g] = first + off_[g] + warmup + steps - from[g];
         TimedWindow &w = win_[g];
         w = TimedWindow();
-        w.mark_begin = first + off_[g] + warmup; w.mark_end = w.mark_begin + steps;
-        w.max_extra = max_extra; w.groups_done = &done; w.n_groups = n_groups_;
+        w.shared = &shared;
+        w.mark_end = first + off_[g] + warmup + steps;
+        w.max_extra = max_extra;
         groups_[g]->set_gates(false);
     }
     std::unique_ptr<Pacer> pacer;
@@ -526,16 +541,13 @@ int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, doub
     std::vector<std::thread> th;
     for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = groups_[g]->run_pipelined(from[g], cnt[g], &win_[g], pacer.get(), g); });
     for (auto &t : th) t.join();
-    double t0 = 0, t1 = 0;
     for (int g = 0; g < n_groups_; ++g) {
         next_[g] = from[g] + win_[g].frames_done;
         groups_[g]->set_gates(true);
-        if (g == 0 || win_[g].t_fe_begin < t0) t0 = win_[g].t_fe_begin;
-        if (g == 0 || win_[g].t_ekf_end > t1) t1 = win_[g].t_ekf_end;
     }
     for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
-    for (int g = 0; g < n_groups_; ++g) if (win_[g].t_ekf_end <= 0 || win_[g].t_fe_begin <= 0) return MSKF_ERR_INVALID;   // a window never closed
-    if (elapsed_s) *elapsed_s = t1 - t0;
+    if (shared.phase.load() != 2) return MSKF_ERR_INVALID;        // the window never closed
+    if (elapsed_s) *elapsed_s = shared.t_close - shared.t_open;
     return MSKF_OK;
 }
 

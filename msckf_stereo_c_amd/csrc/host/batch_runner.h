@@ -27,18 +27,28 @@ struct StreamSequence {   // a looping pre-rendered stereo sequence + IMU sample
     int imu_cursor_ekf = 0;   // next sample for the filter stage of the pipeline
 };
 
-// A measurement window inside one continuous pipelined run (bench.py): the stages of a group open it when they reach
-// frame `mark_begin` and close it after frame `mark_end - 1`; in between every accounting gate is open (kernel timing of the
-// stage's context, host bookkeeping slots, phase times).  A group that has finished keeps stepping untimed cool-down frames
-// (at most `max_extra`) until every group has closed its window, so the last frames of the window see the same load as the rest.
+// A measurement window inside one continuous pipelined run of all groups (bench.py).  The groups' hardware queues are not
+// served evenly (some groups are a quarter of the run ahead of others), so the window is defined on the WORK, not on any one
+// group's frames: it opens when the groups together have completed n_groups x W frames (front-end and filter) and closes
+// when they have completed n_groups x (W + K) — exactly K steps' worth of stream-frames are finished inside it, with every
+// group busy from before it opens until after it closes (a group runs at least W + K frames and then keeps stepping until
+// the window is closed; frames started before it closes are finished but not counted).  Each stage opens its accounting
+// gates (kernel timing of its context, host bookkeeping slots, phase times) at its first frame boundary inside the window
+// and closes them at the first one after it.
+struct TimedShared {
+    std::atomic<long> completed{0};
+    long target_open = 0, target_close = 0;
+    std::atomic<int> phase{0};               // 0 warm-up, 1 window open, 2 closed
+    double t_open = 0, t_close = 0;          // steady_clock seconds
+};
 struct TimedWindow {
-    int mark_begin = 0, mark_end = 0;        // absolute frame indices of this group
+    TimedShared *shared = nullptr;
+    int mark_end = 0;                        // absolute frame index: the sentinel snapshot is taken after frame mark_end - 1 of this group
     int max_extra = 0;
-    std::atomic<int> *groups_done = nullptr;
-    int n_groups = 1;
     // results
-    double t_fe_begin = 0, t_fe_end = 0, t_ekf_begin = 0, t_ekf_end = 0;   // steady_clock seconds
-    int frames_done = 0;                     // frames the group processed in this run, cool-down included
+    double t_fe_begin = 0, t_fe_end = 0, t_ekf_begin = 0, t_ekf_end = 0;   // when the stages opened / closed their gates
+    int fe_frames = 0, ekf_frames = 0;       // frames each stage started between its open and close
+    int frames_done = 0;                     // frames the group processed in this run
 };
 
 // Pacing of the groups of a MultiRunner run: every group's front-end stage publishes how many frames of the run it has
@@ -157,12 +167,11 @@ class MultiRunner {
     void imu(int stream, const mskf_imu_sample &s) { int l; BatchGroup &g = group_of(stream, l); g.imu(l, s); }
     int step(const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, const double *t);
     int run(int first, int n, bool threaded, bool pipelined = false);
-    // `warmup` untimed + `steps` timed frames of every group in ONE pipelined run (no fill / drain at the boundary), then
-    // cool-down frames until every group has closed its window.  *elapsed_s = latest filter-stage close - earliest
-    // front-end open over the groups: every one of the steps x streams frames is processed entirely inside that span.
+    // ONE pipelined run of every group (no fill / drain at the warm-up / timed boundary): *elapsed_s = the time in which the
+    // groups together completed frames n_groups x warmup + 1 ... n_groups x (warmup + steps) of the run (TimedShared).
     int run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s);
     int frames_done(int g) const { return next_[g]; }          // next frame index of group g (absolute)
-    static int pace_slack();                                   // MSKF_PACE (default 2 frames; 0 = groups are not paced)
+    static int pace_slack();                                   // MSKF_PACE = slack in frames (default 0: groups are not paced)
     const TimedWindow &window(int g) const { return win_[g]; }
     // group g works `g * delta` frames ahead of the frame index passed to run(): replicas of one looping sequence in
     // different groups then never read the same stereo pair at the same time (no cache sharing across groups).  The

@@ -54,10 +54,11 @@ int mskfh_runner_run_timed(void *h, int first, int warmup, int steps, int max_ex
     return ((MultiRunner *)h)->run_timed(first, warmup, steps, max_extra, elapsed_s);
 }
 int mskfh_runner_frames_done(void *h, int g) { return ((MultiRunner *)h)->frames_done(g); }
-// marks of group g's last timed window: [0] front-end open, [1] front-end close, [2] filter open, [3] filter close (steady clock, s)
-void mskfh_runner_window(void *h, int g, double out[4]) {
+// group g's stages in the last timed window: [0] front-end open, [1] front-end close, [2] filter open, [3] filter close (steady
+// clock, s), [4] frames the front-end started inside, [5] frames the filter started inside
+void mskfh_runner_window(void *h, int g, double out[6]) {
     const TimedWindow &w = ((MultiRunner *)h)->window(g);
-    out[0] = w.t_fe_begin; out[1] = w.t_fe_end; out[2] = w.t_ekf_begin; out[3] = w.t_ekf_end;
+    out[0] = w.t_fe_begin; out[1] = w.t_fe_end; out[2] = w.t_ekf_begin; out[3] = w.t_ekf_end; out[4] = w.fe_frames; out[5] = w.ekf_frames;
 }
 // wall seconds per phase inside the last timed window, summed over groups (each stage between its own marks)
 void mskfh_runner_get_window_phases(void *h, double *out) {

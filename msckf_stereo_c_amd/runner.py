@@ -126,9 +126,10 @@ class Runner:
         self._chk(self.L.mskfh_runner_run(self.h, first, n, int(threaded), int(pipelined)))
 
     def run_timed(self, first, warmup, steps, max_extra=8):
-        """`warmup` untimed + `steps` timed frames of every group in ONE pipelined run (no fill / drain of the group pipelines
-        at the boundary), then untimed cool-down frames until every group is through.  Returns the seconds from the first
-        group's front-end reaching frame first + warmup to the last group's filter finishing frame first + warmup + steps - 1."""
+        """ONE pipelined run of every group over at least `warmup` + `steps` frames (no fill / drain of the group pipelines at
+        the boundary).  Returns the seconds in which the groups together completed frames n_groups * warmup + 1 ..
+        n_groups * (warmup + steps) of the run: exactly `steps` steps' worth of stream-frames, with every group busy from
+        before that window opens until after it closes (MultiRunner::run_timed)."""
         el = C.c_double(0.0)
         self._chk(self.L.mskfh_runner_run_timed(self.h, first, warmup, steps, max_extra, C.byref(el)))
         return el.value
@@ -138,9 +139,9 @@ class Runner:
         return self.L.mskfh_runner_frames_done(self.h, group)
 
     def window(self, group=0):
-        out = np.zeros(4)
+        out = np.zeros(6)
         self.L.mskfh_runner_window(self.h, group, _p(out))
-        return dict(zip(("fe_open", "fe_close", "ekf_open", "ekf_close"), (float(x) for x in out)))
+        return dict(zip(("fe_open", "fe_close", "ekf_open", "ekf_close", "fe_frames", "ekf_frames"), (float(x) for x in out)))
 
     def mark_dump(self, group=0):
         """(ids, lifetimes, cam0, cam1, imu_state[28]) of local stream 0 of a group at the close of its timed window."""

@@ -545,14 +545,24 @@ def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
     gated-out block sits in the middle (st <= na < me).  H^T H is singular by construction there, and the reference does
     not compress such a stack at all (msckf_vio.cpp:818-821): auto mode must not take the Gram path, and the rows do not
     fit the uncompressed work buffers with their gap, so the Householder TSQR takes them (the same measurement, rotated).
-    The middle feature is made an outlier (its observations shifted), which the gate rejects."""
+    The middle feature is made an outlier (its observations pushed apart, alternately), which the gate rejects."""
     calib = oracle.euroc_calib(376, 240)
     cfg = default_ekf_cfg(max_cam_state_size=30)
     hit = 0
-    for seed in range(300, 340):
-        pr = ekf_problems.make_problem(calib, seed=seed, n_clones=30, n_feat=3, min_obs=9)
+    for seed in range(300, 312):
+        # three features seen by every clone; the first and the last are then cut down to five clones each (disjoint),
+        # the middle one keeps all thirty: 17 + 17 stacked rows on 60 active columns, the last stacked row at 17 + 117 + 17
+        full = ekf_problems.make_problem(calib, seed=seed, n_clones=30, n_feat=3, min_obs=30)
+        keep = [np.arange(0, 5), np.arange(0, 30), np.arange(10, 15)]
+        os_, oc, oz = [0], [], []
+        for j in range(3):
+            a = full["obs_start"][j]
+            for k in keep[j]:
+                oc.append(int(full["obs_clone"][a + k])); oz.append(full["obs_z"][a + k].copy())
+            os_.append(len(oc))
+        pr = dict(full, obs_start=np.array(os_, np.int32), obs_clone=np.array(oc, np.int32), obs_z=np.array(oz))
         a, b = pr["obs_start"][1], pr["obs_start"][2]
-        pr["obs_z"][a:b] += 0.05                       # the middle feature becomes a gross outlier
+        pr["obs_z"][a:b] += 0.2 * np.where(np.arange(b - a) % 2 == 0, 1.0, -1.0)[:, None]      # the middle feature becomes a gross outlier
         ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"], pr["obs_clone"],
                                         pr["obs_z"], -1)
         if list(ref["passed"]) != [1, 0, 1]:
@@ -561,8 +571,7 @@ def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
         st, me = int((4 * n_obs[[0, 2]] - 3).sum()), int((4 * n_obs - 3).sum())
         used = sorted(set(int(c) for j in (0, 2) for c in pr["obs_clone"][pr["obs_start"][j]:pr["obs_start"][j + 1]]))
         na = 6 * len(used)
-        if not (st <= na < me):
-            continue
+        assert st <= na < me
         hit += 1
         s = capi.Stream(gpu_ctx, calib, default_fe_cfg(), cfg)
         s.ekf_set_cov(pr["P"])
@@ -573,7 +582,7 @@ def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
         assert got["used_qr"] == 1, "st <= na < me must be triangularised by the TSQR, not squared into H^T H"
         assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 1e-11
         assert np.abs(got["delta_x"] - ref["delta_x"]).max() / np.abs(ref["delta_x"]).max() < 1e-9
-    assert hit >= 2, "the generator produced no st <= na < me case: widen the seed range"
+    assert hit >= 2, "the oracle gated no [pass, reject, pass] case: widen the seed range"
 
 
 def test_compression_mode_is_validated(gpu_ctx, oracle):

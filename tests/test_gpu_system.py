@@ -523,51 +523,56 @@ def test_staggered_groups_run_ahead(oracle):
 
 
 def test_timed_window_inside_one_pipelined_run(oracle):
-    """MultiRunner::run_timed (bench.py): warm-up + timed steps in ONE pipelined run with per-stage marks and untimed
-    cool-down frames.  The sentinel snapshot taken when the stages close the window equals the oracle at exactly that
-    frame (whatever the cool-down added), the window is non-empty and ordered, each thread's phase times add up to its
-    window, and the trajectory over all frames stays within tolerance."""
-    w, h, prime, warm, steps, delta = 376, 240, 26, 3, 9, 5
+    """MultiRunner::run_timed (bench.py): warm-up + timed steps in ONE pipelined run.  The window is defined on the work
+    (it opens when the groups together have completed n_groups x warm-up frames and closes at n_groups x (warm-up + steps)),
+    every group runs at least warm-up + steps frames and keeps stepping until the window is closed.  The sentinel snapshot
+    taken after frame warm-up + steps of a group equals the oracle at exactly that frame whatever the group did afterwards,
+    each stage's phase times add up to its own window, kernels are timed only inside it, and the trajectory over all
+    frames stays within tolerance."""
+    w, h, prime, warm, steps, delta, extra = 376, 240, 26, 3, 9, 5, 12
     fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
     syn = oracle.Synth(seed=0x5EED0061, width=w, height=h)
     keep = []
     run = R.Runner(syn.calib, fe, ekf, 3, 1, host_threads=1)
-    _attach_sequences(oracle, run, [syn, syn, syn], prime + warm + steps + 2 * delta + 8, keep)
+    _attach_sequences(oracle, run, [syn, syn, syn], prime + warm + steps + 2 * delta + extra + 2, keep)
     run.set_stagger(delta)
     run.run(0, prime, threaded=True, pipelined=True)
     run.set_timing(1)
     run.get_timing(reset=True)
-    elapsed = run.run_timed(prime, warm, steps, max_extra=6)
+    elapsed = run.run_timed(prime, warm, steps, max_extra=extra)
     timing = run.get_timing(reset=True)
     run.set_timing(False)
     assert elapsed > 0
     ph = run.get_window_phases()
+    fe_frames = 0
     for g in range(3):
         wd = run.window(g)
-        assert wd["fe_open"] < wd["fe_close"] and wd["ekf_open"] < wd["ekf_close"] and wd["fe_open"] < wd["ekf_close"]
-        assert elapsed >= wd["ekf_close"] - wd["fe_open"] - 1e-9
+        assert wd["fe_open"] < wd["fe_close"] and wd["ekf_open"] < wd["ekf_close"]
+        fe_frames += int(wd["fe_frames"])
         done = run.frames_done(g) - run.group_offset(g)
-        assert prime + warm + steps <= done <= prime + warm + steps + 6
-        # the group's sentinel at the close of the window = the oracle after exactly prime + warm + steps (+ offset) frames
+        assert prime + warm + steps <= done <= prime + warm + steps + extra
+        # the group's sentinel after frame prime + warm + steps (+ offset) = the oracle after exactly that many frames
         osys = oracle.OracleSystem(syn.calib, fe, ekf)
         syn.feed(osys, prime + warm + steps + g * delta)
         ids, life, c0, c1, imu = run.mark_dump(g)
         o = osys.dump()
         assert np.array_equal(o[0], ids) and np.array_equal(o[1], life) and np.array_equal(o[2], c0) and np.array_equal(o[3], c1)
         assert np.abs(osys.imu_state() - imu).max() < POS_TOL
-        # ... and the live state has moved on by the cool-down frames, still equal to the oracle
+        # ... and the live state has moved on by the frames the group stepped while the window was still open
         syn.feed(osys, done - (prime + warm + steps), start=prime + warm + steps + g * delta)
         for x, y in zip(osys.dump()[:4], run.dump(g)[:4]):
             assert np.array_equal(x, y)
         op, gp = osys.poses(), run.poses(g)
         assert len(op) == len(gp) and np.abs(op["p"] - gp["p"]).max() < POS_TOL
+    # the window holds steps x groups completed frames; the stages started about as many inside it
+    assert 3 * steps - 6 <= fe_frames <= 3 * steps + 6
     fe_sum = sum(ph[k] for k in R.Runner.FE_THREAD_PHASES)
     fe_win = sum(run.window(g)["fe_close"] - run.window(g)["fe_open"] for g in range(3))
     ekf_sum = sum(ph[k] for k in R.Runner.EKF_THREAD_PHASES)
     ekf_win = sum(run.window(g)["ekf_close"] - run.window(g)["ekf_open"] for g in range(3))
     assert abs(fe_sum - fe_win) < 0.02 * fe_win + 1e-3 and abs(ekf_sum - ekf_win) < 0.02 * ekf_win + 1e-3
-    # kernels are timed only inside the window: exactly `steps` pyramid passes (3 levels) per group
-    assert timing["k_pyr_down"][1] == 3 * steps * 3
+    # kernels are timed only inside the window: three pyramid passes per front-end frame started in it
+    assert timing["k_pyr_down"][1] == 3 * fe_frames
     run.close()
 
 
