@@ -32,7 +32,21 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LK_BYTES_PER_TRACK = 4 * (17 * 17 + 16 * 16)      # 4 levels x (17x17 template + 16x16 search footprint) u8
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6                           # FP64 matrix peak
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2                # wave-instructions/s: 1024 SIMD-32, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
+
+
+def _profile(name):
+    """Newest committed summary of a counter pass (profiles/rNN_<name>.json)."""
+    for rnd in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r03_%s.json" % name)
+
+
+PMC_TRAFFIC_FILE = _profile("pmc_hbm_traffic")
+PMC_SQ_FILE = _profile("pmc_sq")
+PMC_MFMA_FILE = _profile("pmc_mfma_c2")
 
 # BASELINE.json configs (SURVEY.md §8 table): image, clone window, grid rows x cols x min x max, streams per GPU, groups
 CONFIGS = {
@@ -71,6 +85,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-all-frames", type=int, default=None, help="frames per stream of the all-cores CPU-oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("MSKF_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--compression", choices=["auto", "gram", "tsqr"], default="auto",
+                    help="QR compression of the stacked Jacobian (msckf_vio.cpp:795-817): auto = Gram + regularised Cholesky with the "
+                         "Householder TSQR where the device decides it is needed (default), gram = Gram only, tsqr = the literal Householder path always")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reductions, "
                     "JSON line) without any device work: for the gloo tests only, the line it prints says so")
@@ -118,7 +135,8 @@ def launch_ranks(args, argv):
 def make_cfgs(args):
     from msckf_stereo_c_amd.ctypes_types import default_ekf_cfg, default_fe_cfg
     r, c, mn, mx = (int(x) for x in args.grid.split("x"))
-    return default_fe_cfg(grid_row=r, grid_col=c, grid_min=mn, grid_max=mx), default_ekf_cfg(max_cam_state_size=args.clones)
+    return (default_fe_cfg(grid_row=r, grid_col=c, grid_min=mn, grid_max=mx),
+            default_ekf_cfg(max_cam_state_size=args.clones, compression_mode={"auto": 0, "gram": 1, "tsqr": 2}[args.compression]))
 
 
 def sequence_seed(rank, world, u):
@@ -501,7 +519,7 @@ def main(argv=None):
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
         else:
-            per_unit = {"k_lk_points4": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
+            per_unit = {"k_track4": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
             achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
@@ -521,12 +539,47 @@ def main(argv=None):
             pass
         roof["avg_launch_us"] = avg_s * 1e6
         roof["units_per_launch"] = units / max(launches, 1)
+        # HBM is not what bounds the track kernel (traffic is half its algorithmic bytes, it runs at a few per cent of the HBM
+        # peak): its governing roof is VALU issue.  Instructions per wave and waves per launch from the committed SQ counter pass
+        # (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, collected at `streams_per_launch` streams, scaled to this run's launches).
+        try:
+            sq_all = json.load(open(PMC_SQ_FILE))
+            sq = sq_all["kernels"].get(dom)
+            spl = sq_all.get("streams_per_launch", 96)
+            if sq and args.config == sq_all.get("config", "c2"):
+                wave_insts = sq["valu_insts_per_wave"] * sq["waves_per_dispatch"] * per_group / spl
+                roof["valu_issue"] = {"bound": "valu", "insts_per_wave": sq["valu_insts_per_wave"], "waves_per_launch": sq["waves_per_dispatch"] * per_group / spl,
+                                      "achieved": wave_insts / avg_s, "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+                                      "frac": wave_insts / avg_s / VALU_ISSUE_PEAK, "source": os.path.relpath(PMC_SQ_FILE, ROOT)}
+                if dom == "k_track4" and roof["units_per_launch"] > 0:
+                    # wave-instructions per point track (a wavefront carries four points: round 2's 7026 per wave = 1757 per point)
+                    roof["valu_issue"]["insts_per_point_track"] = wave_insts / roof["units_per_launch"]
+        except Exception:
+            pass
         kernels = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)} for k, v in timing.items() if v[1]}
         # FP64 matrix-core rate of the dense update kernels alone (the meaningful MFMA number is per kernel)
         gm = timing.get("k_ekf_gemm", (0, 0, 0))
         mfma = {"kernel": "k_ekf_gemm", "tflops": (gm[2] / (gm[0] * 1e-3) / 1e12) if gm[0] > 0 else None, "peak": FP64_PEAK_TFLOPS}
         if mfma["tflops"] is not None:
             mfma["frac"] = mfma["tflops"] / FP64_PEAK_TFLOPS
+            mfma["note"] = "tflops / frac are over SURVEY 8(d)'s ALGORITHMIC flops (dense-d formulas); executed_* are what the matrix cores did"
+        # executed flops: SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed counter pass, per launch and mode, weighted by the modes'
+        # dispatch counts, scaled from that pass's streams per launch to this run's; over the launch time measured in THIS run
+        try:
+            mm = json.load(open(PMC_MFMA_FILE))
+            spl = mm.get("streams_per_launch", 96)
+            modes = {k: v for k, v in mm["kernels"].items() if k.startswith("k_ekf_gemm")}
+            nd = sum(v["dispatches"] for v in modes.values())
+            if nd and gm[1] > 0 and args.config == mm.get("config", "c2"):
+                gflop = sum(v["fp64_mfma_gflop_per_dispatch"] * v["dispatches"] for v in modes.values()) / nd * per_group / spl
+                t_launch = gm[0] * 1e-3 / gm[1]
+                mfma["executed_gflop_per_launch"] = gflop
+                mfma["executed_tflops"] = gflop * 1e9 / t_launch / 1e12
+                mfma["executed_frac"] = mfma["executed_tflops"] / FP64_PEAK_TFLOPS
+                mfma["executed_alone"] = {k: {"tflops": v["tflops"], "mfma_busy_pct_simd": v["mfma_busy_pct_simd"]} for k, v in modes.items()}
+                mfma["source"] = os.path.relpath(PMC_MFMA_FILE, ROOT)
+        except Exception:
+            pass
         seq_note = ("%d distinct looping sequences per GPU, one per stream of a group" % args.unique
                     + ("" if not max_offset else "; the %d groups replay them %d frames apart (never the same stereo pair at the same time)"
                        % (n_groups, args.stagger))
@@ -560,7 +613,7 @@ def main(argv=None):
                                    % (CONFIGS[args.config]["name"], args.config, args.width, args.height, args.clones, args.grid, n_feat, n_streams,
                                       n_groups, args.host_threads, ", FE|EKF pipelined" if pipe else "", seq_note),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
-                       "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": run.num_tsqr_updates(0),
+                       "compression": args.compression, "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": run.num_tsqr_updates(0),
                        "ekf_uncompressed_updates_stream0": run.num_uncompressed_updates(0),
                        "ekf_rows_per_update_stream0": round(run.stacked_rows(0) / max(n_upd, 1), 1),
                        "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1), "kernel_timing_period": timing_period,

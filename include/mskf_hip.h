@@ -61,7 +61,7 @@ void *mskf_ctx_hip_stream(mskf_ctx *ctx);
  * 7 % of the throughput at the C2 bench shape and 36 % at C5 (one stream per launch), measured. */
 enum {
     MSKF_K_PYR = 0, MSKF_K_DETECT, MSKF_K_LK, MSKF_K_EKF_PROPAGATE, MSKF_K_EKF_AUGMENT, MSKF_K_EKF_FEATURES,
-    MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_COUNT
+    MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_FE_BOOK, MSKF_K_COUNT
 };
 int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
 /* Accounting gate (default on): while it is off, launches are not timed and host seconds not accumulated.  Unlike
@@ -139,6 +139,40 @@ int mskf_fe_track_batch_end(mskf_ctx *ctx);
 
 /* curr cam0 pyramid becomes the prev pyramid (image_processor.cpp:194) */
 int mskf_fe_swap(mskf_stream *s);
+
+/* ---- a whole front-end frame on the device
+ * Replaces, for every frame after the first, ALL of cg::ImageProcessor::stereoCallback between the image copy and
+ * publish() (image_processor.cpp:148-200): createImagePyramids, trackFeatures (:352-532), addNewFeatures (:622-756),
+ * pruneGridFeatures (:758-768) and the state rotation (:192-200).  The live grid stays in device memory from frame to
+ * frame; one call enqueues pyramids + detector, the temporal and stereo track of the previous features, the bookkeeping
+ * between (survivors, occupancy, detections, per-cell sieve, candidates), the candidates' stereo track and the bookkeeping
+ * after it (vacancy fill, ids, pruning), and returns the published grid: ids, lifetimes, pixels and the undistorted
+ * points publish() writes into the message (:1137-1182).  One host wait per frame instead of two, no points travel to
+ * the device.  Limits: grid_min / grid_max_feature_num <= 16 (mskf_fe_grid_capacity returns 0 otherwise) and no 2-point
+ * RANSAC between the tracks (MSKF_COMPAT_Q5_NO_RANSAC set, as in the reference); the caller keeps those frames, and the
+ * first frame of a stream, on the mskf_fe_track path and hands the grid over with mskf_fe_set_grid. */
+typedef struct mskf_fe_frame_args {
+    double Hpred[9];              /* in: K R_p_c K^-1 of this frame (image_processor.cpp:335-340) */
+    int32_t capacity;             /* in: entries each output array holds, >= mskf_fe_grid_capacity(stream) */
+    int32_t n;                    /* out: features of the published grid, in flatten order (ascending grid code) */
+    uint64_t *id;                 /* out */
+    int32_t *lifetime;            /* out */
+    mskf_point2f *cam0, *cam1;    /* out: pixels */
+    mskf_point2f *und0, *und1;    /* out: undistorted normalised coordinates */
+    int32_t before_tracking, after_tracking, after_matching, after_ransac;   /* out: TrackingInfo (:514-530) */
+    int32_t n_candidates, n_new;  /* out: candidates stereo-matched for the vacancies, features created */
+    uint64_t next_feature_id;     /* out: the stream's id counter after this frame */
+} mskf_fe_frame_args;
+/* entries a published grid can have: (grid codes) x grid_max_feature_num; 0 = this stream keeps its books on the host */
+int mskf_fe_grid_capacity(mskf_stream *s);
+/* Hand the device the grid a host-side frame has published (the first frame of a stream), with the id counter and the
+ * tracking counters that survive frames without features (:383).  Synchronous. */
+int mskf_fe_set_grid(mskf_stream *s, int n, const uint64_t *id, const int32_t *lifetime, const mskf_point2f *cam0, const mskf_point2f *cam1,
+                     const mskf_point2f *und0, const mskf_point2f *und1, uint64_t next_feature_id, const int32_t tracking_counters[3]);
+/* streams / args must stay valid until _end; the pyramid swap of :194 is part of the call */
+int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0, const uint8_t *const *cam1,
+                              int on_device, mskf_fe_frame_args *args);
+int mskf_fe_frame_batch_end(mskf_ctx *ctx);
 
 /* download pyramid level `level` (0..3) of image role 0: prev cam0, 1: curr cam0, 2: curr cam1 (parity tests) */
 int mskf_fe_get_level(mskf_stream *s, int role, int level, uint8_t *out, int capacity, int *w, int *h);

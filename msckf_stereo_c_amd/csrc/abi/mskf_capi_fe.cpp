@@ -60,6 +60,8 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
     for (int i = 0; i < 3; ++i) c->desc[i].release();
     c->cell_arena.release(); c->trk_in.release(); c->trk_out.release(); c->upd_in.release(); c->upd_out.release();
     c->jobs.release();
+    c->book_desc.release(); c->book_out.release();
+    if (c->pend_frame.done) (void)hipEventDestroy(c->pend_frame.done);
     c->ekf_desc.release();
     c->pred_arena.release();
     if (c->pred_done) (void)hipEventDestroy(c->pred_done);
@@ -218,6 +220,56 @@ void fill_pyr(const mskf_stream *s, int idx, PyrDev &p) {
     if (s->lvl0[idx]) p.lvl[0] = s->lvl0[idx];
 }
 
+// Device-side books of a stream (fe_book.h): the three feature lists, detection / candidate lists and the results of the two
+// track calls, in ONE allocation.  Streams whose grid_min / grid_max exceed the short-list bound of the kernels keep their
+// books on the host (cap stays 0).
+static int book_alloc(mskf_stream *s) {
+    mskf_stream::Book &K = s->book;
+    const mskf_fe_cfg &fe = s->fe;
+    if (fe.grid_min_feature_num > FB_MAXK || fe.grid_max_feature_num > FB_MAXK || fe.grid_min_feature_num < 0 ||
+        fe.grid_max_feature_num < fe.grid_min_feature_num) return MSKF_OK;
+    K.grid_h = s->h / fe.grid_row; K.grid_w = s->w / fe.grid_col;                 // image_processor.cpp:250-251
+    if (K.grid_h <= 0 || K.grid_w <= 0) return MSKF_OK;
+    K.n_cells = fe.grid_row * fe.grid_col;
+    K.n_codes = std::max(((s->h - 1) / K.grid_h) * fe.grid_col + (s->w - 1) / K.grid_w + 1, K.n_cells);   // Q7: partial rows / columns
+    const int cap = K.n_codes * std::max(fe.grid_max_feature_num, 1) + 8;
+    const int cand_cap = K.n_cells * std::max(fe.grid_max_feature_num, 1) + 8;
+    const int det_cap = fe.det_rows * fe.det_cols;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_st = take(sizeof(FeBookState));
+    size_t o_grid[3][8];
+    for (int g = 0; g < 3; ++g) {
+        o_grid[g][0] = take(8 * (size_t)cap); o_grid[g][1] = take(4 * (size_t)cap); o_grid[g][2] = take(4 * (size_t)cap); o_grid[g][3] = take(4 * (size_t)cap);
+        for (int q = 4; q < 8; ++q) o_grid[g][q] = take(8 * (size_t)cap);
+    }
+    const size_t o_det_pt = take(8 * (size_t)det_cap), o_det_sc = take(4 * (size_t)det_cap);
+    const size_t o_cpt = take(8 * (size_t)cand_cap), o_cidx = take(4 * (size_t)cand_cap), o_csc = take(4 * (size_t)cand_cap);
+    const size_t o_coff = take(4 * (size_t)(K.n_cells + 1)), o_ccnt = take(4 * (size_t)(K.n_cells + 1)), o_cell = take(4 * (size_t)(K.n_codes + 1));
+    size_t o_t[5], o_c[5];
+    for (int q = 0; q < 4; ++q) o_t[q] = take(8 * (size_t)cap);
+    o_t[4] = take((size_t)cap);
+    for (int q = 0; q < 4; ++q) o_c[q] = take(8 * (size_t)cand_cap);
+    o_c[4] = take((size_t)cand_cap);
+    MSKF_HIPCHK(hipMalloc((void **)&K.mem, off));
+    MSKF_HIPCHK(hipMemsetAsync(K.mem, 0, off, s->ctx->stream));
+    MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    char *m = K.mem;
+    K.st = (FeBookState *)(m + o_st);
+    for (int g = 0; g < 3; ++g)
+        K.grid[g] = FeGridArr{(unsigned long long *)(m + o_grid[g][0]), (int *)(m + o_grid[g][1]), (int *)(m + o_grid[g][2]), (float *)(m + o_grid[g][3]),
+                              (mskf_point2f *)(m + o_grid[g][4]), (mskf_point2f *)(m + o_grid[g][5]), (mskf_point2f *)(m + o_grid[g][6]), (mskf_point2f *)(m + o_grid[g][7])};
+    K.det_pt = (mskf_point2f *)(m + o_det_pt); K.det_score = (int *)(m + o_det_sc);
+    K.cand_pt = (mskf_point2f *)(m + o_cpt); K.cand_index = (int *)(m + o_cidx); K.cand_score = (int *)(m + o_csc);
+    K.cand_off = (int *)(m + o_coff); K.cand_cnt = (int *)(m + o_ccnt); K.cell_count = (int *)(m + o_cell);
+    K.t_out0 = (mskf_point2f *)(m + o_t[0]); K.t_out1 = (mskf_point2f *)(m + o_t[1]); K.t_und0 = (mskf_point2f *)(m + o_t[2]); K.t_und1 = (mskf_point2f *)(m + o_t[3]);
+    K.t_status = (uint8_t *)(m + o_t[4]);
+    K.c_out0 = (mskf_point2f *)(m + o_c[0]); K.c_out1 = (mskf_point2f *)(m + o_c[1]); K.c_und0 = (mskf_point2f *)(m + o_c[2]); K.c_und1 = (mskf_point2f *)(m + o_c[3]);
+    K.c_status = (uint8_t *)(m + o_c[4]);
+    K.cap = cap; K.cand_cap = cand_cap; K.det_cap = det_cap;
+    return MSKF_OK;
+}
+
 extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
                                   mskf_stream **out) {
     if (!ctx || !calib || !fe || !ekf || !out) return MSKF_ERR_INVALID;
@@ -276,6 +328,8 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
     s->epi_thresh = fe->stereo_threshold * norm_pixel_unit;
     s->det_ch = (s->h + fe->det_rows - 1) / fe->det_rows;
     s->det_cw = (s->w + fe->det_cols - 1) / fe->det_cols;
+    rc = book_alloc(s);
+    if (rc != MSKF_OK) { mskf_stream_destroy(s); return rc; }
     ctx->streams.push_back(s);
     *out = s;
     return MSKF_OK;
@@ -298,6 +352,7 @@ extern "C" void mskf_stream_destroy(mskf_stream *s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx_ekf && s->ctx_ekf != s->ctx) (void)hipStreamSynchronize(s->ctx_ekf->stream);
     for (int i = 0; i < 3; ++i) if (s->pyr[i]) (void)hipFree(s->pyr[i]);
+    if (s->book.mem) (void)hipFree(s->book.mem);
     mskf_ekf_stream_free(s);
     auto &v = s->ctx->streams;
     for (size_t i = 0; i < v.size(); ++i) if (v[i] == s) { v.erase(v.begin() + i); break; }
@@ -318,8 +373,15 @@ static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
     d.cell_keys = (unsigned long long *)(s->ctx->cell_arena.d + s->cell_off);
 }
 
+static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, bool copy_cells);
+
 extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0,
                                          const uint8_t *const *cam1, int on_device) {
+    return push_batch(ctx, n, streams, cam0, cam1, on_device, true);
+}
+
+// copy_cells = false: the per-cell maxima stay on the device (the bookkeeping kernel of a device frame reads them there)
+static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, bool copy_cells) {
     if (!ctx || n <= 0 || !streams || !cam0 || !cam1) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -397,8 +459,10 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
         fe_launch_detect(ctx->desc[0].d, n, max_w, max_h, gen, st);
         mskf_t_end(ctx, ts, px);
     }
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
-    { const int erc = mskf_wait_event(ctx, &ctx->cell_ev, true); if (erc != MSKF_OK) return erc; }
+    if (copy_cells) {
+        MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
+        { const int erc = mskf_wait_event(ctx, &ctx->cell_ev, true); if (erc != MSKF_OK) return erc; }
+    }
     MSKF_HIPCHK(hipGetLastError());
     return MSKF_OK;
 }
@@ -610,6 +674,190 @@ extern "C" int mskf_fe_swap(mskf_stream *s) {
     if (!s) return MSKF_ERR_INVALID;
     std::swap(s->i_prev0, s->i_curr0);
     s->has_curr = false;
+    return MSKF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ a whole frame on the device
+extern "C" int mskf_fe_grid_capacity(mskf_stream *s) { return s ? s->book.cap : 0; }
+
+extern "C" int mskf_fe_set_grid(mskf_stream *s, int n, const uint64_t *id, const int32_t *lifetime, const mskf_point2f *cam0, const mskf_point2f *cam1,
+                                const mskf_point2f *und0, const mskf_point2f *und1, uint64_t next_feature_id, const int32_t tracking_counters[3]) {
+    if (!s || n < 0 || (n && (!id || !lifetime || !cam0 || !cam1 || !und0 || !und1))) return MSKF_ERR_INVALID;
+    mskf_stream::Book &K = s->book;
+    if (!K.cap) { mskf_set_error("this stream keeps its books on the host (grid_min / grid_max above the device limit)"); return MSKF_ERR_UNSUPPORTED; }
+    if (n > K.cap) return MSKF_ERR_CAPACITY;
+    MSKF_HIPCHK(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    MSKF_HIPCHK(hipStreamSynchronize(st));
+    const FeGridArr &G = K.grid[K.parity];
+    if (n) {
+        MSKF_HIPCHK(hipMemcpyAsync(G.id, id, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        MSKF_HIPCHK(hipMemcpyAsync(G.lifetime, lifetime, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+        MSKF_HIPCHK(hipMemcpyAsync(G.cam0, cam0, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        MSKF_HIPCHK(hipMemcpyAsync(G.cam1, cam1, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        MSKF_HIPCHK(hipMemcpyAsync(G.und0, und0, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        MSKF_HIPCHK(hipMemcpyAsync(G.und1, und1, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    FeBookState h;
+    std::memset(&h, 0, sizeof(h));
+    h.next_id = next_feature_id; h.n_prev = n; h.n_curr = n;
+    if (tracking_counters) { h.after_tracking = tracking_counters[0]; h.after_matching = tracking_counters[1]; h.after_ransac = tracking_counters[2]; }
+    MSKF_HIPCHK(hipMemcpyAsync(K.st, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipStreamSynchronize(st));
+    K.n_prev = n; K.n_cand_last = -1; K.grid_set = true;
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0, const uint8_t *const *cam1,
+                                         int on_device, mskf_fe_frame_args *args) {
+    if (!ctx || n <= 0 || !streams || !cam0 || !cam1 || !args) return MSKF_ERR_INVALID;
+    if (ctx->pend_frame.active || ctx->pend_trk.active) { mskf_set_error("a batch of this context is still pending"); return MSKF_ERR_INVALID; }
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
+        if (!s->book.cap) { mskf_set_error("this stream keeps its books on the host (grid_min / grid_max above the device limit)"); return MSKF_ERR_UNSUPPORTED; }
+        if (!s->book.grid_set) { mskf_set_error("no grid on the device yet: the first frame goes through mskf_fe_track + mskf_fe_set_grid"); return MSKF_ERR_INVALID; }
+        if (!(s->fe.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC)) { mskf_set_error("the 2-point RANSAC runs between the track calls on the host: use mskf_fe_track"); return MSKF_ERR_UNSUPPORTED; }
+        const mskf_fe_frame_args &a = args[i];
+        if (a.capacity < s->book.cap || !a.id || !a.lifetime || !a.cam0 || !a.cam1 || !a.und0 || !a.und1) return MSKF_ERR_INVALID;
+    }
+    const auto t_h0 = std::chrono::steady_clock::now();
+    int rc = push_batch(ctx, n, streams, cam0, cam1, on_device, false);
+    if (rc != MSKF_OK) return rc;
+    if ((rc = ctx->desc[1].ensure(n)) != MSKF_OK || (rc = ctx->desc[2].ensure(n)) != MSKF_OK || (rc = ctx->book_desc.ensure(n)) != MSKF_OK) return rc;
+    std::vector<size_t> &out_off = ctx->pend_frame.out_off;
+    out_off.resize(n);
+    size_t out_bytes = 0, scratch_bytes = 0;
+    int max_prev = 0, max_cand_est = 0;
+    for (int i = 0; i < n; ++i) {
+        const mskf_stream::Book &K = streams[i]->book;
+        out_off[i] = out_bytes;
+        out_bytes += (64 + 44 * (size_t)K.cap + 255) & ~(size_t)255;
+        scratch_bytes = std::max(scratch_bytes, 4 * fe_book_scratch_ints(K.cap, K.det_cap, K.n_codes, K.det_cap));
+        max_prev = std::max(max_prev, K.n_prev);
+        // candidates are counted on the device: the launch is sized from the last frame's count, a block takes several point
+        // groups if there are more this time
+        const int est = K.n_cand_last < 0 ? K.cand_cap / 2 : std::min(K.cand_cap, K.n_cand_last + K.n_cand_last / 2 + 32);
+        max_cand_est = std::max(max_cand_est, est);
+    }
+    if (out_bytes > ctx->book_out.cap) {
+        MSKF_HIPCHK(hipStreamSynchronize(st));
+        if ((rc = ctx->book_out.ensure(out_bytes)) != MSKF_OK) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        mskf_stream::Book &K = s->book;
+        const mskf_fe_cfg &fe = s->fe;
+        // first track call: the previous grid's cam0 points, temporal + stereo
+        FeStreamDev &d1 = ctx->desc[1].h[i];
+        fill_fe_desc(s, d1);
+        d1.n_pts = K.n_prev; d1.n_pts_dev = nullptr; d1.do_temporal = 1;
+        std::memcpy(d1.Hpred, args[i].Hpred, sizeof(d1.Hpred));
+        d1.in_pts = K.grid[K.parity].cam0;
+        d1.out0 = K.t_out0; d1.out1 = K.t_out1; d1.und0 = K.t_und0; d1.und1 = K.t_und1; d1.status = K.t_status;
+        // second track call: the candidates fe_book1 leaves in the stream's list, stereo only
+        FeStreamDev &d2 = ctx->desc[2].h[i];
+        fill_fe_desc(s, d2);
+        d2.n_pts = 0; d2.n_pts_dev = &K.st->n_cand; d2.do_temporal = 0;
+        d2.Hpred[0] = d2.Hpred[4] = d2.Hpred[8] = 1.0;
+        d2.in_pts = K.cand_pt;
+        d2.out0 = K.c_out0; d2.out1 = K.c_out1; d2.und0 = K.c_und0; d2.und1 = K.c_und1; d2.status = K.c_status;
+        FeBookDev &B = ctx->book_desc.h[i];
+        std::memset(&B, 0, sizeof(B));
+        B.grid_row = fe.grid_row; B.grid_col = fe.grid_col; B.grid_min = fe.grid_min_feature_num; B.grid_max = fe.grid_max_feature_num;
+        B.n_codes = K.n_codes; B.n_cells = K.n_cells; B.grid_w = K.grid_w; B.grid_h = K.grid_h;
+        B.det_rows = fe.det_rows; B.det_cols = fe.det_cols; B.det_cw = s->det_cw; B.det_ch = s->det_ch;
+        B.thr_score = fe.fast_threshold * 256;
+        B.q4 = (fe.compat_flags & MSKF_COMPAT_Q4_RESPONSE_INDEX) ? 1 : 0;
+        B.cap = K.cap; B.cand_cap = K.cand_cap; B.det_cap = K.det_cap;
+        B.gen = (unsigned int)((s->push_gen - 1) % 255ULL) + 1U;
+        B.st = K.st;
+        B.prev = K.grid[K.parity]; B.curr = K.grid[K.parity ^ 1]; B.tracked = K.grid[2];
+        B.t_out0 = K.t_out0; B.t_out1 = K.t_out1; B.t_und0 = K.t_und0; B.t_und1 = K.t_und1; B.t_status = K.t_status;
+        B.cell_keys = (const unsigned long long *)(ctx->cell_arena.d + s->cell_off);
+        B.det_pt = K.det_pt; B.det_score = K.det_score;
+        B.cand_pt = K.cand_pt; B.cand_index = K.cand_index; B.cand_score = K.cand_score; B.cand_off = K.cand_off; B.cand_cnt = K.cand_cnt;
+        B.c_out0 = K.c_out0; B.c_out1 = K.c_out1; B.c_und0 = K.c_und0; B.c_und1 = K.c_und1; B.c_status = K.c_status;
+        B.cell_count = K.cell_count;
+        char *o = ctx->book_out.d + out_off[i];
+        B.x_info = (int *)o;
+        B.x_id = (unsigned long long *)(o + 64);
+        B.x_lifetime = (int *)(o + 64 + 8 * (size_t)K.cap);
+        B.x_cam0 = (mskf_point2f *)(o + 64 + 12 * (size_t)K.cap);
+        B.x_cam1 = B.x_cam0 + K.cap; B.x_und0 = B.x_cam1 + K.cap; B.x_und1 = B.x_und0 + K.cap;
+    }
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[2].d, ctx->desc[2].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->book_desc.d, ctx->book_desc.h, sizeof(FeBookDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    const int ts1 = mskf_t_begin(ctx, MSKF_K_LK);
+    fe_launch_track(ctx->desc[1].d, n, max_prev, st);
+    mskf_t_end(ctx, ts1, 0);
+    int tb = mskf_t_begin(ctx, MSKF_K_FE_BOOK);
+    fe_launch_book(ctx->book_desc.d, n, 0, scratch_bytes, st);
+    mskf_t_end(ctx, tb, n);
+    const int ts2 = mskf_t_begin(ctx, MSKF_K_LK);
+    fe_launch_track(ctx->desc[2].d, n, std::max(max_cand_est, 4), st);
+    mskf_t_end(ctx, ts2, 0);
+    tb = mskf_t_begin(ctx, MSKF_K_FE_BOOK);
+    fe_launch_book(ctx->book_desc.d, n, 1, scratch_bytes, st);
+    mskf_t_end(ctx, tb, n);
+    MSKF_HIPCHK(hipMemcpyAsync(ctx->book_out.h, ctx->book_out.d, out_bytes, hipMemcpyDeviceToHost, st));
+    MSKF_HIPCHK(hipGetLastError());
+    if ((rc = mskf_wait_event(ctx, &ctx->pend_frame.done, true)) != MSKF_OK) return rc;
+    // state rotation (:192-200): the grid just built is the next frame's previous grid, curr cam0 becomes prev cam0
+    for (int i = 0; i < n; ++i) {
+        mskf_stream *s = streams[i];
+        s->book.parity ^= 1;
+        std::swap(s->i_prev0, s->i_curr0);
+        s->has_curr = false;
+    }
+    ctx->pend_frame.active = true; ctx->pend_frame.n = n; ctx->pend_frame.streams = streams; ctx->pend_frame.args = args;
+    ctx->pend_frame.ts1 = ts1; ctx->pend_frame.ts2 = ts2;
+    if (ctx->t_gate) ctx->host_s[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h0).count();
+    return MSKF_OK;
+}
+
+extern "C" int mskf_fe_frame_batch_end(mskf_ctx *ctx) {
+    if (!ctx) return MSKF_ERR_INVALID;
+    mskf_ctx::PendingFrame &F = ctx->pend_frame;
+    if (!F.active) return MSKF_OK;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    F.active = false;
+    int rc;
+    if ((rc = mskf_wait_event(ctx, &F.done, false)) != MSKF_OK) return rc;
+    const auto t_h1 = std::chrono::steady_clock::now();
+    long long tracks1 = 0, tracks2 = 0;
+    bool overflow = false;
+    for (int i = 0; i < F.n; ++i) {
+        mskf_stream *s = F.streams[i];
+        mskf_stream::Book &K = s->book;
+        mskf_fe_frame_args &a = F.args[i];
+        const char *o = ctx->book_out.h + F.out_off[i];
+        const int *info = (const int *)o;
+        const int m = info[0];
+        if (m < 0 || m > K.cap || info[8]) { overflow = true; continue; }
+        a.n = m; a.n_candidates = info[1];
+        a.before_tracking = info[2]; a.after_tracking = info[3]; a.after_matching = info[4]; a.after_ransac = info[5];
+        a.next_feature_id = (uint64_t)(unsigned int)info[6] | ((uint64_t)(unsigned int)info[7] << 32);
+        a.n_new = info[9];
+        std::memcpy(a.id, o + 64, 8 * (size_t)m);
+        std::memcpy(a.lifetime, o + 64 + 8 * (size_t)K.cap, 4 * (size_t)m);
+        const char *p = o + 64 + 12 * (size_t)K.cap;
+        std::memcpy(a.cam0, p, 8 * (size_t)m);
+        std::memcpy(a.cam1, p + 8 * (size_t)K.cap, 8 * (size_t)m);
+        std::memcpy(a.und0, p + 16 * (size_t)K.cap, 8 * (size_t)m);
+        std::memcpy(a.und1, p + 24 * (size_t)K.cap, 8 * (size_t)m);
+        tracks1 += (long long)a.before_tracking + (a.before_tracking > 0 ? a.after_tracking : 0);
+        tracks2 += a.n_candidates;
+        K.n_prev = m; K.n_cand_last = a.n_candidates;
+    }
+    if (F.ts1 >= 0) ctx->t_pending[F.ts1].units = tracks1;
+    if (F.ts2 >= 0) ctx->t_pending[F.ts2].units = tracks2;
+    mskf_t_collect(ctx);
+    if (ctx->t_gate) ctx->host_s[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
+    if (overflow) { mskf_set_error("device bookkeeping reported a capacity overflow"); return MSKF_ERR_CAPACITY; }
     return MSKF_OK;
 }
 

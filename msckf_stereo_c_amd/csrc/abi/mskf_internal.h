@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../../include/mskf_hip.h"
 #include "../hip/fe_device.h"
+#include "../hip/fe_book.h"
 #include "../hip/ekf_device.h"
 #include "host_math.h"
 
@@ -18,6 +19,7 @@ void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_
 int mskf_wait(mskf_ctx *c);
 void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st);
 void fe_launch_track(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st);
+void fe_launch_book(const FeBookDev *books_dev, int n_streams, int which, size_t scratch_bytes, hipStream_t st);
 }
 
 void mskf_set_error(const std::string &s);
@@ -66,7 +68,14 @@ struct mskf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;          // false: created by mskf_ctx_create_shared on another context's stream
-    PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track, 2: reserved
+    PinnedDev<FeStreamDev> desc[3];   // 0: push/detect, 1: track (first track call of a device frame), 2: second track call of a device frame
+    PinnedDev<FeBookDev> book_desc;   // bookkeeping descriptors of a device frame batch
+    PinnedDev<char> book_out;         // what a device frame batch returns: per stream 16 ints + the published grid
+    struct PendingFrame {
+        bool active = false; int n = 0; mskf_stream *const *streams = nullptr; struct mskf_fe_frame_args *args = nullptr;
+        std::vector<size_t> out_off; int ts1 = -1, ts2 = -1;
+        hipEvent_t done = nullptr;
+    } pend_frame;
     hipEvent_t wait_ev = nullptr;     // mark of mskf_wait
     bool wait_block = false;
     volatile unsigned int *flag_h = nullptr;   // pinned host words the mark kernels write (spinning mode), one per mark slot
@@ -128,6 +137,20 @@ struct mskf_stream {
     int det_cw = 0, det_ch = 0;
     int det_floor = 0;                // mskf_fe_set_detect_floor
     double time_stamp = 0;
+    // ---- device-side bookkeeping (fe_book.h): grids, candidate lists and track results of the stream, one allocation
+    struct Book {
+        char *mem = nullptr;
+        int cap = 0, cand_cap = 0, det_cap = 0, n_codes = 0, n_cells = 0, grid_w = 0, grid_h = 0;
+        FeBookState *st = nullptr;
+        FeGridArr grid[3];                         // [parity], [parity ^ 1]: previous / current grid; [2]: this frame's survivors
+        mskf_point2f *det_pt = nullptr; int *det_score = nullptr;
+        mskf_point2f *cand_pt = nullptr; int *cand_index = nullptr, *cand_score = nullptr, *cand_off = nullptr, *cand_cnt = nullptr, *cell_count = nullptr;
+        mskf_point2f *t_out0 = nullptr, *t_out1 = nullptr, *t_und0 = nullptr, *t_und1 = nullptr; uint8_t *t_status = nullptr;
+        mskf_point2f *c_out0 = nullptr, *c_out1 = nullptr, *c_und0 = nullptr, *c_und1 = nullptr; uint8_t *c_status = nullptr;
+        int parity = 0;                            // grid[parity] holds the published grid of the last frame
+        int n_prev = 0, n_cand_last = -1;          // host copies of the counts (launch sizing)
+        bool grid_set = false;
+    } book;
     // ---- EKF
     EkfStreamState ekf_state;
     void *ekf_extra = nullptr;

@@ -42,7 +42,8 @@ struct EkfStreamDev {
     double *T;                // na x (d+1) work: T = R P[act, :], then Y = L^-1 [T | Q^T r]
     double *S;                // (na+1)^2 work (compact): Gram matrix [H_act|r]^T [H_act|r], then its Cholesky factor L = R^T (+ the Q^T r row)
     double *W;                // na x na work (compact): S = T[:, act] R^T + sigma^2 I, then its Cholesky factor
-    int *act;                 // active columns of this update (the 6 columns of every clone a stacked feature observed), ascending; count in rows_out[2]
+    int *act;                 // active columns of this update (the 6 columns of every clone a stacked feature observed), ascending; count in rows_out[2];
+                              // act + ld: indices of the stacked rows, in order, when the update is not compressed (2 ld ints in all)
     double *gate_S;           // EKF_SLOTS x (nmax x nmax)
     int nmax;                 // 4 * max_clones
     double *delta_x;          // d
@@ -59,9 +60,9 @@ struct EkfStreamDev {
     int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns,
                               // [3] compression diagnostics: bit 0 = Householder TSQR used, bit 1 = the lambda prior of the Gram path
                               //     would bias P by more than QR_BIAS_LIMIT (auto mode then re-does the compression as TSQR), bit 2 = no
-                              //     compression (last stacked row <= active columns: the stacked rows themselves are the measurement),
+                              //     compression (stacked rows <= active columns: the stacked rows themselves are the measurement),
                               //     bits 8.. = pivots of the Gram factor below 100 lambda (reported only)
-                              // [4] nk = rows of the compressed measurement = dimension of S: na, or rows_out[1] without compression
+                              // [4] nk = rows of the compressed measurement = dimension of S: na, or rows_out[0] without compression
     // propagation / augmentation
     const double *PhiQ;       // n_steps x (2 x 21 x 21): Phi then Q   (generic form)
     const mskf_imu_step *imu_steps;   // or: n_steps compact IMU records, Phi/Q formed on the device

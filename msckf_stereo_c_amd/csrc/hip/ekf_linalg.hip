@@ -1,8 +1,8 @@
 // ekf_linalg.hip — batched dense FP64 building blocks of the Kalman update (msckf_vio.cpp:795-904),
 // one job per VIO stream, blockIdx.y = stream of the batch:
 //
-//  k_ekf_gemm   : 32x32 output tile per wavefront (64-thread workgroup), v_mfma_f64_16x16x4_f64, 2 x 2 sub-tiles = four
-//                 accumulators, K staged through LDS 32 at a time, next stage prefetched into registers.  Modes:
+//  k_ekf_gemm   : 32x32 output tile per workgroup, v_mfma_f64_16x16x4_f64 (one 16x16 sub-tile per wave,
+//                 K staged through LDS 32 at a time, next stage prefetched into registers).  Modes:
 //                   GRAM  G  = [Hs|rs]^T [Hs|rs]          ((d+1)x(d+1), replaces the QR: G = R^T R, last row = (Q^T r)^T R)
 //                   T     T  = R P,  R = L^T upper        (skips the zero half of R)
 //                   S2    S  = T R^T + sigma^2 I          (symmetric, lower computed and mirrored)
@@ -35,13 +35,13 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // How a stream's stack is compressed is decided from ONE pair of numbers everywhere (the GRAM pass, the factorisation
 // kernels, the fused small update): st = rows_out[0], the rows actually stacked, and na = rows_out[2], the active columns.
 //   * st <= na (auto mode): the reference compresses nothing there (msckf_vio.cpp:818-821) and H^T H would be singular by
-//     construction, so the Gram path is never taken.  When also me = rows_out[1] (last stacked row + 1, i.e. with the gaps
-//     that gated-out blocks leave) <= na, the rows themselves are the measurement ("direct": R = H_act, me x na, zero rows
-//     in the gaps); with gaps beyond that (st <= na < me) the rows would not fit the na-row work buffers and the stack is
-//     triangularised by the Householder TSQR instead, which is the same measurement rotated.
-//   * otherwise Gram + regularised Cholesky, re-done as TSQR when the factorisation raises the bias flag (bit 1).
-__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || (S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]); }
-__device__ __forceinline__ bool ekf_direct_wanted(const EkfStreamDev &S) { return S.qr_mode == 0 && S.rows_out[1] <= S.rows_out[2]; }
+//     construction, so neither the Gram pass nor any factorisation of the stack runs: the st stacked rows themselves are the
+//     measurement ("direct": R = H_act, st x na).  Blocks that were gated out leave gaps between the stacked rows (the last
+//     stacked row, rows_out[1], may lie far beyond na), so the rows are addressed through a compact list of their indices
+//     (rowidx, built by ekf_compress_entry behind the active-column list).
+//   * otherwise Gram + regularised Cholesky, re-done as Householder TSQR when the factorisation raises the bias flag (bit 1).
+__device__ __forceinline__ bool ekf_direct_wanted(const EkfStreamDev &S) { return S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]; }
+__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || ekf_direct_wanted(S); }
 // the stream's stacked rows are used uncompressed (set by the factorisation kernel): R = H_act (rows_out[1] x na, dense, rowmask-gathered)
 __device__ __forceinline__ bool ekf_direct(const EkfStreamDev &S) { return (S.rows_out[3] & 4) != 0; }
 // streams whose whole update runs in k_ekf_small_update (route bit, set per STREAM by the host: at most SU_MAX_NA active
@@ -62,24 +62,23 @@ template <> struct GemmTraits<GM_PUPD> { static constexpr bool TA = true,  SYM =
 
 #define GT 32      // output tile edge
 #ifndef GK
-#define GK 32      // K per LDS stage
+#define GK 32      // K per LDS stage (64 measured slower: 49 vs 41 us per launch, the LDS footprint halves the workgroups per CU)
 #endif
-#define GWG 64     // threads per workgroup: ONE wavefront owns a whole 32 x 32 output tile
-#define GHI (GWG / 32)
-#define GNE (GK / GHI)   // elements of each operand per thread and stage
+#define GNE (GK / 8)   // elements of each operand per thread and stage
 
-// One 32 x 32 output tile per WAVEFRONT (a 64-thread workgroup): a 2 x 2 block of 16 x 16 MFMA sub-tiles, i.e. four
-// independent accumulators, fed from two A and two B values per k-step, so every LDS read feeds two
-// v_mfma_f64_16x16x4_f64 (round 2: one sub-tile per wave of a 256-thread workgroup, two LDS reads per MFMA, two
-// workgroup barriers per K stage; counters: matrix pipes busy 20 % of the time).  A one-wave workgroup needs no barrier
-// at all: its LDS operations execute in program order (the next stage is written over the tile the MFMA operands were
-// just read from), and the global loads of stage s + 1 are in flight (registers) while the 32 MFMAs of stage s — 2048
-// cycles of matrix-pipe time, about one L2 round trip — issue.  17 KiB of LDS per wave: nine tiles in flight per CU.
-// The tile count per stream is what it was
-// (the 64 x 64-per-workgroup variant of round 2 lost on occupancy, not on this).  Diagonal tiles of the symmetric modes
-// skip the upper-right sub-tile.  Sums over k run in the same order as before: results are bit-identical to round 2.
+// One 32x32 output tile per workgroup (one 16x16 MFMA sub-tile per wave).  (Tried in round 2: 64x64 tiles with a 2x2 block
+// of sub-tiles per wave, i.e. half the LDS reads per MFMA.  2.6 x SLOWER at the C2 shapes, 109 vs 42 us per launch: with
+// na = 100..175 a stream has 3..6 such tiles, the launch no longer fills the CUs, and a workgroup is bound by the latency of
+// its ~22 K stages, not by feeding the matrix pipe.  Tried in round 3: the 32x32 tile per WAVE in a 64-thread workgroup,
+// four independent accumulators, no barriers, one LDS read per MFMA — same tile count, bit-identical results, and 2 x
+// slower: 83 vs 41 us per launch alone at 192 streams.  A v_mfma_f64_16x16x4 occupies the matrix pipe for 64 cycles, so
+// neither dependent issue nor LDS reads per MFMA are what leaves the pipe idle; with one wave per tile a tile's 32
+// global loads per stage are issued by 64 lanes instead of 256 and only 4 tiles' worth of loads are in flight per SIMD.)
+// The K loop is software pipelined:
+// the global loads of stage s+1 are issued into registers before the MFMAs of stage s, so a stage costs an LDS
+// round trip instead of an HBM/L2 round trip.
 template <int MODE>
-__global__ __launch_bounds__(GWG) void k_ekf_gemm(const EkfStreamDev *streams) {
+__global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     using TR = GemmTraits<MODE>;
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
@@ -99,27 +98,24 @@ __global__ __launch_bounds__(GWG) void k_ekf_gemm(const EkfStreamDev *streams) {
     else if (MODE == GM_PUPD) { A = S.T;  B = S.T;  C = S.P; M = N = d; K = nk; alpha = -1.0; beta = 1.0; }   // P -= Y^T Y
     const int tiles_n = (N + GT - 1) / GT, tiles_m = (M + GT - 1) / GT;
     const int tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid;
     if (MODE == GM_PUPD && tile >= tiles_m * tiles_n) {
         // tiles_n extra workgroups: delta_x = Y^T w, w = column d of Y (msckf_vio.cpp:860); 32 columns each,
-        // the K range split over the two thread rows and added in a fixed order
+        // the K range split over the 8 thread rows and reduced through LDS
         const int c0 = (tile - tiles_m * tiles_n) * GT;
         if (c0 >= d) return;
         const double *Y = S.T;
-        const int cl = tid & 31, ks = tid >> 5;
+        __shared__ double s_part[8][GT + 1];
+        const int cl = threadIdx.x & 31, ks = threadIdx.x >> 5;
         const int c = c0 + cl;
-        // (eight interleaved partial sums, as the 256-thread version had: the result keeps its bits)
-        double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double s2 = 0;
         if (c < d)
-            for (int k = ks; k < nk; k += GHI) p8[k & 7] += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
-        __shared__ double s_p8[GHI][8][GT + 1];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s_p8[ks][q][cl] = p8[q];
+            for (int k = ks; k < nk; k += 8) s2 += Y[(size_t)k * ld + c] * Y[(size_t)k * ld + d];
+        s_part[ks][cl] = s2;
         __syncthreads();
         if (ks == 0 && c < d) {
             double t = 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t += s_p8[0][q][cl] + s_p8[1][q][cl];     // one of the two is an exact zero (k & 7 has k's parity)
+            for (int q = 0; q < 8; ++q) t += s_part[q][cl];
             S.delta_x[c] = t;
         }
         return;
@@ -128,10 +124,11 @@ __global__ __launch_bounds__(GWG) void k_ekf_gemm(const EkfStreamDev *streams) {
     const int ti = tile / tiles_n, tj = tile - ti * tiles_n;
     if (TR::SYM && tj > ti) return;
     const int i0 = ti * GT, j0 = tj * GT;
-    const bool diag_tile = TR::SYM && ti == tj;
     __shared__ double sA[GK][GT + 1];   // sA[k][i]
     __shared__ double sB[GK][GT + 1];   // sB[k][j]
-    const int lo = tid & 31, hi = tid >> 5;          // hi in [0, GHI)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int lo = tid & 31, hi = tid >> 5;          // hi in [0,8)
     int k_begin = 0;
     if (TR::KMIN_I && !direct) k_begin = (i0 / GK) * GK;
     if (TR::KMIN_J && !direct) k_begin = (j0 / GK) * GK;
@@ -147,97 +144,83 @@ __global__ __launch_bounds__(GWG) void k_ekf_gemm(const EkfStreamDev *streams) {
     const int cloneA = MODE == GM_GRAM ? (colA < d ? (colA - EKF_IMU_DIM) / 6 : -1) : 0;
     const int cloneB = MODE == GM_GRAM ? (colB < d ? (colB - EKF_IMU_DIM) / 6 : -1) : 0;
     const unsigned long long *__restrict__ rowmask = S.rowmask;
+    const int *__restrict__ rowidx = S.act + S.ld;       // uncompressed update: the stacked rows, in order (ekf_compress_entry)
     double ra[GNE], rb[GNE];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < GNE; ++e) {
             if (MODE == GM_GRAM) {
-                // both operands are (column = lo, row = hi + GHI e) of [H | r]
-                const int gk = k0 + hi + GHI * e;
+                // both operands are (column = lo, row = hi + 8 e) of [H | r]
+                const int gk = k0 + hi + 8 * e;
                 double v = 0.0, w = 0.0;
                 if (gk < K) {
                     const unsigned long long rm = rowmask[gk];
                     const bool onA = cloneA < 0 ? rm != 0ULL : ((rm >> cloneA) & 1ULL) != 0ULL;
                     const bool onB = cloneB < 0 ? rm != 0ULL : ((rm >> cloneB) & 1ULL) != 0ULL;
                     if (onA && i0 + lo < M) v = A[(size_t)gk * ld + colA];
-                    if (onB && j0 + lo < N && !diag_tile) w = B[(size_t)gk * ld + colB];
-                    if (diag_tile) w = v;                 // the same column of the same row
+                    if (onB && j0 + lo < N) w = B[(size_t)gk * ld + colB];
                 }
                 ra[e] = v; rb[e] = w;
                 continue;
             }
-            // A: TA -> (i = lo, k = hi + GHI e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + GHI e) reads A[i*ld + k]
-            // (GK == 32: one 32-wide k range per stage)
-            const int ii = TR::TA ? lo : hi + GHI * e, kk = TR::TA ? hi + GHI * e : lo;
+            // A: TA -> (i = lo, k = hi + 8e) reads A[k*ld + i] coalesced in i; else (k = lo, i = hi + 8e) reads A[i*ld + k]
+            const int ii = TR::TA ? lo : hi + 8 * (e / (GK / 32)), kk = TR::TA ? hi + 8 * e : lo + 32 * (e % (GK / 32));
             const int gi = i0 + ii, gk = k0 + kk;
             double v = 0.0;
             if (gi < M && gk < K && !(TR::KMIN_I && !direct && gk < gi)) {
                 if (MODE == GM_S2) v = A[(size_t)gi * ld + act[gk]];              // T[:, act]
-                else if (MODE == GM_T && direct) {                                // H_act row gi, rowmask-gathered
-                    const int col = act[gk];
-                    if ((rowmask[gi] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) v = A[(size_t)gi * ld + col];
+                else if (MODE == GM_T && direct) {                                // H_act row gi = stacked row rowidx[gi], rowmask-gathered
+                    const int col = act[gk], ri = rowidx[gi];
+                    if ((rowmask[ri] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) v = A[(size_t)ri * ld + col];
                 }
-                else v = A[(size_t)gk * ld + gi];
+                else v = A[(size_t)gk * ld + (MODE == GM_GRAM ? colA : gi)];
             }
             ra[e] = v;
-            const int gj = j0 + lo, gkb = k0 + hi + GHI * e;
+            const int gj = j0 + lo, gkb = k0 + hi + 8 * e;
             double w = 0.0;
             if (gj < N && gkb < K && !(TR::KMIN_J && !direct && gkb < gj)) {
                 if (MODE == GM_T) w = B[(size_t)act[gkb] * ld + gj];             // P[act, :]
-                else if (MODE == GM_S2 && direct) {                               // (H_act)^T: row gj of H, column act[gkb]
-                    const int col = act[gkb];
-                    if ((rowmask[gj] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) w = B[(size_t)gj * ld + col];
+                else if (MODE == GM_S2 && direct) {                               // (H_act)^T: stacked row rowidx[gj] of H, column act[gkb]
+                    const int col = act[gkb], rj = rowidx[gj];
+                    if ((rowmask[rj] >> ((col - EKF_IMU_DIM) / 6)) & 1ULL) w = B[(size_t)rj * ld + col];
                 }
-                else w = B[(size_t)gkb * ld + gj];
+                else w = B[(size_t)gkb * ld + (MODE == GM_GRAM ? colB : gj)];
             }
             rb[e] = w;
         }
     };
-    static_assert(GK == 32, "the non-transposed A loader covers one 32-wide k range per stage");
-    auto stash = [&]() {
-#pragma unroll
-        for (int e = 0; e < GNE; ++e) {
-            if (TR::TA) sA[hi + GHI * e][lo] = ra[e]; else sA[lo][hi + GHI * e] = ra[e];
-            sB[hi + GHI * e][lo] = rb[e];
-        }
-    };
-    v4f64 acc00 = {0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     if (k_begin < k_end) fetch(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += GK) {
-        // one wavefront: the reads of the previous stage were issued before these writes and LDS executes a wave's
-        // operations in order, so the tile can be overwritten in place
-        stash();
-        if (k0 + GK < k_end) fetch(k0 + GK);          // global loads of the next stage fly during this stage's MFMAs
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < GNE; ++e) {
+            if (TR::TA) sA[hi + 8 * e][lo] = ra[e]; else sA[lo + 32 * (e % (GK / 32))][hi + 8 * (e / (GK / 32))] = ra[e];
+            sB[hi + 8 * e][lo] = rb[e];
+        }
+        __syncthreads();
+        if (k0 + GK < k_end) fetch(k0 + GK);
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             const int kk = 4 * s + (lane >> 4);
-            const double a0 = sA[kk][lane & 15], a1 = sA[kk][16 + (lane & 15)];
-            const double b0 = sB[kk][lane & 15], b1 = sB[kk][16 + (lane & 15)];
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
-            if (!diag_tile) acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
+            const double a = sA[kk][wi + (lane & 15)];
+            const double b = sB[kk][wj + (lane & 15)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    // epilogue: lane holds D[row = (lane>>4) + 4 r][col = lane & 15] of each sub-tile
-    auto store = [&](const v4f64 &acc, int wi, int wj) {
+    // epilogue: lane holds D[row = (lane>>4) + 4 r][col = lane & 15]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + wi + (lane >> 4) + 4 * r;
-            const int j = j0 + wj + (lane & 15);
-            if (i >= M || j >= N) continue;
-            if (TR::SYM && j > i) continue;             // diagonal tiles: lower part only, mirrored below
-            double v = alpha * acc[r];
-            if (MODE == GM_PUPD) v += beta * C[(size_t)i * ld + j];
-            if (i == j) v += diag_add;
-            C[(size_t)i * ld + j] = v;
-            if (TR::SYM && i != j) C[(size_t)j * ld + i] = v;
-        }
-    };
-    store(acc00, 0, 0); store(acc10, 16, 0); store(acc11, 16, 16);
-    if (!diag_tile) store(acc01, 0, 16);
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi + (lane >> 4) + 4 * r;
+        const int j = j0 + wj + (lane & 15);
+        if (i >= M || j >= N) continue;
+        if (TR::SYM && j > i) continue;             // diagonal tiles: lower part only, mirrored below
+        double v = alpha * acc[r];
+        if (MODE == GM_PUPD) v += beta * C[(size_t)i * ld + j];
+        if (i == j) v += diag_add;
+        C[(size_t)i * ld + j] = v;
+        if (TR::SYM && i != j) C[(size_t)j * ld + i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------ Householder TSQR
@@ -309,15 +292,34 @@ __device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, Col
 // What the Gram factorisation kernels do for a stream BEFORE factoring (which == 0 only).  Returns 0: factor the Gram
 // matrix; 1: the stack is used uncompressed and everything is set up (the kernel returns); 2: no Gram matrix was formed,
 // go straight to the TSQR.
-__device__ __forceinline__ int ekf_compress_entry(const EkfStreamDev &S) {
+__device__ __forceinline__ int ekf_compress_entry(const EkfStreamDev &S, int *s_w /* shared, >= blockDim / 64 ints */) {
     const int na = S.rows_out[2], me = S.rows_out[1], d = S.d, ld = S.ld;
     if (na <= 0) { if (threadIdx.x == 0) S.rows_out[3] = 0; return 1; }
     if (ekf_direct_wanted(S)) {
         // The reference's m <= d case (msckf_vio.cpp:818-821): no more stacked rows than active columns, nothing to
-        // compress.  The rows themselves are the measurement: R = H_act (me x na, read through the rowmask by the T and
-        // S GEMMs), Q^T r = r, S is me x me.  (Rows of blocks that were not stacked are zero rows: sigma^2 on S's diagonal.)
-        for (int i = threadIdx.x; i < me; i += blockDim.x) S.T[(size_t)i * ld + d] = S.rowmask[i] ? S.Hs[(size_t)i * ld + d] : 0.0;
-        if (threadIdx.x == 0) { S.rows_out[3] = 4; S.rows_out[4] = me; }
+        // compress.  The stacked rows themselves are the measurement: R = H_act (st x na, read through rowidx and the
+        // rowmask by the T and S GEMMs), Q^T r = r, S is st x st.  rowidx = indices of the stacked rows in order: ranks
+        // from wave ballots + a scan over the waves' counts, 512 rows per pass.
+        int *rowidx = S.act + ld;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
+        int base = 0;
+        for (int r0 = 0; r0 < me; r0 += (int)blockDim.x) {
+            const int r = r0 + tid;
+            const bool on = r < me && S.rowmask[r] != 0ULL;
+            const unsigned long long b = __ballot(on);
+            if (lane == 0) s_w[wave] = __popcll(b);
+            __syncthreads();
+            int off = base, tot = 0;
+            for (int w = 0; w < nw; ++w) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
+            if (on && off + __popcll(b & ((1ULL << lane) - 1ULL)) < ld) rowidx[off + __popcll(b & ((1ULL << lane) - 1ULL))] = r;
+            base += tot;
+            __syncthreads();
+        }
+        // (base == rows_out[0] <= na <= ld - 21: the list fits the ld ints behind act)
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < base; i += (int)blockDim.x) S.T[(size_t)i * ld + d] = S.Hs[(size_t)rowidx[i] * ld + d];
+        if (tid == 0) { S.rows_out[3] = 4; S.rows_out[4] = base; }
         return 1;
     }
     return ekf_skip_gram(S) ? 2 : 0;
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
-    if (which == 0) { entry = ekf_compress_entry(S); if (entry == 1) return; }
+    __shared__ int s_w[CHOLG_THREADS / 64];
+    if (which == 0) { entry = ekf_compress_entry(S, s_w); if (entry == 1) return; }
     const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
     const int nt = n + (which == 0 ? 1 : 0);              // + the extra Q^T r row of the Gram factorisation
     const int lda = S.ld;
@@ -440,7 +443,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
-    if (which == 0) { entry = ekf_compress_entry(S); if (entry == 1) return; }
+    __shared__ int s_w[CHOL_WAVES];
+    if (which == 0) { entry = ekf_compress_entry(S, s_w); if (entry == 1) return; }
     double *A = which == 0 ? S.S : S.W;
     const int off = 0, lda = S.ld;                 // compact storage: index i <-> column act[i]
     const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
@@ -821,10 +825,10 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
     const int t = (max_mn + GT - 1) / GT;
     const dim3 grid(t * t + (mode == GM_PUPD ? t : 0), n);
     switch (mode) {
-        case GM_GRAM: hipLaunchKernelGGL(k_ekf_gemm<GM_GRAM>, grid, dim3(GWG), 0, st, d); break;
-        case GM_T:    hipLaunchKernelGGL(k_ekf_gemm<GM_T>, grid, dim3(GWG), 0, st, d); break;
-        case GM_S2:   hipLaunchKernelGGL(k_ekf_gemm<GM_S2>, grid, dim3(GWG), 0, st, d); break;
-        default:      hipLaunchKernelGGL(k_ekf_gemm<GM_PUPD>, grid, dim3(GWG), 0, st, d); break;
+        case GM_GRAM: hipLaunchKernelGGL(k_ekf_gemm<GM_GRAM>, grid, dim3(256), 0, st, d); break;
+        case GM_T:    hipLaunchKernelGGL(k_ekf_gemm<GM_T>, grid, dim3(256), 0, st, d); break;
+        case GM_S2:   hipLaunchKernelGGL(k_ekf_gemm<GM_S2>, grid, dim3(256), 0, st, d); break;
+        default:      hipLaunchKernelGGL(k_ekf_gemm<GM_PUPD>, grid, dim3(256), 0, st, d); break;
     }
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {

@@ -262,13 +262,17 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
     FB_FOR(c, B.n_cells) {
         B.cand_off[c] = L.cellC[c];
         if (B.cand_cnt[c] <= 0) continue;
-        // the cell's best grid_max detections, descending response, ties in detection order: insertion into a short list
+        // A cell with more than grid_max detections keeps its best grid_max, descending response, ties in detection order
+        // (insertion into a short list); a cell with fewer is NOT sorted (:664 sorts only when it has to cut): detection order.
         int best_q[FB_MAXK], best_s[FB_MAXK];
-        int m = 0;
+        int m = 0, cnt = 0;
         const int K = B.grid_max;
+        for (int q = 0; q < n_det; ++q) cnt += L.b[q] == c ? 1 : 0;
+        const bool cut = cnt > K;
         for (int q = 0; q < n_det; ++q) {
             if (L.b[q] != c) continue;
             const int s = B.det_score[q];
+            if (!cut) { best_q[m] = q; best_s[m] = s; ++m; continue; }
             if (m == K && !(s > best_s[K - 1])) continue;
             int pos = m < K ? m : K - 1;
             while (pos > 0 && s > best_s[pos - 1]) { best_q[pos] = best_q[pos - 1]; best_s[pos] = best_s[pos - 1]; --pos; }

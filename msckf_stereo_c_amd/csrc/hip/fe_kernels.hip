@@ -256,10 +256,17 @@ __device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t 
 // region of level 0, writing its level-1 tile and scoring the region as four sub-tiles.  It removes a launch and the
 // second read of cam0, but the detector is LDS / latency bound, not bandwidth bound: four serial sub-tiles per workgroup
 // at 46 KB of LDS ran 33 % slower than the two separate kernels, 315 vs 237 ms per 40 steps.)
-__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams, int tiles_x, unsigned int gen) {
-    const FeStreamDev &S = streams[blockIdx.y];
+// Block -> (stream, tile): workgroups are dealt to the eight XCDs round robin (b and b + 8 share one), and each XCD has its
+// own L2.  With the tiles of an image spread over all of them every XCD fetched the 8-pixel halo rows / columns of its tiles
+// from memory again: 2.8 x the image bytes (profiles/r02_pmc_hbm_traffic.json).  The tiles of ONE stream now get block ids
+// that are congruent modulo 8, so an image travels through one L2 and the halo of a tile is its neighbour's hit.
+__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams, int n_streams, int tiles_x, int tiles, unsigned int gen) {
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int si = xcd + 8 * (qb / tiles), ti = qb - (qb / tiles) * tiles;
+    if (si >= n_streams) return;
+    const FeStreamDev &S = streams[si];
     const int W = S.curr0.w[0], H = S.curr0.h[0];
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int tyi = ti / tiles_x, txi = ti - tyi * tiles_x;
     const int tx0 = txi * DTW, ty0 = tyi * DTH;
     if (tx0 >= W || ty0 >= H) return;
     const uint8_t *img = S.curr0.lvl[0];
@@ -288,7 +295,8 @@ __global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams
 
 extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st) {
     const int tiles_x = (max_w + DTW - 1) / DTW, tiles_y = (max_h + DTH - 1) / DTH;
-    hipLaunchKernelGGL(k_detect_cells, dim3(tiles_x * tiles_y, n_streams), dim3(256), 0, st, streams_dev, tiles_x, gen);
+    const int tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(k_detect_cells, dim3(8 * ((n_streams + 7) / 8) * tiles), dim3(256), 0, st, streams_dev, n_streams, tiles_x, tiles, gen);
 }
 
 // ------------------------------------------------------------------------------------------ point math

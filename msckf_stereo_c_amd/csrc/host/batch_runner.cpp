@@ -113,6 +113,33 @@ int BatchGroup::step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, 
     auto parh = [&](const Half &H, const std::function<void(int)> &fn) {
         if (pool_) pool_->run(H.n, [&](int k) { fn(H.i0 + k); }); else for (int i = H.i0; i < H.i0 + H.n; ++i) fn(i);
     };
+    // Every frame after a stream's first runs as ONE device call per half-batch (mskf_fe_frame_batch_*): pyramids, detector,
+    // both track calls and the bookkeeping between and after them; the host prepares the prediction and takes the grid.
+    {
+        bool all_dev = true;
+        for (int i = 0; i < n && all_dev; ++i) all_dev = systems_[i]->imgproc_ptr_->canDeviceFrame();
+        if (all_dev) {
+            fa_.resize(n);
+            for (Half &H : half_) {
+                bool ok = true;
+                for (int i = H.i0; i < H.i0 + H.n; ++i) ok = systems_[i]->imgproc_ptr_->frameBegin(t[i], fa_[i]) && ok;
+                if (!ok) { error_ = "frameBegin failed: " + systems_[H.i0]->imgproc_ptr_->error(); return MSKF_ERR_INVALID; }
+                lap(PH_PREP1);
+                BR_CHK(mskf_fe_frame_batch_begin(H.ctx, H.n, streams_.data() + H.i0, cam0 + H.i0, cam1 + H.i0, on_device, fa_.data() + H.i0));
+                lap(PH_PUSH);
+            }
+            for (Half &H : half_) {
+                BR_CHK(mskf_fe_frame_batch_end(H.ctx));
+                lap(PH_TRACK1);
+                parh(H, [&](int i) {
+                    systems_[i]->imgproc_ptr_->frameEnd(fa_[i], is_draw);
+                    systems_[i]->set_feature_msg(systems_[i]->imgproc_ptr_->feature_msg_ptr_);
+                });
+                lap(PH_AFTER2);
+            }
+            return MSKF_OK;
+        }
+    }
     // image size comes from the calibration the stream was created with
     for (int i = 0; i < n; ++i) systems_[i]->imgproc_ptr_->phaseBegin(t[i], 0, 0);
     for (Half &H : half_) BR_CHK(mskf_fe_push_stereo_batch(H.ctx, H.n, streams_.data() + H.i0, cam0 + H.i0, cam1 + H.i0, on_device));
@@ -336,7 +363,7 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
                 const double tq = now_s();
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&]() { return !queue.empty() || producer_done; });
-                if (queue.empty()) return;
+                if (queue.empty()) break;
                 fb = std::move(queue.front());
                 queue.pop_front();
                 phase_s[PH_EKF_QWAIT] += now_s() - tq;
@@ -371,6 +398,8 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
             }
             { std::lock_guard<std::mutex> lk(mu); pool.push_back(std::move(fb)); }
         }
+        // the window closed while this stage was inside its last frames (or never did): its accounting ends with its work
+        if (win && ekf_mine == 1) { win->t_ekf_end = now_s(); gate(false, false); ekf_mine = 2; }
     });
     if (win) hostprof::enabled() = false;
     int rc = MSKF_OK;
@@ -435,16 +464,12 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
             mark_dump.fe_valid = true;
         }
     }
+    if (win && fe_mine == 1) { win->t_fe_end = now_s(); gate(true, false); fe_mine = 2; }
     if (pacer) pacer->done[pacer_slot].store(0x7fffffff);      // (also on an error exit: nobody waits for this group any more)
     { std::lock_guard<std::mutex> lk(mu); producer_done = true; }
     cv.notify_all();
     consumer.join();
-    if (win) {
-        // a stage whose gates are still open closes them now (the window closed while it was inside its last frame)
-        if (fe_mine == 1) { win->t_fe_end = now_s(); gate(true, false); }
-        if (ekf_mine == 1) { win->t_ekf_end = now_s(); gate(false, false); }
-        win->frames_done = k - first;
-    }
+    if (win) win->frames_done = k - first;
     hostprof::enabled() = true;
     if (rc == MSKF_OK) rc = ekf_rc.load();
     return rc;

@@ -146,6 +146,7 @@ class BatchGroup {
     std::vector<std::unique_ptr<System>> systems_;
     std::vector<mskf_stream *> streams_;
     std::vector<mskf_fe_track_args> a1_, a2_;
+    std::vector<mskf_fe_frame_args> fa_;
     std::vector<mskf_ekf_update_args> u_;
     std::vector<const uint8_t *> p0_, p1_;
     std::vector<double> t_;

@@ -32,6 +32,8 @@ int mskfh_load_configs(const char *config_dir, mskf_calib *calib, mskf_fe_cfg *f
     }
 }
 
+// where the front-end's bookkeeping runs (ImageProcessor::setFeBooksOnHost): tests compare the two paths
+void mskfh_set_fe_books_on_host(int on) { ImageProcessor::setFeBooksOnHost(on); }
 void mskfh_runner_destroy(void *h) { delete (MultiRunner *)h; }
 int mskfh_runner_num_streams(void *h) { return ((MultiRunner *)h)->n_streams(); }
 const char *mskfh_runner_error(void *h) { static thread_local std::string e; e = ((MultiRunner *)h)->error(); return e.c_str(); }

@@ -3,8 +3,11 @@
 #include "image_processor.h"
 #include "host_prof.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <iomanip>
 #include <iostream>
 
@@ -151,6 +154,18 @@ void ImageProcessor::stereoCallback(const cg::Image &cam0_img, const cg::Image &
         if (rc != MSKF_OK) { fail("mskf_stream_create", rc); return; }
         own_stream_ = true;
         mskf_fe_set_detect_floor(stream_, cfg_.fast_threshold * 256);
+    }
+    if (canDeviceFrame()) {
+        // every frame after the first: one call, the bookkeeping between the tracks runs on the device
+        mskf_fe_frame_args fa;
+        if (!frameBegin(cam0_img.time_stamp, fa)) return;
+        mskf_stream *ss[1] = {stream_};
+        const uint8_t *a[1] = {cam0_img.image.data()}, *b[1] = {cam1_img.image.data()};
+        int frc = mskf_fe_frame_batch_begin(mskf_stream_ctx(stream_), 1, ss, a, b, 0, &fa);
+        if (frc == MSKF_OK) frc = mskf_fe_frame_batch_end(mskf_stream_ctx(stream_));
+        if (frc != MSKF_OK) { fail("mskf_fe_frame_batch", frc); return; }
+        frameEnd(fa, is_draw);
+        return;
     }
     phaseBegin(cam0_img.time_stamp, w, h);
     int rc = mskf_fe_push_stereo(stream_, cam0_img.image.data(), cam1_img.image.data(), w, h, w, cam0_img.time_stamp);
@@ -575,7 +590,71 @@ void ImageProcessor::phaseAfter1(mskf_fe_track_args &args2) {
     stage_ = 3;
 }
 
+// process-wide switch: -1 = not decided (MSKF_FE_BOOKS=host in the environment decides), 0 = device, 1 = host
+static std::atomic<int> g_fe_books_host{-1};
+void ImageProcessor::setFeBooksOnHost(int on) { g_fe_books_host.store(on < 0 ? -1 : (on ? 1 : 0)); }
+bool ImageProcessor::feBooksOnHost() {
+    int v = g_fe_books_host.load(std::memory_order_relaxed);
+    if (v < 0) { const char *e = std::getenv("MSKF_FE_BOOKS"); v = (e && e[0] == 'h') ? 1 : 0; g_fe_books_host.store(v); }
+    return v != 0;
+}
+
+bool ImageProcessor::canDeviceFrame() const {
+    if (feBooksOnHost() || !stream_ || is_first_img) return false;
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC)) return false;       // the RANSAC of :482-500 sits between the tracks, on the host
+    return mskf_fe_grid_capacity(stream_) > 0;
+}
+
+bool ImageProcessor::frameBegin(double time_stamp, mskf_fe_frame_args &a) {
+    phaseBegin(time_stamp, 0, 0);
+    hostprof::Scope hp(hostprof::FE_PREPARE);
+    std::memset(&a, 0, sizeof(a));
+    if (!device_grid_valid_) {
+        // the last frame ran on the host (the first frame of the stream): hand the device its grid, id counter and the
+        // tracking counters that survive frames without features
+        const int32_t counters[3] = {after_tracking, after_matching, after_ransac};
+        const int rc = mskf_fe_set_grid(stream_, (int)prev_.size(), (const uint64_t *)prev_.id.data(), prev_.lifetime.data(), prev_.cam0.data(), prev_.cam1.data(),
+                                        prev_.und0.data(), prev_.und1.data(), (uint64_t)next_feature_id, counters);
+        if (rc != MSKF_OK) { fail("mskf_fe_set_grid", rc); return false; }
+        device_grid_valid_ = true;
+    }
+    hm::Mat3 cam0_R_p_c, cam1_R_p_c;
+    integrateImuData(cam0_R_p_c, cam1_R_p_c);                // :360 (the window is consumed even when nothing is tracked: the buffer must not grow)
+    cam0_R_p_c_ = cam0_R_p_c; cam1_R_p_c_ = cam1_R_p_c;
+    computeHpred(cam0_R_p_c, a.Hpred);
+    const int cap = mskf_fe_grid_capacity(stream_);
+    curr_.id.resize(cap); curr_.lifetime.resize(cap); curr_.code.resize(cap); curr_.response.resize(cap);
+    curr_.cam0.resize(cap); curr_.cam1.resize(cap); curr_.und0.resize(cap); curr_.und1.resize(cap);
+    a.capacity = cap;
+    static_assert(sizeof(FeatureIDType) == sizeof(uint64_t), "id type");
+    a.id = (uint64_t *)curr_.id.data(); a.lifetime = curr_.lifetime.data();
+    a.cam0 = curr_.cam0.data(); a.cam1 = curr_.cam1.data(); a.und0 = curr_.und0.data(); a.und1 = curr_.und1.data();
+    stage_ = 5;
+    return true;
+}
+
+void ImageProcessor::frameEnd(const mskf_fe_frame_args &a, bool is_draw) {
+    const size_t n = (size_t)a.n;
+    curr_.id.resize(n); curr_.lifetime.resize(n); curr_.code.resize(n); curr_.response.resize(n);
+    curr_.cam0.resize(n); curr_.cam1.resize(n); curr_.und0.resize(n); curr_.und1.resize(n);
+    for (size_t k = 0; k < n; ++k) curr_.code[k] = gridCode(curr_.cam0[k]);      // (the host path's arrays stay complete: a later host frame may read them)
+    before_tracking = a.before_tracking; after_tracking = a.after_tracking; after_matching = a.after_matching; after_ransac = a.after_ransac;
+    next_feature_id = (FeatureIDType)a.next_feature_id;
+    stage_ = 0;
+    if (is_draw) {   // :163-184
+        prev_ids_.assign(prev_.id.begin(), prev_.id.end());
+        prev_cam0_points_.clear(); prev_cam1_points_.clear(); curr_cam0_points_.clear(); curr_cam1_points_.clear();
+        for (size_t k = 0; k < prev_.size(); ++k) { prev_cam0_points_[prev_.id[k]] = Point2f(prev_.cam0[k].x, prev_.cam0[k].y); prev_cam1_points_[prev_.id[k]] = Point2f(prev_.cam1[k].x, prev_.cam1[k].y); }
+        for (size_t k = 0; k < curr_.size(); ++k) { curr_cam0_points_[curr_.id[k]] = Point2f(curr_.cam0[k].x, curr_.cam0[k].y); curr_cam1_points_[curr_.id[k]] = Point2f(curr_.cam1[k].x, curr_.cam1[k].y); }
+    }
+    hostprof::Scope hp_pub(hostprof::FE_PUBLISH);
+    publish();
+    if (!(cfg_.compat_flags & MSKF_COMPAT_Q2_PREV_ALIAS)) cam0_prev_time = cam0_curr_time;
+    std::swap(prev_, curr_);     // (the pyramid rotation of :194 is part of the device call)
+}
+
 void ImageProcessor::phaseAfter2(bool is_draw) {
+    device_grid_valid_ = false;      // a host-side frame: the device's grid (if any) is stale from here on
     if (stage_ == 3) {
         { hostprof::Scope hp(hostprof::FE_NEW_TAIL); addNewFeaturesTail(); }
         { hostprof::Scope hp(hostprof::FE_PRUNE); assembleGrid(); }

@@ -77,6 +77,16 @@ class ImageProcessor {
     void phaseAfter1(mskf_fe_track_args &args);                     // consume results; prepare new-feature candidates
     void phaseAfter2(bool is_draw);                                 // addNewFeatures tail, prune, publish, rotate
     bool isFirstImage() const { return is_first_img; }
+    // ---- a whole frame on the device (mskf_fe_frame_batch_*): the bookkeeping of phaseAfter1 / phaseAfter2 runs in kernels
+    // between the track calls, the grid stays in device memory; the host only integrates the gyro for the prediction, receives
+    // the published grid and writes the message.  Possible for every frame but the first of a stream unless the configuration
+    // needs the host between the tracks (2-point RANSAC) or exceeds the kernels' per-cell bound; MSKF_FE_BOOKS=host forces
+    // the phased path.
+    bool canDeviceFrame() const;
+    static void setFeBooksOnHost(int on);   // 1: every frame on the phased (host bookkeeping) path, 0: device frames where possible, -1: MSKF_FE_BOOKS decides
+    static bool feBooksOnHost();
+    bool frameBegin(double time_stamp, mskf_fe_frame_args &args);   // phaseBegin + prediction + output arrays; false on error
+    void frameEnd(const mskf_fe_frame_args &args, bool is_draw);    // take the published grid, publish(), rotate
     void enableFileOutputs() { if (!debug_.is_open()) debug_.open("debug_imageprocessor.txt"); }   // image_processor.cpp:134
     // records [zeroTailStart(), features.size()) of feature_msg_ptr_ were pushed but never written (Q1)
     size_t zeroTailStart() const { return max_published_; }
@@ -170,6 +180,7 @@ class ImageProcessor {
     std::vector<int> order_;                                             // scratch: sort permutation
     size_t max_published_ = 0;
     int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
+    bool device_grid_valid_ = false;   // the device's grid is the one this object published last (false after a host-side frame)
     std::ofstream debug_;
 };
 

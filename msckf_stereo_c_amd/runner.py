@@ -74,6 +74,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_fe_books_on_host(on):
+    """Process-wide: 1 = the front-end's bookkeeping stays on the host for every frame (the phased mskf_fe_track path), 0 = whole
+    frames on the device wherever the configuration allows (default), -1 = back to the MSKF_FE_BOOKS environment variable."""
+    lib().mskfh_set_fe_books_on_host(int(on))
+
+
 class Runner:
     """n_groups x per_group independent VIO streams on one GPU."""
 
@@ -169,8 +175,8 @@ class Runner:
         else:
             self.L.mskfh_runner_keep_trajectory_stream(self.h, int(stream), int(keep))
 
-    KERNELS = ["k_pyr_down", "k_detect_cells", "k_lk_points4", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
-               "k_ekf_cap", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_small", "k_ekf_remove_clone", "k_pt_geom"]
+    KERNELS = ["k_pyr_down", "k_detect_cells", "k_track4", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
+               "k_ekf_cap", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_small", "k_ekf_remove_clone", "k_pt_geom", "k_fe_book"]
 
     def set_timing(self, enable):
         self.L.mskfh_runner_set_timing(self.h, int(enable))

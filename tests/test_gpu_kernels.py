@@ -543,8 +543,8 @@ def test_ekf_mixed_batch_takes_each_stream_its_own_route(gpu_ctx, oracle):
 def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
     """a stack with fewer STACKED rows than active columns whose last stacked row lies beyond them because a
     gated-out block sits in the middle (st <= na < me).  H^T H is singular by construction there, and the reference does
-    not compress such a stack at all (msckf_vio.cpp:818-821): auto mode must not take the Gram path, and the rows do not
-    fit the uncompressed work buffers with their gap, so the Householder TSQR takes them (the same measurement, rotated).
+    not compress such a stack at all (msckf_vio.cpp:818-821): auto mode must not take the Gram path; the stacked rows are
+    used as they are, addressed through a compact list of their indices (the gap does not fit the na-row work buffers).
     The middle feature is made an outlier (its observations pushed apart, alternately), which the gate rejects."""
     calib = oracle.euroc_calib(376, 240)
     cfg = default_ekf_cfg(max_cam_state_size=30)
@@ -579,7 +579,7 @@ def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
         Pg = s.ekf_get_cov()
         s.close()
         assert got["rows"] == st == ref["rows"]
-        assert got["used_qr"] == 1, "st <= na < me must be triangularised by the TSQR, not squared into H^T H"
+        assert got["used_qr"] == 2, "st <= na < me: the stacked rows are the measurement, uncompressed (never squared into H^T H)"
         assert np.abs(Pg - ref["P"]).max() / np.abs(ref["P"]).max() < 1e-11
         assert np.abs(got["delta_x"] - ref["delta_x"]).max() / np.abs(ref["delta_x"]).max() < 1e-9
     assert hit >= 2, "the oracle gated no [pass, reject, pass] case: widen the seed range"

@@ -602,3 +602,49 @@ def test_stream_results_do_not_depend_on_the_batch(oracle):
     assert np.array_equal(alone.imu_state(0), batch.imu_state(2))
     alone.close()
     batch.close()
+
+
+def test_device_books_equal_host_books(oracle):
+    """The front-end's bookkeeping on the device (mskf_fe_frame_batch_*: fe_book1 / fe_book2 between the track kernels,
+    the grid resident in device memory) against the phased path with the books on the host (mskf_fe_track + the host
+    mirror's phaseAfter1 / phaseAfter2), on the same streams: identical grids in every frame, identical messages
+    (Q1 tail included), identical tracking info, poses within rounding — and both equal the oracle.  Streams: a normal
+    one, a fast one (many lost features), and a grid with partial rows / columns (333 x 251, quirk Q7)."""
+    cases = [(376, 240, 0x5EED0080, 1.0, default_fe_cfg()), (376, 240, 0x5EED0081, 2.5, default_fe_cfg(grid_row=3, grid_col=4, grid_min=2, grid_max=3)),
+             (333, 251, 0x5EED0082, 1.0, default_fe_cfg(grid_row=4, grid_col=5, grid_min=3, grid_max=4))]
+    for w, h, seed, motion, fe in cases:
+        ekf = default_ekf_cfg(max_cam_state_size=10)
+        syn = oracle.Synth(seed=seed, width=w, height=h, motion_scale=motion)
+        osys = oracle.OracleSystem(syn.calib, fe, ekf)
+        runs = []
+        for host in (1, 0):
+            R.set_fe_books_on_host(host)
+            runs.append(R.Runner(syn.calib, fe, ekf, 1, 1))
+        try:
+            j = 0
+            for k in range(60):
+                t_img = syn.frame_time(k)
+                while True:
+                    s = syn.imu(j)
+                    j += 1
+                    osys.imu(s)
+                    for r in runs:
+                        r.imu(0, s)
+                    if not (s.time_stamp <= t_img):
+                        break
+                a, b = syn.render(k)
+                osys.stereo(a, b, t_img)
+                osys.backend()
+                for host, r in zip((1, 0), runs):
+                    R.set_fe_books_on_host(host)
+                    r.step([a], [b], [t_img])
+                compare_frame(k, osys, runs[0])
+                compare_frame(k, osys, runs[1])
+                compare_msgs(osys, runs[1])
+            compare_poses(osys, runs[1])
+            pa, pb = runs[0].poses(0), runs[1].poses(0)
+            assert np.array_equal(pa["p"], pb["p"]) and np.array_equal(pa["q"], pb["q"])
+        finally:
+            R.set_fe_books_on_host(-1)
+            for r in runs:
+                r.close()
