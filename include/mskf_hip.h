@@ -50,6 +50,11 @@ int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **out);
 int mskf_ctx_create_shared(mskf_ctx *parent, mskf_ctx **out);
 void mskf_ctx_destroy(mskf_ctx *ctx);
 int mskf_ctx_sync(mskf_ctx *ctx);
+/* How the *_end calls of this context wait for the device: 0 = spin on a completion mark in pinned host memory (lowest
+ * latency, occupies a core), 1 = park the thread on a blocking HIP event.  Default: MSKF_WAIT=block in the environment
+ * selects 1, else 0.  A stage that waits once per frame for a long chain of kernels (the device front-end frame) loses
+ * nothing by parking and leaves its core to the threads that have host work. */
+int mskf_ctx_set_wait_mode(mskf_ctx *ctx, int block);
 /* the HIP stream of this context as a void* (hipStream_t), for event timing by the caller */
 void *mskf_ctx_hip_stream(mskf_ctx *ctx);
 

@@ -183,6 +183,13 @@ extern "C" int mskf_ctx_set_timing(mskf_ctx *c, int enable) {
     return MSKF_OK;
 }
 
+extern "C" int mskf_ctx_set_wait_mode(mskf_ctx *c, int block) {
+    if (!c) return MSKF_ERR_INVALID;
+    if (c->pend_trk.active || c->pend_upd.active || c->pend_pv.active || c->pend_frame.active) { mskf_set_error("a batch of this context is pending"); return MSKF_ERR_INVALID; }
+    c->wait_block = block != 0;
+    return MSKF_OK;
+}
+
 extern "C" int mskf_ctx_timing_gate(mskf_ctx *c, int on) {
     if (!c) return MSKF_ERR_INVALID;
     c->t_gate = on != 0;          // no synchronisation: launches already begun keep the state they were begun with
@@ -735,7 +742,7 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
         const mskf_stream::Book &K = streams[i]->book;
         out_off[i] = out_bytes;
         out_bytes += (64 + 44 * (size_t)K.cap + 255) & ~(size_t)255;
-        scratch_bytes = std::max(scratch_bytes, 4 * fe_book_scratch_ints(K.cap, K.det_cap, K.n_codes, K.det_cap));
+        scratch_bytes = std::max(scratch_bytes, 4 * fe_book_scratch_ints(K.cap, K.cand_cap, K.det_cap, K.n_codes, K.det_cap));
         max_prev = std::max(max_prev, K.n_prev);
         // candidates are counted on the device: the launch is sized from the last frame's count, a block takes several point
         // groups if there are more this time

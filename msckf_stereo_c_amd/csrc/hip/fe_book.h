@@ -97,22 +97,29 @@ struct FeBookDev {          // everything the two kernels need for one stream (b
     mskf_point2f *x_cam0, *x_cam1, *x_und0, *x_und1;
 };
 
+// Everything a phase walks serially (one item per grid cell going over all survivors / detections / candidates) is staged
+// here first: a serial walk over global memory pays a cache round trip per element (the first version of fe_book1 counted
+// the survivors per cell that way and took 0.7 ms).
 struct FeBookScratch {      // workgroup scratch (LDS on the device), carved from one int array by fe_book_scratch_init
-    int *a;                 // max(cap, det_cap): flags / scan values
-    int *b;                 // max(cap, det_cap): codes
+    int *a;                 // max(cap, det_cap): flags / scan values / detection scores / ranked candidate lists
+    int *b;                 // max(cap, det_cap): grid codes of the survivors / of the detections
+    int *c;                 // cand_cap: per candidate, the score it is ranked with (-1: no stereo match)
+    int *d;                 // cap: lifetimes of the survivors
     int *chunk;             // FB_NTH + 1: chunk sums of the scans
     int *cellA, *cellB, *cellC, *cellD;   // n_codes + 1 each
     unsigned char *occ;     // det_rows * det_cols
 };
 
-FB_FN size_t fe_book_scratch_ints(int cap, int det_cap, int n_codes, int det_cells) {
+FB_FN size_t fe_book_scratch_ints(int cap, int cand_cap, int det_cap, int n_codes, int det_cells) {
     const int m = cap > det_cap ? cap : det_cap;
-    return (size_t)2 * m + (FB_NTH + 1) + (size_t)4 * (n_codes + 1) + (size_t)(det_cells + 3) / 4 + 8;
+    return (size_t)2 * m + cand_cap + cap + (FB_NTH + 1) + (size_t)4 * (n_codes + 1) + (size_t)(det_cells + 3) / 4 + 8;
 }
-FB_FN void fe_book_scratch_init(FeBookScratch &L, int *mem, int cap, int det_cap, int n_codes, int det_cells) {
+FB_FN void fe_book_scratch_init(FeBookScratch &L, int *mem, int cap, int cand_cap, int det_cap, int n_codes, int det_cells) {
     const int m = cap > det_cap ? cap : det_cap;
     L.a = mem; mem += m;
     L.b = mem; mem += m;
+    L.c = mem; mem += cand_cap;
+    L.d = mem; mem += cap;
     L.chunk = mem; mem += FB_NTH + 1;
     L.cellA = mem; mem += n_codes + 1;
     L.cellB = mem; mem += n_codes + 1;
@@ -186,6 +193,7 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
         B.tracked.id[k] = B.prev.id[i];
         B.tracked.lifetime[k] = B.prev.lifetime[i] + 1;
         B.tracked.code[k] = code;
+        L.b[k] = code;                                      // (b held the bit-0 flags' scan: dead since n_bit0 was read)
         B.tracked.response[k] = 0.f;
         B.tracked.cam0[k] = p; B.tracked.cam1[k] = B.t_out1[i];
         B.tracked.und0[k] = B.t_und0[i]; B.tracked.und1[k] = B.t_und1[i];
@@ -200,7 +208,7 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
     // tracked features per grid code: one item per code walks the survivors (no atomics)
     FB_FOR(c, B.n_codes) {
         int cnt = 0;
-        for (int k = 0; k < n_tr; ++k) cnt += B.tracked.code[k] == c ? 1 : 0;
+        for (int k = 0; k < n_tr; ++k) cnt += L.b[k] == c ? 1 : 0;
         L.cellA[c] = cnt;
         B.cell_count[c] = cnt;
     }
@@ -235,8 +243,8 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
         B.det_score[q] = (int)((key >> 32) & 0xFFFFFFULL);
     }
     FB_SYNC();
-    // grid code of every detection (reused by every cell's walk below)
-    FB_FOR(q, n_det) { const mskf_point2f p = B.det_pt[q]; L.b[q] = fb_grid_code(B, p.x, p.y); }
+    // grid code and score of every detection (walked by every cell below)
+    FB_FOR(q, n_det) { const mskf_point2f p = B.det_pt[q]; L.b[q] = fb_grid_code(B, p.x, p.y); L.a[q] = B.det_score[q]; }
     FB_SYNC();
     // ---- sieve (:661-677): every grid cell keeps its grid_max best detections by response, stable (equal responses keep
     //      their detection order).  Only the cells with a vacancy send theirs on (a full cell's candidates cannot influence any
@@ -271,7 +279,7 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
         const bool cut = cnt > K;
         for (int q = 0; q < n_det; ++q) {
             if (L.b[q] != c) continue;
-            const int s = B.det_score[q];
+            const int s = L.a[q];
             if (!cut) { best_q[m] = q; best_s[m] = s; ++m; continue; }
             if (m == K && !(s > best_s[K - 1])) continue;
             int pos = m < K ? m : K - 1;
@@ -296,8 +304,17 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
     FeBookState &st = *B.st;
     const int n_tr = st.n_tracked, n_cand = st.n_cand, n_det = st.n_det;
     int *tot = L.chunk + FB_NTH;
-    // codes of the survivors into scratch (every cell walks them twice)
-    FB_FOR(k, n_tr) L.b[k] = B.tracked.code[k];
+    // codes and lifetimes of the survivors into scratch (every cell walks them), and per candidate the score it is ranked
+    // with: under Q4 the detection-order score at the candidate's position in the full candidate list (:698), else its own
+    FB_FOR(k, n_tr) { L.b[k] = B.tracked.code[k]; L.d[k] = B.tracked.lifetime[k]; }
+    FB_FOR(i, n_cand) {
+        int sc = -1;
+        if (B.c_status[i] & 2) {
+            sc = B.cand_score[i];
+            if (B.q4) { const int di = B.cand_index[i]; sc = di < n_det ? B.det_score[di] : 0; }
+        }
+        L.c[i] = sc;
+    }
     FB_FOR(c, B.n_codes + 1) { L.cellA[c] = c < B.n_codes ? B.cell_count[c] : 0; }
     FB_SYNC();
     // ---- addNewFeatures tail (:700-750): per cell, the matched candidates ranked by response (stable) fill the vacancy.
@@ -314,9 +331,8 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
                 float best_r[FB_MAXK];
                 const int o = B.cand_off[c], e = o + B.cand_cnt[c];
                 for (int i = o; i < e && i < n_cand; ++i) {
-                    if (!(B.c_status[i] & 2)) continue;
-                    int sc = B.cand_score[i];
-                    if (B.q4) { const int di = B.cand_index[i]; sc = di < n_det ? B.det_score[di] : 0; }
+                    const int sc = L.c[i];
+                    if (sc < 0) continue;
                     const float r = (float)((double)sc / 256.0);
                     if (m == K && !(r > best_r[K - 1])) continue;
                     int pos = m < K ? m : K - 1;
@@ -363,8 +379,7 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
                 B.curr.und0[o] = B.tracked.und0[k]; B.curr.und1[o] = B.tracked.und1[k];
             } else {
                 const int i = L.a[c * B.grid_min + k];
-                int sc = B.cand_score[i];
-                if (B.q4) { const int di = B.cand_index[i]; sc = di < n_det ? B.det_score[di] : 0; }
+                const int sc = L.c[i];
                 B.curr.id[o] = id0 + (unsigned long long)(L.cellC[c] + k); B.curr.lifetime[o] = 1; B.curr.code[o] = c;
                 B.curr.response[o] = (float)((double)sc / 256.0);
                 B.curr.cam0[o] = B.c_out0[i]; B.curr.cam1[o] = B.c_out1[i];
@@ -387,7 +402,7 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
                 best_src[pos] = src_tracked; best_k[pos] = k; best_life[pos] = life;
                 if (m < K) ++m;
             };
-            for (int k = 0; k < n_tr; ++k) if (L.b[k] == c) offer(1, k, B.tracked.lifetime[k]);
+            for (int k = 0; k < n_tr; ++k) if (L.b[k] == c) offer(1, k, L.d[k]);
             for (int k = 0; k < n_n; ++k) offer(0, k, 1);
             for (int s = 0; s < m; ++s) emit(s, best_src[s], best_k[s]);
         }

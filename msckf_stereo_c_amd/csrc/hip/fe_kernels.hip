@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void k_fe_book(const FeBookDev *books, int whi
     const FeBookDev &B = books[blockIdx.x];
     extern __shared__ int s_book[];
     FeBookScratch L;
-    fe_book_scratch_init(L, s_book, B.cap, B.det_cap, B.n_codes, B.det_rows * B.det_cols);
+    fe_book_scratch_init(L, s_book, B.cap, B.cand_cap, B.det_cap, B.n_codes, B.det_rows * B.det_cols);
     if (which == 0) fe_book1(B, L); else fe_book2(B, L);
 }
 extern "C" void fe_launch_book(const FeBookDev *books_dev, int n_streams, int which, size_t scratch_bytes, hipStream_t st) {

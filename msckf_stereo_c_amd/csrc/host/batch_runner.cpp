@@ -64,6 +64,8 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
         const char *pe = std::getenv("MSKF_EKF_PRIORITY");   // default on; MSKF_EKF_PRIORITY=0 disables
         rc = mskf_ctx_create_prio(device, !(pe && pe[0] == '0'), &half_[0].ctx_ekf);
     }
+    // MSKF_FE_WAIT=block: the front-end stage parks in its one wait per frame (device frames) instead of spinning on it
+    if (rc == MSKF_OK) { const char *fw = std::getenv("MSKF_FE_WAIT"); if (fw && fw[0] == 'b') mskf_ctx_set_wait_mode(half_[0].ctx, 1); }
     for (int h = 1; h < nh && rc == MSKF_OK; ++h) {
         rc = mskf_ctx_create_shared(half_[0].ctx, &half_[h].ctx);
         if (rc == MSKF_OK) rc = mskf_ctx_create_shared(half_[0].ctx_ekf, &half_[h].ctx_ekf);

@@ -189,7 +189,7 @@ int main(int argc, char **argv) {
         for (auto &x : g) x.resize(cap);
         FeBookState st;
         std::memset(&st, 0, sizeof(st));
-        std::vector<int> scratch(fe_book_scratch_ints(cap, det_cap, n_codes, det_cells));
+        std::vector<int> scratch(fe_book_scratch_ints(cap, cand_cap, det_cap, n_codes, det_cells));
         std::vector<mskf_point2f> det_pt(det_cap), cand_pt(cand_cap), c_out0(cand_cap), c_out1(cand_cap), c_und0(cand_cap), c_und1(cand_cap);
         std::vector<int> det_score(det_cap), cand_index(cand_cap), cand_score(cand_cap), cand_off(n_cells + 1), cand_cnt(n_cells + 1), cell_count(n_codes + 1);
         std::vector<uint8_t> c_status(cand_cap);
@@ -255,7 +255,7 @@ int main(int argc, char **argv) {
             B.cell_count = cell_count.data();
             B.x_info = x_info.data(); B.x_id = x_id.data(); B.x_lifetime = x_life.data(); B.x_cam0 = x_c0.data(); B.x_cam1 = x_c1.data(); B.x_und0 = x_u0.data(); B.x_und1 = x_u1.data();
             FeBookScratch L;
-            fe_book_scratch_init(L, scratch.data(), cap, det_cap, n_codes, det_cells);
+            fe_book_scratch_init(L, scratch.data(), cap, cand_cap, det_cap, n_codes, det_cells);
             std::fill(scratch.begin(), scratch.end(), 0x5a5a5a5a);      // (nothing may depend on what the scratch held before)
             fe_book1(B, L);
             // candidates: the reference's list restricted to the cells with a vacancy, same order, same positions
