@@ -38,7 +38,8 @@ typedef struct mskf_ctx mskf_ctx;
 typedef struct mskf_stream mskf_stream;
 
 const char *mskf_last_error(void);
-int mskf_abi_version(void);   /* 2 since round 2: update args carry diag_out, mskf_ekf_cfg.compression_mode, *_begin / *_end entry points */
+int mskf_abi_version(void);   /* 2: update args carry diag_out, mskf_ekf_cfg.compression_mode, *_begin / *_end entry points; 3 (round 3): update args carry
+                                 pos_var_out, mskf_fe_frame_batch_* (whole front-end frames on the device), mskf_ctx_timing_gate, mskf_ctx_set_wait_mode */
 
 int mskf_ctx_create(int device, mskf_ctx **out);
 /* Same, with the context's HIP stream created at the device's most urgent priority when high_priority != 0.
@@ -223,6 +224,11 @@ typedef struct mskf_ekf_update_args {
     int32_t *diag_out;              /* out, optional (may be NULL), 2 ints: [0] how the stack was compressed: 0 Gram + Cholesky,
                                        1 Householder TSQR, 2 not at all (rows <= active columns, msckf_vio.cpp:818-821);
                                        [1] pivots of the Gram factor below 100 lambda (-1: not computed) */
+    double *pos_var_out;            /* out, optional (may be NULL), 3 doubles: P(12,12), P(13,13), P(14,14) AFTER this update, i.e.
+                                       what onlineReset tests (msckf_vio.cpp:1194-1196) — they come back with the update's
+                                       results, so a caller that updates every frame never needs mskf_ekf_get_pos_var and its
+                                       extra wait (clone removal does not touch these entries).  -1 when no stream of the batch
+                                       had features (nothing was launched).  ABI v3 */
 } mskf_ekf_update_args;
 
 /* What processModel (msckf_vio.cpp:409-469) needs to propagate the covariance over one IMU sample.

@@ -36,7 +36,7 @@ class EkfUpdateArgs(C.Structure):
                 ("apply_row_cap", C.c_int32), ("_pad", C.c_int32), ("gravity", C.c_double * 3),
                 ("clones", C.c_void_p), ("features", C.c_void_p), ("obs_clone", C.c_void_p), ("obs_z", C.c_void_p),
                 ("delta_x", C.c_void_p), ("feat_status", C.c_void_p), ("gamma", C.c_void_p), ("rows_out", C.c_void_p),
-                ("diag_out", C.c_void_p)]
+                ("diag_out", C.c_void_p), ("pos_var_out", C.c_void_p)]
 
 
 EXPORTS = [

@@ -16,6 +16,7 @@ void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
+void ekf_launch_posvar_upd(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
@@ -482,6 +483,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     int max_feat_pairs = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, tri; int n_tri; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
+    bool any_pv = false;
     std::vector<Lay> lay(n);
     size_t in_bytes = 0, out_bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -544,7 +546,8 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         L.o_gamma = align_up(L.o_dx + sizeof(double) * (size_t)E.ld, 16);
         L.o_pos = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
         L.o_rows = align_up(L.o_pos + sizeof(double) * 3 * (size_t)a.n_feat, 16);
-        L.o_status = L.o_rows + 32;
+        L.o_status = L.o_rows + 32 + 32;           // rows_out (5 ints, padded to 32 bytes) + 3 position variances
+        any_pv |= a.pos_var_out != nullptr;
         out_bytes = align_up(L.o_status + (size_t)a.n_feat, 64);
         if (m_total > E.max_rows) {
             MSKF_HIPCHK(hipStreamSynchronize(st));
@@ -635,6 +638,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         D.gamma = (double *)(dout + L.o_gamma);
         D.pos_out = (double *)(dout + L.o_pos);
         D.rows_out = (int *)(dout + L.o_rows);
+        D.pos_var_out = a.pos_var_out ? (double *)(dout + L.o_rows + 32) : nullptr;
         D.feat_status = (uint8_t *)(dout + L.o_status);
     }
     if (max_feat > 0) {
@@ -686,6 +690,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
         mskf_t_end(ctx, ts, any_general ? (long long)(4.0 * d3) : 0);
+        if (any_pv) ekf_launch_posvar_upd(ctx->ekf_desc.d, n, st);       // the position variances ride home with the results
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
@@ -730,6 +735,10 @@ extern "C" int mskf_ekf_update_batch_end(mskf_ctx *ctx) {
         EkfStreamState &E = streams[i]->ekf_state;
         const LayOut &L = lay[i];
         const int d = E.d;
+        if (a.pos_var_out) {
+            if (U.launched) std::memcpy(a.pos_var_out, hout + L.o_rows + 32, sizeof(double) * 3);
+            else a.pos_var_out[0] = a.pos_var_out[1] = a.pos_var_out[2] = -1.0;       // nothing ran: no value (variances are never negative)
+        }
         if (!a.n_feat) {
             if (a.delta_x) std::memset(a.delta_x, 0, sizeof(double) * (size_t)d);
             if (a.rows_out) *a.rows_out = 0;

@@ -11,7 +11,7 @@ static thread_local std::string g_last_error;
 void mskf_set_error(const std::string &s) { g_last_error = s; }
 
 extern "C" const char *mskf_last_error(void) { return g_last_error.c_str(); }
-extern "C" int mskf_abi_version(void) { return 2; }   // 2: round 2 (mskf_ekf_update_args.diag_out, compression_mode, *_begin / *_end, detector floor)
+extern "C" int mskf_abi_version(void) { return 3; }   // 3: round 3 (mskf_ekf_update_args.pos_var_out, mskf_fe_frame_batch_*, timing gate, wait mode)
 
 extern "C" int mskf_ctx_create(int device, mskf_ctx **out) { return mskf_ctx_create_prio(device, 0, out); }
 

@@ -50,6 +50,7 @@ struct EkfStreamDev {
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
     double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
+    double *pos_var_out;      // 3: P(12,12), P(13,13), P(14,14) after the update (k_ekf_posvar_upd), or null
     int route;                // which kernels handle this stream's update, decided per STREAM from its own features (never from
                               // the rest of the batch, so a stream's arithmetic does not depend on its neighbours): bit 0 pair
                               // kernels (every feature has exactly the same two Jacobian clones), bit 1 wave-per-feature class

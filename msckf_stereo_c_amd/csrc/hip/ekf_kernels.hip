@@ -268,6 +268,16 @@ __global__ void k_ekf_posvar(const EkfStreamDev *streams, int n, double *out) {
     out[i] = S.P[(size_t)k * S.ld + k];
 }
 
+// the same at the end of an update batch, into every stream's own result slot (mskf_ekf_update_args.pos_var_out)
+__global__ void k_ekf_posvar_upd(const EkfStreamDev *streams, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const EkfStreamDev &S = streams[i / 3];
+    if (!S.pos_var_out) return;
+    const int k = 12 + i % 3;
+    S.pos_var_out[i % 3] = S.P[(size_t)k * S.ld + k];
+}
+
 // ------------------------------------------------------------------------------------ feature blocks
 #define MAX_CLONES_DEV 64          // 4*64 = 256 block rows max per feature
 
@@ -1222,6 +1232,9 @@ void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int ma
 }
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_posvar, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n, out);
+}
+void ekf_launch_posvar_upd(const EkfStreamDev *d, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_ekf_posvar_upd, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n);
 }
 void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d); }
 }

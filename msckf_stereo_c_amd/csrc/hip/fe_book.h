@@ -20,8 +20,13 @@
 // The SAME source runs on the host in tests/cpp/fe_book_test.cpp: every step is a sequence of phases, a phase is a loop
 // over independent items (FB_FOR) that reads only what earlier phases wrote, and phases are separated by FB_SYNC.  On the
 // device the items of a phase are spread over the threads of the workgroup and FB_SYNC is the workgroup barrier; on the
-// host the items run one after the other.  No atomics, no cross-lane operations: sums and ranks come from scans with a
-// fixed order, so the results do not depend on the schedule and the host run is a faithful check of the logic.
+// host the items run one after the other.  Work is parallel over the ITEMS (features, detections, candidates), never a
+// serial walk of one thread per grid cell over all of them: an item finds its place among the few members of its own
+// cell.  Two kinds of cross-item operations: exclusive scans (exact integers: the device takes a wave-shuffle path, the
+// host a loop) and counters bumped with FB_INC (an atomic add on the device) that hand out slots of per-cell member lists.
+// The ORDER inside such a list depends on the schedule, but nothing that is read from it does: counts, and ranks under
+// total orders (ties broken by the item's own index), which is also how the reference's stable sorts are reproduced.
+// The host run is therefore a faithful check of the logic.
 #pragma once
 #include <stdint.h>
 #include "../../../include/mskf_types.h"
@@ -40,10 +45,12 @@
 #define FB_FOR(i, n) for (int i = (int)threadIdx.x; i < (n); i += (int)blockDim.x)
 #define FB_SYNC() __syncthreads()
 #define FB_NTH ((int)blockDim.x)
+#define FB_INC(p) atomicAdd((p), 1)
 #else
 #define FB_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define FB_SYNC() ((void)0)
 #define FB_NTH 256
+#define FB_INC(p) ((*(p))++)
 #endif
 
 #define FB_MAXK 16          // grid_min / grid_max above this: the host keeps the books (ImageProcessor falls back)
@@ -97,22 +104,22 @@ struct FeBookDev {          // everything the two kernels need for one stream (b
     mskf_point2f *x_cam0, *x_cam1, *x_und0, *x_und1;
 };
 
-// Everything a phase walks serially (one item per grid cell going over all survivors / detections / candidates) is staged
-// here first: a serial walk over global memory pays a cache round trip per element (the first version of fe_book1 counted
-// the survivors per cell that way and took 0.7 ms).
-struct FeBookScratch {      // workgroup scratch (LDS on the device), carved from one int array by fe_book_scratch_init
-    int *a;                 // max(cap, det_cap): flags / scan values / detection scores / ranked candidate lists
-    int *b;                 // max(cap, det_cap): grid codes of the survivors / of the detections
-    int *c;                 // cand_cap: per candidate, the score it is ranked with (-1: no stereo match)
+// Workgroup scratch (LDS on the device), carved from one int array by fe_book_scratch_init.
+struct FeBookScratch {
+    int *a;                 // max(cap, det_cap): flags / scan values; then detection scores
+    int *b;                 // max(cap, det_cap): grid codes of the survivors; then of the detections
+    int *c;                 // cand_cap: per candidate, the score it is ranked with (-1: no stereo match); then its rank among the cell's new features
     int *d;                 // cap: lifetimes of the survivors
-    int *chunk;             // FB_NTH + 1: chunk sums of the scans
-    int *cellA, *cellB, *cellC, *cellD;   // n_codes + 1 each
+    int *tl;                // cap: survivors listed by grid cell (order inside a cell unspecified)
+    int *dl;                // det_cap: detections listed by grid cell (order inside a cell unspecified)
+    int *chunk;             // FB_NTH + 1: partial sums of the scans, [FB_NTH] = total
+    int *cell[8];           // n_codes + 1 each
     unsigned char *occ;     // det_rows * det_cols
 };
 
 FB_FN size_t fe_book_scratch_ints(int cap, int cand_cap, int det_cap, int n_codes, int det_cells) {
     const int m = cap > det_cap ? cap : det_cap;
-    return (size_t)2 * m + cand_cap + cap + (FB_NTH + 1) + (size_t)4 * (n_codes + 1) + (size_t)(det_cells + 3) / 4 + 8;
+    return (size_t)2 * m + cand_cap + 2 * (size_t)cap + det_cap + (FB_NTH + 1) + (size_t)8 * (n_codes + 1) + (size_t)(det_cells + 3) / 4 + 8;
 }
 FB_FN void fe_book_scratch_init(FeBookScratch &L, int *mem, int cap, int cand_cap, int det_cap, int n_codes, int det_cells) {
     const int m = cap > det_cap ? cap : det_cap;
@@ -120,11 +127,10 @@ FB_FN void fe_book_scratch_init(FeBookScratch &L, int *mem, int cap, int cand_ca
     L.b = mem; mem += m;
     L.c = mem; mem += cand_cap;
     L.d = mem; mem += cap;
+    L.tl = mem; mem += cap;
+    L.dl = mem; mem += det_cap;
     L.chunk = mem; mem += FB_NTH + 1;
-    L.cellA = mem; mem += n_codes + 1;
-    L.cellB = mem; mem += n_codes + 1;
-    L.cellC = mem; mem += n_codes + 1;
-    L.cellD = mem; mem += n_codes + 1;
+    for (int q = 0; q < 8; ++q) { L.cell[q] = mem; mem += n_codes + 1; }
     L.occ = (unsigned char *)mem;
     (void)det_cells;
 }
@@ -134,32 +140,35 @@ FB_FN int fb_grid_code(const FeBookDev &B, float x, float y) {
     return (int)(y / (float)B.grid_h) * B.grid_col + (int)(x / (float)B.grid_w);
 }
 
-// Exclusive prefix sum of v[0, n) in place, total returned through *total (every caller passes workgroup-shared memory).
-// Chunks of consecutive items are summed by one item each, the chunk sums are scanned serially by one item, the chunks are
-// then rewritten: fixed order, no atomics.
-FB_FN void fb_exclusive_scan(int *v, int n, int *chunk, int *total) {
-    const int nth = FB_NTH;
-    const int per = (n + nth - 1) / nth;
-    const int nch = per > 0 ? (n + per - 1) / per : 0;
-    FB_FOR(c, nch) {
-        int s = 0;
-        const int e = (c + 1) * per < n ? (c + 1) * per : n;
-        for (int i = c * per; i < e; ++i) s += v[i];
-        chunk[c] = s;
+// Exclusive prefix sum of v[0, n) in place, total in chunk[FB_NTH] (workgroup-shared); exact integers, so the two
+// implementations give the same values: on the device blockDim elements per pass, inclusive scan inside a wavefront with
+// shuffles, the waves' totals through `chunk`; on the host a loop.  Ends with a barrier.
+FB_FN void fb_exclusive_scan(int *v, int n, int *chunk) {
+#if FB_DEVICE
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = (int)blockDim.x, nw = nth >> 6;
+    __syncthreads();                 // (everyone has read the previous scan's total before this one replaces it)
+    int carry = 0;
+    for (int base = 0; base < n; base += nth) {
+        const int i = base + tid;
+        const int own = i < n ? v[i] : 0;
+        int x = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) chunk[wave] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < nw; ++w) { const int t = chunk[w]; if (w < wave) woff += t; tot += t; }
+        if (i < n) v[i] = carry + woff + x - own;
+        carry += tot;
+        __syncthreads();
     }
-    FB_SYNC();
-    FB_FOR(one, 1) {
-        int run = 0;
-        for (int c = 0; c < nch; ++c) { const int t = chunk[c]; chunk[c] = run; run += t; }
-        *total = run;
-    }
-    FB_SYNC();
-    FB_FOR(c, nch) {
-        int run = chunk[c];
-        const int e = (c + 1) * per < n ? (c + 1) * per : n;
-        for (int i = c * per; i < e; ++i) { const int t = v[i]; v[i] = run; run += t; }
-    }
-    FB_SYNC();
+    if (tid == 0) chunk[FB_NTH] = carry;
+    __syncthreads();
+#else
+    int run = 0;
+    for (int i = 0; i < n; ++i) { const int t = v[i]; v[i] = run; run += t; }
+    chunk[FB_NTH] = run;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ after the first track call
@@ -167,20 +176,17 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
     FeBookState &st = *B.st;
     const int n = st.n_prev;
     const int det_cells = B.det_rows * B.det_cols;
-    int *tot = L.chunk + FB_NTH;         // scan totals land here (shared)
+    const int *tot = L.chunk + FB_NTH;
+    int *cnt_t = L.cell[0], *det_cnt = L.cell[1], *kept = L.cell[2], *flat = L.cell[3], *c_cnt = L.cell[4], *c_off = L.cell[5], *d_off = L.cell[6], *fill = L.cell[7];
     // ---- trackFeatures tail (:416-513).  status bit 0: temporal track inside the image, bit 1: stereo match accepted (only
     //      ever set together with bit 0).  Survivors keep their order (:440, :465-480 compaction), lifetime + 1 (:508).
-    FB_FOR(i, n) L.a[i] = (B.t_status[i] & 3) == 3 ? 1 : 0;
-    FB_FOR(c, B.n_codes + 1) { L.cellA[c] = 0; }
+    FB_FOR(i, n) { const int s = B.t_status[i]; L.a[i] = (s & 3) == 3 ? 1 : 0; L.b[i] = (s & 1) ? 1 : 0; }
+    FB_FOR(c, B.n_codes + 1) { cnt_t[c] = 0; det_cnt[c] = 0; fill[c] = 0; }
     FB_FOR(k, det_cells) L.occ[k] = 0;
     FB_SYNC();
-    // tracking info: features with bit 0 (the scan of a copy in b gives the count)
-    FB_FOR(i, n) L.b[i] = (B.t_status[i] & 1) ? 1 : 0;
-    FB_SYNC();
-    fb_exclusive_scan(L.b, n, L.chunk, tot);
+    fb_exclusive_scan(L.b, n, L.chunk);                 // tracking info: features with bit 0
     const int n_bit0 = *tot;
-    FB_SYNC();
-    fb_exclusive_scan(L.a, n, L.chunk, tot);
+    fb_exclusive_scan(L.a, n, L.chunk);
     const int n_tr = *tot;
     FB_SYNC();
     FB_FOR(i, n) {
@@ -193,10 +199,10 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
         B.tracked.id[k] = B.prev.id[i];
         B.tracked.lifetime[k] = B.prev.lifetime[i] + 1;
         B.tracked.code[k] = code;
-        L.b[k] = code;                                      // (b held the bit-0 flags' scan: dead since n_bit0 was read)
         B.tracked.response[k] = 0.f;
         B.tracked.cam0[k] = p; B.tracked.cam1[k] = B.t_out1[i];
         B.tracked.und0[k] = B.t_und0[i]; B.tracked.und1[k] = B.t_und1[i];
+        FB_INC(&cnt_t[code]);                               // survivors per grid code
         // CornerDetector::set_grid_position of the truncated pixel (:632-649)
         const int xi = (int)p.x, yi = (int)p.y;
         int r = (int)((float)yi / (float)B.det_ch), c = (int)((float)xi / (float)B.det_cw);
@@ -205,33 +211,25 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
         L.occ[r * B.det_cols + c] = 1;                      // (several items may store the same 1)
     }
     FB_SYNC();
-    // tracked features per grid code: one item per code walks the survivors (no atomics)
-    FB_FOR(c, B.n_codes) {
-        int cnt = 0;
-        for (int k = 0; k < n_tr; ++k) cnt += L.b[k] == c ? 1 : 0;
-        L.cellA[c] = cnt;
-        B.cell_count[c] = cnt;
-    }
+    FB_FOR(c, B.n_codes) B.cell_count[c] = cnt_t[c];
     FB_FOR(one, 1) {
         st.n_tracked = n_tr;
         st.before_tracking = n;
         if (n > 0) { st.after_tracking = n_bit0; st.after_matching = n_tr; st.after_ransac = n_tr; }   // (:383: nothing is touched without features)
     }
-    FB_SYNC();
     // ---- detections (:657): cells in order whose maximum beats the threshold and that hold no live feature
     FB_FOR(k, det_cells) {
         const unsigned long long key = B.cell_keys[k];
         const int score = (unsigned int)(key >> 56) == B.gen ? (int)((key >> 32) & 0xFFFFFFULL) : 0;
         L.a[k] = (score > B.thr_score && !L.occ[k]) ? 1 : 0;
+        L.dl[k] = L.a[k];                                   // (dl is free until the per-cell lists are built)
     }
     FB_SYNC();
-    FB_FOR(k, det_cells) L.b[k] = L.a[k];
-    FB_SYNC();
-    fb_exclusive_scan(L.a, det_cells, L.chunk, tot);
+    fb_exclusive_scan(L.a, det_cells, L.chunk);
     const int n_det = *tot;
     FB_SYNC();
     FB_FOR(k, det_cells) {
-        if (!L.b[k]) continue;
+        if (!L.dl[k]) continue;
         const unsigned long long key = B.cell_keys[k];
         const unsigned int order = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFULL);
         const int cy = k / B.det_cols, cx = k - cy * B.det_cols;
@@ -239,61 +237,60 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
         mskf_point2f p;
         p.y = (float)(cy * B.det_ch + (int)(order / (unsigned)B.det_cw));
         p.x = (float)(cx * B.det_cw + (int)(order % (unsigned)B.det_cw));
+        const int score = (int)((key >> 32) & 0xFFFFFFULL);
         B.det_pt[q] = p;
-        B.det_score[q] = (int)((key >> 32) & 0xFFFFFFULL);
+        B.det_score[q] = score;
+        // grid cell of the detection (:661-663; outside the nominal cells: dropped, Q7)
+        const int code = fb_grid_code(B, p.x, p.y);
+        L.b[q] = code;
+        if (code >= 0 && code < B.n_cells) FB_INC(&det_cnt[code]);
     }
     FB_SYNC();
-    // grid code and score of every detection (walked by every cell below)
-    FB_FOR(q, n_det) { const mskf_point2f p = B.det_pt[q]; L.b[q] = fb_grid_code(B, p.x, p.y); L.a[q] = B.det_score[q]; }
-    FB_SYNC();
+    FB_FOR(q, n_det) L.a[q] = B.det_score[q];               // (a held the scan: every reader of it is past the barrier)
     // ---- sieve (:661-677): every grid cell keeps its grid_max best detections by response, stable (equal responses keep
-    //      their detection order).  Only the cells with a vacancy send theirs on (a full cell's candidates cannot influence any
-    //      output), but every cell's kept count moves the position in the reference's full candidate list (Q4).
-    //      cellB = kept count of every cell, cellC = candidates of the cell (0 for a full one)
+    //      their detection order); a cell with fewer is not sorted at all (:664 sorts only when it has to cut).  Only the
+    //      cells with a vacancy send theirs on (a full cell's candidates cannot influence any output), but every cell's kept
+    //      count moves the position in the reference's full candidate list (Q4).
     FB_FOR(c, B.n_cells) {
-        int cnt = 0;
-        for (int q = 0; q < n_det; ++q) cnt += L.b[q] == c ? 1 : 0;
-        const int kept = cnt < B.grid_max ? cnt : B.grid_max;
-        L.cellB[c] = kept;
-        L.cellC[c] = L.cellA[c] < B.grid_min ? kept : 0;
+        const int k = det_cnt[c] < B.grid_max ? det_cnt[c] : B.grid_max;
+        kept[c] = k; flat[c] = k;
+        const int cc = cnt_t[c] < B.grid_min ? k : 0;
+        c_cnt[c] = cc; c_off[c] = cc;
+        d_off[c] = det_cnt[c];
     }
     FB_SYNC();
-    FB_FOR(c, B.n_cells) L.cellD[c] = L.cellB[c];
-    FB_SYNC();
-    fb_exclusive_scan(L.cellD, B.n_cells, L.chunk, tot);          // cellD = position of the cell's first candidate in the full list
-    FB_SYNC();
-    FB_FOR(c, B.n_cells) B.cand_cnt[c] = L.cellC[c];
-    FB_SYNC();
-    fb_exclusive_scan(L.cellC, B.n_cells, L.chunk, tot);          // cellC = offset of the cell in the list that is sent on
+    fb_exclusive_scan(flat, B.n_cells, L.chunk);             // position of the cell's first candidate in the full list
+    fb_exclusive_scan(d_off, B.n_cells, L.chunk);            // the cell's range in the per-cell detection lists
+    fb_exclusive_scan(c_off, B.n_cells, L.chunk);            // offset of the cell in the list that is sent on
     const int n_cand = *tot;
     FB_SYNC();
-    FB_FOR(c, B.n_cells) {
-        B.cand_off[c] = L.cellC[c];
-        if (B.cand_cnt[c] <= 0) continue;
-        // A cell with more than grid_max detections keeps its best grid_max, descending response, ties in detection order
-        // (insertion into a short list); a cell with fewer is NOT sorted (:664 sorts only when it has to cut): detection order.
-        int best_q[FB_MAXK], best_s[FB_MAXK];
-        int m = 0, cnt = 0;
-        const int K = B.grid_max;
-        for (int q = 0; q < n_det; ++q) cnt += L.b[q] == c ? 1 : 0;
-        const bool cut = cnt > K;
-        for (int q = 0; q < n_det; ++q) {
-            if (L.b[q] != c) continue;
-            const int s = L.a[q];
-            if (!cut) { best_q[m] = q; best_s[m] = s; ++m; continue; }
-            if (m == K && !(s > best_s[K - 1])) continue;
-            int pos = m < K ? m : K - 1;
-            while (pos > 0 && s > best_s[pos - 1]) { best_q[pos] = best_q[pos - 1]; best_s[pos] = best_s[pos - 1]; --pos; }
-            best_q[pos] = q; best_s[pos] = s;
-            if (m < K) ++m;
+    FB_FOR(c, B.n_cells) { B.cand_cnt[c] = c_cnt[c]; B.cand_off[c] = c_off[c]; }
+    FB_FOR(q, n_det) {
+        const int code = L.b[q];
+        if (code < 0 || code >= B.n_cells || c_cnt[code] <= 0) continue;
+        L.dl[d_off[code] + FB_INC(&fill[code])] = q;        // member list of the cell (order unspecified)
+    }
+    FB_SYNC();
+    // every detection of a cell with a vacancy finds its own place: its rank among the cell's detections, by (response
+    // descending, detection order) when the cell has to cut, by detection order when it does not
+    FB_FOR(q, n_det) {
+        const int code = L.b[q];
+        if (code < 0 || code >= B.n_cells || c_cnt[code] <= 0) continue;
+        const int o = d_off[code], m = det_cnt[code];
+        const bool cut = m > B.grid_max;
+        const int s = L.a[q];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const int q2 = L.dl[o + j];
+            const int s2 = L.a[q2];
+            rank += cut ? ((s2 > s || (s2 == s && q2 < q)) ? 1 : 0) : (q2 < q ? 1 : 0);
         }
-        const int off = L.cellC[c], flat = L.cellD[c];
-        for (int k = 0; k < m; ++k) {
-            if (off + k >= B.cand_cap) { st.overflow = 1; break; }
-            B.cand_pt[off + k] = B.det_pt[best_q[k]];
-            B.cand_score[off + k] = best_s[k];
-            B.cand_index[off + k] = flat + k;
-        }
+        if (rank >= kept[code]) continue;
+        const int at = c_off[code] + rank;
+        if (at >= B.cand_cap) { st.overflow = 1; continue; }
+        B.cand_pt[at] = B.det_pt[q];
+        B.cand_score[at] = s;
+        B.cand_index[at] = flat[code] + rank;
     }
     FB_FOR(one, 1) { st.n_det = n_det; st.n_cand = n_cand < B.cand_cap ? n_cand : B.cand_cap; }
     FB_SYNC();
@@ -303,10 +300,12 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
 FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
     FeBookState &st = *B.st;
     const int n_tr = st.n_tracked, n_cand = st.n_cand, n_det = st.n_det;
-    int *tot = L.chunk + FB_NTH;
-    // codes and lifetimes of the survivors into scratch (every cell walks them), and per candidate the score it is ranked
-    // with: under Q4 the detection-order score at the candidate's position in the full candidate list (:698), else its own
+    const int *tot = L.chunk + FB_NTH;
+    int *cnt_t = L.cell[0], *t_off = L.cell[1], *fill = L.cell[2], *new_cnt = L.cell[3], *new_off = L.cell[4], *out_off = L.cell[5];
+    // codes and lifetimes of the survivors, their per-cell counts, and per candidate the score it is ranked with: under Q4
+    // the detection-order score at the candidate's position in the full candidate list (:698), else its own
     FB_FOR(k, n_tr) { L.b[k] = B.tracked.code[k]; L.d[k] = B.tracked.lifetime[k]; }
+    FB_FOR(c, B.n_codes + 1) { const int v = c < B.n_codes ? B.cell_count[c] : 0; cnt_t[c] = v; t_off[c] = v; fill[c] = 0; }
     FB_FOR(i, n_cand) {
         int sc = -1;
         if (B.c_status[i] & 2) {
@@ -315,97 +314,84 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
         }
         L.c[i] = sc;
     }
-    FB_FOR(c, B.n_codes + 1) { L.cellA[c] = c < B.n_codes ? B.cell_count[c] : 0; }
     FB_SYNC();
+    fb_exclusive_scan(t_off, B.n_codes, L.chunk);
+    FB_SYNC();
+    FB_FOR(k, n_tr) { const int c = L.b[k]; L.tl[t_off[c] + FB_INC(&fill[c])] = k; }     // survivors of every cell (order unspecified)
     // ---- addNewFeatures tail (:700-750): per cell, the matched candidates ranked by response (stable) fill the vacancy.
-    //      cellB = new features of the cell.  The response a candidate is ranked with is, under Q4, the detection-order
-    //      response at the candidate's position in the full candidate list (:698), else its own.
-    //      The ranked list of a cell is kept in a[c * grid_min ..] for the emit phase (candidate indices; cap >= n_codes * grid_max).
+    //      A candidate's rank among its cell's matched candidates, by (response descending, candidate order): a[i], or -1
+    FB_FOR(i, n_cand) {
+        L.a[i] = -1;
+        const int sc = L.c[i];
+        if (sc < 0) continue;
+        const mskf_point2f p = B.cand_pt[i];
+        const int c = fb_grid_code(B, p.x, p.y);
+        if (c < 0 || c >= B.n_cells) continue;
+        const float r = (float)((double)sc / 256.0);
+        const int o = B.cand_off[c], e = o + B.cand_cnt[c];
+        int rank = 0;
+        for (int j = o; j < e && j < n_cand; ++j) {
+            const int s2 = L.c[j];
+            if (s2 < 0) continue;
+            const float r2 = (float)((double)s2 / 256.0);
+            rank += (r2 > r || (r2 == r && j < i)) ? 1 : 0;
+        }
+        if (rank < B.grid_min - cnt_t[c]) L.a[i] = rank;
+    }
     FB_FOR(c, B.n_codes) {
         int m = 0;
         if (c < B.n_cells) {
-            const int vac = B.grid_min - L.cellA[c];
-            const int K = vac < FB_MAXK ? vac : FB_MAXK;
-            if (K > 0) {
-                int best_i[FB_MAXK];
-                float best_r[FB_MAXK];
-                const int o = B.cand_off[c], e = o + B.cand_cnt[c];
-                for (int i = o; i < e && i < n_cand; ++i) {
-                    const int sc = L.c[i];
-                    if (sc < 0) continue;
-                    const float r = (float)((double)sc / 256.0);
-                    if (m == K && !(r > best_r[K - 1])) continue;
-                    int pos = m < K ? m : K - 1;
-                    while (pos > 0 && r > best_r[pos - 1]) { best_i[pos] = best_i[pos - 1]; best_r[pos] = best_r[pos - 1]; --pos; }
-                    best_i[pos] = i; best_r[pos] = r;
-                    if (m < K) ++m;
-                }
-                for (int k = 0; k < m; ++k) L.a[c * B.grid_min + k] = best_i[k];
-            }
+            const int o = B.cand_off[c], e = o + B.cand_cnt[c];
+            for (int j = o; j < e && j < n_cand; ++j) m += L.c[j] >= 0 ? 1 : 0;
+            const int vac = B.grid_min - cnt_t[c];
+            m = m < vac ? m : (vac > 0 ? vac : 0);
         }
-        L.cellB[c] = m;
+        new_cnt[c] = m; new_off[c] = m;
+        const int total = cnt_t[c] + m;
+        out_off[c] = total < B.grid_max ? total : B.grid_max;
     }
     FB_SYNC();
-    FB_FOR(c, B.n_codes) L.cellC[c] = L.cellB[c];
-    FB_SYNC();
-    fb_exclusive_scan(L.cellC, B.n_codes, L.chunk, tot);          // cellC = rank of the cell's first new feature: ids in ascending cell order (:745)
+    fb_exclusive_scan(new_off, B.n_codes, L.chunk);          // rank of the cell's first new feature: ids in ascending cell order (:745)
     const int n_new = *tot;
-    FB_SYNC();
-    // ---- this frame's grid (:498-513, :735-750) and pruneGridFeatures (:758-768): per cell the survivors in track order,
-    //      then the new features in rank order; a cell over grid_max keeps its grid_max longest-lived, stable.
-    //      cellD = features the cell publishes
-    FB_FOR(c, B.n_codes) {
-        const int total = L.cellA[c] + L.cellB[c];
-        L.cellD[c] = total < B.grid_max ? total : B.grid_max;
-    }
-    FB_SYNC();
-    // (the scan overwrites cellD with the offsets; the counts are recomputed where they are needed)
-    fb_exclusive_scan(L.cellD, B.n_codes, L.chunk, tot);
+    fb_exclusive_scan(out_off, B.n_codes, L.chunk);          // where the cell starts in the published grid
     const int n_curr = *tot;
     FB_SYNC();
     const unsigned long long id0 = st.next_id;
-    FB_FOR(c, B.n_codes) {
-        const int n_t = L.cellA[c], n_n = L.cellB[c], total = n_t + n_n;
-        const int out0 = L.cellD[c];
-        if (total == 0) continue;
-        // member m of the cell: m < n_t -> the m-th survivor with this code (track order); else new feature m - n_t
-        auto emit = [&](int slot, int src_tracked, int k) {
-            const int o = out0 + slot;
-            if (o >= B.cap) { st.overflow = 1; return; }
-            if (src_tracked) {
-                B.curr.id[o] = B.tracked.id[k]; B.curr.lifetime[o] = B.tracked.lifetime[k]; B.curr.code[o] = c;
-                B.curr.response[o] = B.tracked.response[k];
-                B.curr.cam0[o] = B.tracked.cam0[k]; B.curr.cam1[o] = B.tracked.cam1[k];
-                B.curr.und0[o] = B.tracked.und0[k]; B.curr.und1[o] = B.tracked.und1[k];
-            } else {
-                const int i = L.a[c * B.grid_min + k];
-                const int sc = L.c[i];
-                B.curr.id[o] = id0 + (unsigned long long)(L.cellC[c] + k); B.curr.lifetime[o] = 1; B.curr.code[o] = c;
-                B.curr.response[o] = (float)((double)sc / 256.0);
-                B.curr.cam0[o] = B.c_out0[i]; B.curr.cam1[o] = B.c_out1[i];
-                B.curr.und0[o] = B.c_und0[i]; B.curr.und1[o] = B.c_und1[i];
-            }
-        };
-        if (total <= B.grid_max) {
-            int slot = 0;
-            for (int k = 0; k < n_tr && slot < n_t; ++k) if (L.b[k] == c) emit(slot++, 1, k);
-            for (int k = 0; k < n_n; ++k) emit(n_t + k, 0, k);
-        } else {
-            // the grid_max longest-lived of the cell's members, ties in member order: insertion into a short list
-            int best_src[FB_MAXK], best_k[FB_MAXK], best_life[FB_MAXK];
-            int m = 0;
-            const int K = B.grid_max;
-            auto offer = [&](int src_tracked, int k, int life) {
-                if (m == K && !(life > best_life[K - 1])) return;
-                int pos = m < K ? m : K - 1;
-                while (pos > 0 && life > best_life[pos - 1]) { best_src[pos] = best_src[pos - 1]; best_k[pos] = best_k[pos - 1]; best_life[pos] = best_life[pos - 1]; --pos; }
-                best_src[pos] = src_tracked; best_k[pos] = k; best_life[pos] = life;
-                if (m < K) ++m;
-            };
-            for (int k = 0; k < n_tr; ++k) if (L.b[k] == c) offer(1, k, L.d[k]);
-            for (int k = 0; k < n_n; ++k) offer(0, k, 1);
-            for (int s = 0; s < m; ++s) emit(s, best_src[s], best_k[s]);
+    // ---- this frame's grid (:498-513, :735-750) and pruneGridFeatures (:758-768): per cell the survivors in track order,
+    //      then the new features in rank order; a cell over grid_max keeps its grid_max longest-lived, stable.  A survivor's
+    //      slot is its rank among the cell's survivors: by track order, or by (lifetime descending, track order) when the cell
+    //      is cut.  New features have lifetime 1, survivors at least 2: the new ones always follow, in rank order.
+    FB_FOR(k, n_tr) {
+        const int c = L.b[k];
+        const int m = cnt_t[c], total = m + new_cnt[c];
+        const bool cut = total > B.grid_max;
+        const int life = L.d[k], o = t_off[c];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const int k2 = L.tl[o + j];
+            rank += cut ? ((L.d[k2] > life || (L.d[k2] == life && k2 < k)) ? 1 : 0) : (k2 < k ? 1 : 0);
         }
+        if (rank >= B.grid_max) continue;
+        const int at = out_off[c] + rank;
+        if (at >= B.cap) { st.overflow = 1; continue; }
+        B.curr.id[at] = B.tracked.id[k]; B.curr.lifetime[at] = life; B.curr.code[at] = c;
+        B.curr.response[at] = B.tracked.response[k];
+        B.curr.cam0[at] = B.tracked.cam0[k]; B.curr.cam1[at] = B.tracked.cam1[k];
+        B.curr.und0[at] = B.tracked.und0[k]; B.curr.und1[at] = B.tracked.und1[k];
+    }
+    FB_FOR(i, n_cand) {
+        const int r = L.a[i];
+        if (r < 0) continue;
+        const mskf_point2f p = B.cand_pt[i];
+        const int c = fb_grid_code(B, p.x, p.y);
+        const int slot = cnt_t[c] + r;
+        if (slot >= B.grid_max) continue;
+        const int at = out_off[c] + slot;
+        if (at >= B.cap) { st.overflow = 1; continue; }
+        B.curr.id[at] = id0 + (unsigned long long)(new_off[c] + r); B.curr.lifetime[at] = 1; B.curr.code[at] = c;
+        B.curr.response[at] = (float)((double)L.c[i] / 256.0);
+        B.curr.cam0[at] = B.c_out0[i]; B.curr.cam1[at] = B.c_out1[i];
+        B.curr.und0[at] = B.c_und0[i]; B.curr.und1[at] = B.c_und1[i];
     }
     FB_SYNC();
     // ---- what the host gets (publish, :1137-1182, writes the message from it) and the state of the next frame
@@ -415,7 +401,6 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
         B.x_cam0[o] = B.curr.cam0[o]; B.x_cam1[o] = B.curr.cam1[o];
         B.x_und0[o] = B.curr.und0[o]; B.x_und1[o] = B.curr.und1[o];
     }
-    FB_SYNC();
     FB_FOR(one, 1) {
         st.n_new = n_new;
         st.n_curr = n_out;
@@ -423,7 +408,8 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
         st.n_prev = n_out;
         B.x_info[0] = n_out; B.x_info[1] = n_cand; B.x_info[2] = st.before_tracking; B.x_info[3] = st.after_tracking;
         B.x_info[4] = st.after_matching; B.x_info[5] = st.after_ransac;
-        B.x_info[6] = (int)(unsigned int)(st.next_id & 0xFFFFFFFFULL); B.x_info[7] = (int)(unsigned int)(st.next_id >> 32);
+        const unsigned long long nid = id0 + (unsigned long long)n_new;
+        B.x_info[6] = (int)(unsigned int)(nid & 0xFFFFFFFFULL); B.x_info[7] = (int)(unsigned int)(nid >> 32);
         B.x_info[8] = st.overflow; B.x_info[9] = n_new; B.x_info[10] = st.n_det; B.x_info[11] = n_tr;
     }
     FB_SYNC();

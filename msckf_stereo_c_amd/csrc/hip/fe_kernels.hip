@@ -12,6 +12,7 @@
 // window), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
+#include <mutex>
 #include "fe_device.h"
 
 // ------------------------------------------------------------------------------------------ pyr_down
@@ -900,6 +901,9 @@ __global__ __launch_bounds__(256) void k_fe_book(const FeBookDev *books, int whi
     if (which == 0) fe_book1(B, L); else fe_book2(B, L);
 }
 extern "C" void fe_launch_book(const FeBookDev *books_dev, int n_streams, int which, size_t scratch_bytes, hipStream_t st) {
+    // (the 4K configuration's lists need more than the 64 KiB a kernel gets by default)
+    static std::once_flag attr_once;
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fe_book), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
     hipLaunchKernelGGL(k_fe_book, dim3(n_streams), dim3(256), scratch_bytes, st, books_dev, which);
 }
 

@@ -251,6 +251,15 @@ int BatchGroup::step_ekf(const FrameBatch *fb) {
         for (int k = 0; k < H.n; ++k) any_rm |= H.rm[2 * k] >= 0;
         if (any_rm) BR_CHK(mskf_ekf_remove_clones_batch(H.ctx_ekf, H.n, streams_.data() + H.i0, H.rm.data()));
         lap(PH_EKF_C);
+        // onlineReset (msckf_vio.cpp:1186-1236) needs P(12..14) of every stream: they came back with the frame's last update;
+        // only when some stream had no update at all this frame they are fetched with a launch and a wait of their own
+        bool all_pv = true;
+        for (int k = 0; k < H.n && all_pv; ++k) { const MsckfVio &v = *systems_[H.i0 + k]->msckfvio_ptr(); all_pv = !v.frameActive() || v.havePosVar(); }
+        if (all_pv) {
+            for (int k = 0; k < H.n; ++k) { MsckfVio &v = *systems_[H.i0 + k]->msckfvio_ptr(); if (v.frameActive()) v.phaseD(v.posVar()); }
+            lap(PH_POSVAR);
+            continue;
+        }
         H.pv.assign(3 * (size_t)H.n, 0.0);
         BR_CHK(mskf_ekf_get_pos_var_batch_begin(H.ctx_ekf, H.n, streams_.data() + H.i0, H.pv.data()));
         H.pv_pending = true;

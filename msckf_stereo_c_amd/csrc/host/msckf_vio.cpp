@@ -155,6 +155,7 @@ void MsckfVio::featureCallback(const CameraMeasurementConstPtr &msg) {
     }
     phaseC();
     if (cfg_.position_std_threshold > 0) {
+        if (pos_var_valid_) { phaseD(pos_var_); return; }      // came back with the frame's last update (clone removal does not touch it)
         double pv[3];
         int rc = mskf_ekf_get_pos_var(stream_, pv);
         if (rc != MSKF_OK) { fail("mskf_ekf_get_pos_var", rc); return; }
@@ -165,6 +166,7 @@ void MsckfVio::featureCallback(const CameraMeasurementConstPtr &msg) {
 bool MsckfVio::phaseA(const CameraMeasurementConstPtr &msg, mskf_ekf_update_args &upd, bool defer_device) {
     std::memset(&upd, 0, sizeof(upd));
     frame_active_ = false;
+    pos_var_valid_ = false;
     defer_device_ = defer_device;
     have_J_ = false;
     imu_steps_.clear();
@@ -394,6 +396,8 @@ void MsckfVio::finishArgs(mskf_ekf_update_args &upd, int dof_offset, int apply_c
     upd.rows_out = &rows_out_;
     upd.diag_out = diag_out_;
     diag_out_[0] = diag_out_[1] = 0;
+    upd.pos_var_out = pos_var_buf_;         // P(12..14, 12..14) diagonal after the update, for onlineReset (phaseD)
+    pos_var_buf_[0] = pos_var_buf_[1] = pos_var_buf_[2] = -1.0;
 }
 
 // removeLostFeatures, selection part (:937-984).  Features are visited in ascending id (the reference's map order);
@@ -528,6 +532,7 @@ void MsckfVio::dumpFeatureJacobians() {
 }
 
 void MsckfVio::phaseB(mskf_ekf_update_args &upd) {
+    if (!feats_.empty()) takePosVar();           // what the lost-feature update brought back
     dumpFeatureJacobians();                      // (no-op unless file outputs are on and this is frame 9)
     // tail of removeLostFeatures (:1016-1021)
     if (!feats_.empty() && rows_out_ > 0) { hostprof::Scope hp(hostprof::EKF_APPLY1); applyCorrection(delta_x_); }
@@ -628,6 +633,7 @@ void MsckfVio::phaseC(bool defer_device) {
     pending_rm_[0] = pending_rm_[1] = -1;
     if (!frame_active_) return;
     if (prune_pending_) {
+        if (!feats_.empty()) takePosVar();       // the pruning update ran after the lost-feature update: its values are the current ones
         dumpFeatureJacobians();
         hostprof::Scope hp(hostprof::EKF_TAIL_PRUNE);
         // tail of pruneCamStateBuffer (:1100-1181)

@@ -83,6 +83,9 @@ class MsckfVio {
     const int32_t *pendingRemovals() const { return pending_rm_; }   // two clone indices (current state order) or -1
     // phase D: online reset decision from the position variances (msckf_vio.cpp:1186-1236)
     void phaseD(const double pos_var[3]);
+    // the position variances the last update of this frame brought back (mskf_ekf_update_args.pos_var_out), if any
+    bool havePosVar() const { return pos_var_valid_; }
+    const double *posVar() const { return pos_var_; }
     bool frameActive() const { return frame_active_; }
     void enableFileOutputs() {   // msckf_vio.cpp:169-171
         if (!pose_outfile_.is_open()) pose_outfile_.open("pose_out.txt");
@@ -174,6 +177,9 @@ class MsckfVio {
     std::vector<uint8_t> feat_status_;
     int32_t rows_out_ = 0;
     int32_t diag_out_[2] = {0, 0};
+    double pos_var_[3] = {-1, -1, -1}, pos_var_buf_[3] = {-1, -1, -1};
+    bool pos_var_valid_ = false;
+    void takePosVar() { if (pos_var_buf_[0] >= 0) { pos_var_[0] = pos_var_buf_[0]; pos_var_[1] = pos_var_buf_[1]; pos_var_[2] = pos_var_buf_[2]; pos_var_valid_ = true; } }
     int n_tsqr_ = 0, n_direct_ = 0;
     long long rows_sum_ = 0;
     std::vector<StateIDType> rm_cam_state_ids_;
