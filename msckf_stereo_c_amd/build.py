@@ -16,6 +16,8 @@ OUT = os.path.join(HERE, "_build")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# extra compiler flags for experiments (e.g. MSKF_EXTRA_FLAGS=-DEKF_NO_PRIO python -m msckf_stereo_c_amd.build --force)
+COMMON += [f for f in os.environ.get("MSKF_EXTRA_FLAGS", "").split() if f]
 
 HIP_SRCS = [
     "hip/fe_kernels.hip",

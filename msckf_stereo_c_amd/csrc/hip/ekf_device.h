@@ -5,6 +5,15 @@
 #include "../../../include/mskf_hip.h"
 
 #define EKF_IMU_DIM 21
+// The filter's kernels are the serial chain of a frame (a dozen short, latency-bound launches per update) and share the
+// device with the front-end's wide, VALU-bound kernels of the other groups.  Their waves ask for the highest issue
+// priority: on a SIMD they share with track / detector waves they are served first (the stream priority only orders the
+// dispatch).  -DEKF_NO_PRIO builds without.
+#ifdef EKF_NO_PRIO
+#define EKF_PRIO() ((void)0)
+#else
+#define EKF_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 #define EKF_SLOTS 64          // feature workgroups per stream and launch (each loops over its features)
 
 // Per feature of one update (device copy of mskf_ekf_feature + row offset of its block)
