@@ -43,7 +43,7 @@ void ForkJoin::run(int n, const std::function<void(int)> &fn) {
     while (done_.load() < nt_ - 1) std::this_thread::yield();
 }
 
-BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads) {
+BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads, mskf_ctx *fe_queue) {
     // per-stream host phases of a group are independent: optional helper threads for the front-end / filter halves
     // (MSKF_FE_HOST_THREADS / MSKF_EKF_HOST_THREADS override the common host_threads argument)
     int ht_fe = host_threads, ht_ekf = host_threads;
@@ -59,7 +59,7 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
     if (const char *e = std::getenv("MSKF_HALVES")) nh = std::max(1, std::min(2, std::atoi(e)));
     if (n < 2) nh = 1;
     half_.resize(nh);
-    int rc = mskf_ctx_create(device, &half_[0].ctx);
+    int rc = fe_queue ? mskf_ctx_create_shared(fe_queue, &half_[0].ctx) : mskf_ctx_create(device, &half_[0].ctx);
     if (rc == MSKF_OK) {
         const char *pe = std::getenv("MSKF_EKF_PRIORITY");   // default on; MSKF_EKF_PRIORITY=0 disables
         rc = mskf_ctx_create_prio(device, !(pe && pe[0] == '0'), &half_[0].ctx_ekf);
@@ -77,6 +77,7 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
         systems_.emplace_back(new System(calib, fe, ekf, H.ctx, device));
         if (!systems_.back()->ok()) { error_ = std::string("stream setup failed: ") + mskf_last_error(); return; }
         systems_.back()->copy_draw_buffers = false;
+        systems_.back()->imgproc_ptr_->setCompactTail(true);      // the Q1 tail of the message as a count (image_processor.h)
         streams_.push_back(systems_.back()->stream());
         // the filter half of every stream runs on its own context (own HIP stream): no device data is shared
         if (mskf_stream_set_ekf_ctx(streams_.back(), H.ctx_ekf) != MSKF_OK) { error_ = mskf_last_error(); return; }
@@ -190,7 +191,7 @@ int BatchGroup::step_ekf(const FrameBatch *fb) {
         if (fb) { msgs[i] = fb->msg[i]; v.setZeroTailHint(msgs[i].get(), fb->tail_start[i], fb->total[i]); }
         else {
             msgs[i] = systems_[i]->feature_msg();
-            v.setZeroTailHint(msgs[i].get(), systems_[i]->imgproc_ptr_->zeroTailStart());
+            v.setZeroTailHint(msgs[i].get(), systems_[i]->imgproc_ptr_->zeroTailStart(), systems_[i]->imgproc_ptr_->messageSize());
         }
     }
     // streams of the half with a non-empty update -> one batched launch (args stay in H until the *_end call)
@@ -451,8 +452,8 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
         for (int i = 0; i < n; ++i) {
             const ImageProcessor &ip = *systems_[i]->imgproc_ptr_;
             const CameraMeasurement &live = *ip.feature_msg_ptr_;
-            const size_t total = live.features.size(), start = ip.zeroTailStart();
-            const size_t keep = std::min(total, start + 1);
+            const size_t total = ip.messageSize(), start = ip.zeroTailStart();
+            const size_t keep = std::min(live.features.size(), start + 1);
             if (!fb->msg[i] || fb->msg[i].use_count() > 1) fb->msg[i].reset(new CameraMeasurement);
             fb->msg[i]->time_stamp = live.time_stamp;
             fb->msg[i]->features.assign(live.features.begin(), live.features.begin() + keep);
@@ -489,7 +490,21 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
 MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
                          int host_threads)
     : n_groups_(n_groups), per_group_(per_group), off_(n_groups, 0), next_(n_groups, 0), win_(n_groups) {
-    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads));
+    // A device offers 16 hardware queues before streams get multiplexed (GPU_MAX_HW_QUEUES).  Every group needs a queue of its own
+    // for its filter stage (the serial chain of the frame); its front-end stage is ONE device call per frame and idles most of the
+    // step, so several groups may share a front-end queue: MSKF_FE_QUEUES = n shares n front-end streams round robin among the
+    // groups (0 / unset: one per group), which lets 12 groups run on 12 + 4 queues.
+    int nq = 0;
+    if (const char *e = std::getenv("MSKF_FE_QUEUES")) nq = std::max(0, std::atoi(e));
+    if (nq >= n_groups) nq = 0;
+    for (int q = 0; q < nq; ++q) { mskf_ctx *c = nullptr; if (mskf_ctx_create(device, &c) == MSKF_OK) fe_queues_.push_back(c); }
+    if ((int)fe_queues_.size() != nq) { for (mskf_ctx *c : fe_queues_) mskf_ctx_destroy(c); fe_queues_.clear(); nq = 0; }
+    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads, nq ? fe_queues_[g % nq] : nullptr));
+}
+
+MultiRunner::~MultiRunner() {
+    groups_.clear();                                   // shared contexts first: they borrow the owners' streams
+    for (mskf_ctx *c : fe_queues_) mskf_ctx_destroy(c);
 }
 
 bool MultiRunner::ok() const {

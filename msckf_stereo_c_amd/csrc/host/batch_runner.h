@@ -92,7 +92,8 @@ class ForkJoin {
 
 class BatchGroup {
   public:
-    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1);
+    // fe_queue: a context whose HIP stream this group's front-end stage shares with other groups (nullptr: a stream of its own)
+    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1, mskf_ctx *fe_queue = nullptr);
     ~BatchGroup();
     bool ok() const { return ok_; }
     int size() const { return (int)systems_.size(); }
@@ -158,6 +159,7 @@ class MultiRunner {
   public:
     MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
                 int host_threads = 1);
+    ~MultiRunner();
     bool ok() const;
     int n_streams() const { return n_groups_ * per_group_; }
     int n_groups() const { return n_groups_; }
@@ -184,6 +186,7 @@ class MultiRunner {
   private:
     int n_groups_, per_group_;
     std::vector<std::unique_ptr<BatchGroup>> groups_;
+    std::vector<mskf_ctx *> fe_queues_;     // MSKF_FE_QUEUES: front-end streams shared by several groups (owners; the groups hold shared contexts)
     std::vector<int> off_, next_;   // per group: frame offset, next frame not yet processed
     std::vector<TimedWindow> win_;
 };

@@ -170,10 +170,13 @@ void mskfh_get_dump(void *h, int stream, uint64_t *ids, int32_t *lifetime, mskf_
     info->before_tracking = ip.last_tracking_info.before_tracking; info->after_tracking = ip.last_tracking_info.after_tracking;
     info->after_matching = ip.last_tracking_info.after_matching; info->after_ransac = ip.last_tracking_info.after_ransac;
 }
-int mskfh_msg_size(void *h, int stream) { return (int)((MultiRunner *)h)->system(stream).imgproc_ptr_->feature_msg_ptr_->features.size(); }
+// the message as the reference holds it: with the whole Q1 tail of never-written records (kept as a count by the batch runner)
+int mskfh_msg_size(void *h, int stream) { return (int)((MultiRunner *)h)->system(stream).imgproc_ptr_->messageSize(); }
 void mskfh_get_msg(void *h, int stream, mskf_feature_meas *out) {
-    const auto &f = ((MultiRunner *)h)->system(stream).imgproc_ptr_->feature_msg_ptr_->features;
+    const ImageProcessor &ip = *((MultiRunner *)h)->system(stream).imgproc_ptr_;
+    const auto &f = ip.feature_msg_ptr_->features;
     static_assert(sizeof(FeatureMeasurement) == sizeof(mskf_feature_meas), "record layout");
+    std::memset(out, 0, ip.messageSize() * sizeof(mskf_feature_meas));
     std::memcpy(out, f.data(), f.size() * sizeof(mskf_feature_meas));
 }
 int mskfh_num_poses(void *h, int stream) { return (int)((MultiRunner *)h)->system(stream).msckfvio_ptr()->poses().size(); }

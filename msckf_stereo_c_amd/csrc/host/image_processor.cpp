@@ -686,6 +686,12 @@ void ImageProcessor::publish() {
     const size_t n = curr_.size();
     // Q1: the reference push_backs one value-initialised record per feature and then writes records 0 .. n-1: the
     // message grows by n every frame and is never cleared
+    if (compact_tail_) {
+        if (!(cfg_.compat_flags & MSKF_COMPAT_Q1_MSG_ACCUMULATE)) logical_size_ = 0;
+        logical_size_ += n;
+        const size_t head = std::max(max_published_, n);            // live + stale records
+        msg.resize(std::min(logical_size_, head + 1), FeatureMeasurement{0, 0, 0, 0, 0});
+    } else
     msg.resize(msg.size() + n, FeatureMeasurement{0, 0, 0, 0, 0});
     for (size_t i = 0; i < n; ++i) {
         FeatureMeasurement &m = msg[i];

@@ -90,6 +90,13 @@ class ImageProcessor {
     void enableFileOutputs() { if (!debug_.is_open()) debug_.open("debug_imageprocessor.txt"); }   // image_processor.cpp:134
     // records [zeroTailStart(), features.size()) of feature_msg_ptr_ were pushed but never written (Q1)
     size_t zeroTailStart() const { return max_published_; }
+    // Q1 makes the message grow by a frame's features every frame, for ever (a 2000-frame run: 35 MB per stream, every frame's
+    // records written into fresh pages).  Everything behind zeroTailStart() is value-initialised records that are never written, so
+    // a caller that knows the convention (the batch runner; MsckfVio::setZeroTailHint collapses that tail anyway) may ask for the tail to
+    // be kept as a COUNT: the vector then holds the live and stale records plus the first tail record, messageSize() is what
+    // features.size() would be.  Off by default: the public member behaves as in the reference.
+    void setCompactTail(bool on) { compact_tail_ = on; }
+    size_t messageSize() const { return compact_tail_ ? logical_size_ : feature_msg_ptr_->features.size(); }
 
     // debug / parity: live grid in flatten order
     void dumpCurrent(std::vector<FeatureIDType> &ids, std::vector<int> &lifetime, std::vector<Point2f> &cam0,
@@ -179,6 +186,8 @@ class ImageProcessor {
     std::vector<int> sieve_count_;                                       // candidates per grid cell (all cells)
     std::vector<int> order_;                                             // scratch: sort permutation
     size_t max_published_ = 0;
+    bool compact_tail_ = false;
+    size_t logical_size_ = 0;
     int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
     bool device_grid_valid_ = false;   // the device's grid is the one this object published last (false after a host-side frame)
     std::ofstream debug_;
