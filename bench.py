@@ -605,6 +605,8 @@ def main(argv=None):
                 "frames_started_in_window": {"front_end": int(sum(w["fe_frames"] for w in windows)), "filter": int(sum(w["ekf_frames"] for w in windows)),
                                              "counted": args.steps * n_groups},
                 "frames_run_by_group": frames_by_group,      # each >= W + K; the spread is how unevenly the groups' queues were served
+                "stage_ms_per_frame_by_group": {"front_end": [round((w["fe_close"] - w["fe_open"]) * 1e3 / max(w["fe_frames"], 1), 2) for w in windows],
+                                                "filter": [round((w["ekf_close"] - w["ekf_open"]) * 1e3 / max(w["ekf_frames"], 1), 2) for w in windows]},
                 "run_wall_ms": round(wall_run * 1e3, 1),
             }
         else:

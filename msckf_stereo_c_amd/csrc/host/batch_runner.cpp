@@ -494,6 +494,10 @@ MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_cal
     // for its filter stage (the serial chain of the frame); its front-end stage is ONE device call per frame and idles most of the
     // step, so several groups may share a front-end queue: MSKF_FE_QUEUES = n shares n front-end streams round robin among the
     // groups (0 / unset: one per group), which lets 12 groups run on 12 + 4 queues.
+    // MSKF_DUMMY_STREAMS = k: k HIP streams created (and left idle) before the groups' own (experiment: the first streams a
+    // process creates were served measurably worse than the later ones)
+    if (const char *e = std::getenv("MSKF_DUMMY_STREAMS"))
+        for (int q = 0; q < std::atoi(e); ++q) { mskf_ctx *c = nullptr; if (mskf_ctx_create(device, &c) == MSKF_OK) dummies_.push_back(c); }
     int nq = 0;
     if (const char *e = std::getenv("MSKF_FE_QUEUES")) nq = std::max(0, std::atoi(e));
     if (nq >= n_groups) nq = 0;
@@ -505,6 +509,7 @@ MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_cal
 MultiRunner::~MultiRunner() {
     groups_.clear();                                   // shared contexts first: they borrow the owners' streams
     for (mskf_ctx *c : fe_queues_) mskf_ctx_destroy(c);
+    for (mskf_ctx *c : dummies_) mskf_ctx_destroy(c);
 }
 
 bool MultiRunner::ok() const {

@@ -186,6 +186,7 @@ class MultiRunner {
   private:
     int n_groups_, per_group_;
     std::vector<std::unique_ptr<BatchGroup>> groups_;
+    std::vector<mskf_ctx *> dummies_;
     std::vector<mskf_ctx *> fe_queues_;     // MSKF_FE_QUEUES: front-end streams shared by several groups (owners; the groups hold shared contexts)
     std::vector<int> off_, next_;   // per group: frame offset, next frame not yet processed
     std::vector<TimedWindow> win_;
