@@ -97,7 +97,9 @@ def parse(argv=None):
         if getattr(args, k) is None:
             setattr(args, k, preset[k] if k not in ("streams", "groups") else int(os.environ.get("MSKF_BENCH_" + k.upper(), preset[k])))
     if args.prime is None:
-        args.prime = 25 + 20 + args.clones      # static start, gravity/bias initialisation, clone window full
+        # static start, gravity / bias initialisation, clone window full — and one whole period of the looping trajectory, so that
+        # every group has met its largest frame (staging buffers grow to their final size) before the timed steps
+        args.prime = max(25 + 20 + args.clones, 25 + args.loop + 2)
     return args
 
 
@@ -609,6 +611,9 @@ def main(argv=None):
                                                 "filter": [round((w["ekf_close"] - w["ekf_open"]) * 1e3 / max(w["ekf_frames"], 1), 2) for w in windows]},
                 "run_wall_ms": round(wall_run * 1e3, 1),
             }
+            if os.environ.get("MSKF_BENCH_GROUP_PHASES"):
+                host_phases["window_phases_ms_by_group"] = [{k: round(v * 1e3, 2) for k, v in run.get_window_phases_group(g).items() if v > 0} for g in range(n_groups)]
+                host_phases["windows_ms_by_group"] = [{k: round((v - min(w["fe_open"] for w in windows if w["fe_open"] > 0)) * 1e3, 1) if k.endswith(("open", "close")) else v for k, v in w.items()} for w in windows]
         else:
             host_phases = per([k for k in phases if phases[k] > 0])
         out = {

@@ -39,6 +39,13 @@ class EkfUpdateArgs(C.Structure):
                 ("diag_out", C.c_void_p), ("pos_var_out", C.c_void_p)]
 
 
+class FeFrameArgs(C.Structure):   # mskf_fe_frame_args (include/mskf_hip.h)
+    _fields_ = [("Hpred", C.c_double * 9), ("capacity", C.c_int32), ("n", C.c_int32),
+                ("id", C.c_void_p), ("lifetime", C.c_void_p), ("cam0", C.c_void_p), ("cam1", C.c_void_p), ("und0", C.c_void_p), ("und1", C.c_void_p),
+                ("before_tracking", C.c_int32), ("after_tracking", C.c_int32), ("after_matching", C.c_int32), ("after_ransac", C.c_int32),
+                ("n_candidates", C.c_int32), ("n_new", C.c_int32), ("next_feature_id", C.c_uint64)]
+
+
 EXPORTS = [
     "mskf_last_error", "mskf_abi_version", "mskf_ctx_create", "mskf_ctx_create_prio", "mskf_ctx_create_shared", "mskf_ctx_destroy", "mskf_ctx_sync", "mskf_ctx_hip_stream",
     "mskf_stream_create", "mskf_stream_destroy", "mskf_fe_push_stereo", "mskf_fe_push_stereo_device",

@@ -96,6 +96,15 @@ int mskf_ekf_stream_init(mskf_stream *s) {
         E.gate_S = q; q += n_gate;
         E.chi2 = q;
     }
+    {
+        // stacked Jacobian + row masks: the lost-feature stack is capped at max_stack_rows + one block, the pruning stack is
+        // five rows per feature the map can hold (every live grid slot); sized once so that a run does not grow it
+        const int live = s->fe.grid_row * s->fe.grid_col * std::max(s->fe.grid_max_feature_num, 1) + 64;
+        const int cap = std::min(kMaxRows, std::max(std::max(2048, s->ekf.max_stack_rows + 4 * E.max_clones + 64), 5 * live));
+        if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld + (size_t)cap, st)) != MSKF_OK) return rc;
+        E.rs = E.Hs + (size_t)cap * E.ld;
+        E.max_rows = cap;
+    }
     MSKF_HIPCHK(hipStreamSynchronize(st));
     double tab[100];
     tab[0] = 0.0;
@@ -108,7 +117,7 @@ int mskf_ekf_stream_init(mskf_stream *s) {
 void mskf_ekf_stream_free(mskf_stream *s) {
     EkfStreamState &E = s->ekf_state;
     if (E.pool) (void)hipFree(E.pool);          // P, T, S, W, P_alt, act, gate_S, chi2
-    if (E.Hs) (void)hipFree(E.Hs);              // Hs + rowmask
+    if (E.Hs) { if (E.hs_async) (void)hipFreeAsync(E.Hs, s->ctx_ekf->stream); else (void)hipFree(E.Hs); }      // Hs + rowmask
     if (E.h_arena) (void)hipHostFree(E.h_arena);
     if (E.d_arena) (void)hipFree(E.d_arena);
     if (E.h_out) (void)hipHostFree(E.h_out);
@@ -550,13 +559,18 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         any_pv |= a.pos_var_out != nullptr;
         out_bytes = align_up(L.o_status + (size_t)a.n_feat, 64);
         if (m_total > E.max_rows) {
-            MSKF_HIPCHK(hipStreamSynchronize(st));
-            if (E.Hs) (void)hipFree(E.Hs);      // (rs lives behind Hs in the same allocation)
+            // Growth of the stacked-Jacobian buffer, STREAM-ORDERED: hipFree / hipMalloc synchronise the whole device, and a
+            // group that grows a buffer in the middle of a run then waits until every other group's queue is idle (measured in
+            // the round-3 bench: the two groups that met their largest pruning update inside the timed window stood still for
+            // 0.3 s each).  The first allocation is sized for what a stream of this configuration can stack (stream init).
+            if (E.Hs) MSKF_HIPCHK(hipFreeAsync(E.Hs, st));      // (rs lives behind Hs in the same allocation)
             E.Hs = E.rs = nullptr;
             const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
-            if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld + (size_t)cap, st)) != MSKF_OK) return rc;
+            MSKF_HIPCHK(hipMallocAsync((void **)&E.Hs, ((size_t)cap * E.ld + (size_t)cap) * sizeof(double), st));
+            MSKF_HIPCHK(hipMemsetAsync(E.Hs, 0, ((size_t)cap * E.ld + (size_t)cap) * sizeof(double), st));
             E.rs = E.Hs + (size_t)cap * E.ld;
             E.max_rows = cap;
+            E.hs_async = true;
         }
         if (a.n_feat > 0) {
             if (pairs) wave = false;

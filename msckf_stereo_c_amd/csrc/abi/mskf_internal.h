@@ -40,7 +40,7 @@ struct PinnedDev {  // a pinned host array with a device twin
     int ensure(size_t n) {
         if (n <= cap) return MSKF_OK;
         release();
-        size_t c = n < 16 ? 16 : n + n / 2;
+        size_t c = n < 16 ? 16 : 2 * n;      // (growth frees and allocates: both synchronise the device, so it must stay rare)
         MSKF_HIPCHK(hipHostMalloc((void **)&h, c * sizeof(T), hipHostMallocDefault));
         MSKF_HIPCHK(hipMalloc((void **)&d, c * sizeof(T)));
         cap = c;

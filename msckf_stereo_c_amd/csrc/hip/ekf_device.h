@@ -88,6 +88,7 @@ struct EkfStreamDev {
 struct EkfStreamState {       // host-side bookkeeping of the device buffers of one stream
     int max_clones = 0, ld = 0, d = EKF_IMU_DIM;
     int max_rows = 0, max_feat = 0, max_obs = 0, nmax = 0;
+    bool hs_async = false;    // Hs came from the stream-ordered allocator (grown during a run)
     double *pool = nullptr;   // one allocation: P, T, S, W, P_alt, act, gate_S, chi2
     double *P = nullptr, *Hs = nullptr, *rs = nullptr, *T = nullptr, *S = nullptr, *W = nullptr, *gate_S = nullptr;
     int *act = nullptr;       // ld ints: active column list of the current update

@@ -497,7 +497,7 @@ MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_cal
     // MSKF_DUMMY_STREAMS = k: k HIP streams created (and left idle) before the groups' own (experiment: the first streams a
     // process creates were served measurably worse than the later ones)
     if (const char *e = std::getenv("MSKF_DUMMY_STREAMS"))
-        for (int q = 0; q < std::atoi(e); ++q) { mskf_ctx *c = nullptr; if (mskf_ctx_create(device, &c) == MSKF_OK) dummies_.push_back(c); }
+        for (int q = 0; q < std::atoi(e); ++q) { mskf_ctx *c = nullptr; if (mskf_ctx_create(device, &c) == MSKF_OK) { (void)mskf_ctx_sync(c); dummies_.push_back(c); } }   // (used once: the runtime binds a hardware queue at first use)
     int nq = 0;
     if (const char *e = std::getenv("MSKF_FE_QUEUES")) nq = std::max(0, std::atoi(e));
     if (nq >= n_groups) nq = 0;

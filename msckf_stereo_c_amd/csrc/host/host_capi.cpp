@@ -69,6 +69,10 @@ void mskfh_runner_get_window_phases(void *h, double *out) {
     for (int g = 0; g < r->n_groups(); ++g)
         for (int k = 0; k < BatchGroup::PH_COUNT; ++k) out[k] += r->group(g).window_phase_s[k];
 }
+void mskfh_runner_get_window_phases_group(void *h, int g, double *out) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int k = 0; k < BatchGroup::PH_COUNT; ++k) out[k] = r->group(g).window_phase_s[k];
+}
 // state of local stream 0 of group g when its stages closed the window; returns the feature count (-1: no window closed)
 int mskfh_runner_mark_dump_size(void *h, int g) {
     const BatchGroup::MarkDump &m = ((MultiRunner *)h)->group(g).mark_dump;

@@ -195,6 +195,13 @@ class Runner:
     FE_THREAD_PHASES = ["fe_pace_wait", "imu_feed", "push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "handoff", "fe_queue_wait"]
     EKF_THREAD_PHASES = ["ekf_queue_wait", "imu_feed_ekf", "ekf_A", "update1", "ekf_B", "update2", "ekf_C", "posvar"]
 
+    def get_window_phases_group(self, g):
+        """The same for one group."""
+        out = np.zeros(len(self.PHASES))
+        self.L.mskfh_runner_get_window_phases_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.L.mskfh_runner_get_window_phases_group(self.h, int(g), _p(out))
+        return {n: float(out[i]) for i, n in enumerate(self.PHASES)}
+
     def get_window_phases(self):
         """Wall seconds per phase inside the last timed window, summed over groups."""
         out = np.zeros(len(self.PHASES))

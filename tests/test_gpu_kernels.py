@@ -591,3 +591,47 @@ def test_compression_mode_is_validated(gpu_ctx, oracle):
     for bad in (-1, 3, 0x7fffffff):
         with pytest.raises(capi.MskfError):
             capi.Stream(gpu_ctx, calib, default_fe_cfg(), default_ekf_cfg(compression_mode=bad))
+
+
+def test_device_frame_entry_points_refuse_what_they_cannot_do(gpu_ctx, oracle):
+    """mskf_fe_frame_batch_* (whole front-end frames on the device): no grid handed over yet, output arrays too small, the
+    2-point RANSAC configuration (the RANSAC sits between the track calls, on the host) and per-cell limits above the
+    kernels' bound are refused with a status and a message, never silently."""
+    import ctypes as C
+    from msckf_stereo_c_amd.ctypes_types import COMPAT_REFERENCE, POINT2F
+    L = gpu_ctx.L
+    L.mskf_fe_grid_capacity.argtypes = [C.c_void_p]
+    L.mskf_fe_frame_batch_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(capi.FeFrameArgs)]
+    L.mskf_fe_set_grid.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
+    w, h = 376, 240
+    calib = oracle.euroc_calib(w, h)
+    img = np.zeros((h, w), np.uint8)
+
+    def frame(stream, cap):
+        ids = np.zeros(max(cap, 1), np.uint64); life = np.zeros(max(cap, 1), np.int32)
+        pts = [np.zeros(max(cap, 1), POINT2F) for _ in range(4)]
+        a = capi.FeFrameArgs()
+        a.Hpred[0] = a.Hpred[4] = a.Hpred[8] = 1.0
+        a.capacity = cap
+        a.id, a.lifetime = ids.ctypes.data, life.ctypes.data
+        a.cam0, a.cam1, a.und0, a.und1 = (p.ctypes.data for p in pts)
+        hs = (C.c_void_p * 1)(stream.h)
+        c0 = (C.c_void_p * 1)(img.ctypes.data); c1 = (C.c_void_p * 1)(img.ctypes.data)
+        return L.mskf_fe_frame_batch_begin(gpu_ctx.h, 1, hs, c0, c1, 0, (capi.FeFrameArgs * 1)(a))
+
+    s = capi.Stream(gpu_ctx, calib, default_fe_cfg(), default_ekf_cfg())
+    cap = L.mskf_fe_grid_capacity(s.h)
+    assert cap >= 4 * 5 * 4
+    assert frame(s, cap) == -1 and b"no grid on the device" in L.mskf_last_error()          # MSKF_ERR_INVALID: first frame goes the phased way
+    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None) == 0
+    assert frame(s, cap - 1) == -1                                                          # output arrays too small
+    assert L.mskf_fe_set_grid(s.h, cap + 1, None, None, None, None, None, None, 0, None) == -1
+    s.close()
+    s = capi.Stream(gpu_ctx, calib, default_fe_cfg(compat=COMPAT_REFERENCE & ~8), default_ekf_cfg())     # Q5 cleared: RANSAC on
+    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None) == 0
+    assert frame(s, L.mskf_fe_grid_capacity(s.h)) == -3 and b"RANSAC" in L.mskf_last_error()   # MSKF_ERR_UNSUPPORTED
+    s.close()
+    s = capi.Stream(gpu_ctx, calib, default_fe_cfg(grid_min=17, grid_max=20), default_ekf_cfg())
+    assert L.mskf_fe_grid_capacity(s.h) == 0
+    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None) == -3
+    s.close()
