@@ -42,6 +42,8 @@ int dev_alloc(double **p, size_t n, hipStream_t st) {
 // a pinned host arena with a device twin and an event guarding reuse of the host side
 int arena_ensure(char **h, char **d, size_t *cap, size_t need) {
     if (need <= *cap) return MSKF_OK;
+    // (single-stream entry points only — mskf_ekf_propagate / _augment —, not on the batched path: see PinnedDev::ensure for why
+    // a running pipeline must not free)
     if (*h) (void)hipHostFree(*h);
     if (*d) (void)hipFree(*d);
     *h = *d = nullptr; *cap = 0;

@@ -37,10 +37,15 @@ template <typename T>
 struct PinnedDev {  // a pinned host array with a device twin
     T *h = nullptr, *d = nullptr;
     size_t cap = 0;
+    std::vector<std::pair<T *, T *>> retired;      // outgrown buffers, freed with the owner
+    // Growth NEVER frees: hipFree / hipHostFree wait for every stream of the device, and a context that outgrew a staging
+    // buffer in the middle of a run stood still until all the other groups' queues were idle (0.3 s in the round-3 bench).
+    // The outgrown pair is retired and freed by release(); with doubling that is at most as much again as the final size.
     int ensure(size_t n) {
         if (n <= cap) return MSKF_OK;
-        release();
-        size_t c = n < 16 ? 16 : 2 * n;      // (growth frees and allocates: both synchronise the device, so it must stay rare)
+        if (h || d) retired.push_back({h, d});
+        h = d = nullptr; cap = 0;
+        size_t c = n < 16 ? 16 : 2 * n;
         MSKF_HIPCHK(hipHostMalloc((void **)&h, c * sizeof(T), hipHostMallocDefault));
         MSKF_HIPCHK(hipMalloc((void **)&d, c * sizeof(T)));
         cap = c;
@@ -49,6 +54,8 @@ struct PinnedDev {  // a pinned host array with a device twin
     void release() {
         if (h) (void)hipHostFree(h);
         if (d) (void)hipFree(d);
+        for (auto &r : retired) { if (r.first) (void)hipHostFree(r.first); if (r.second) (void)hipFree(r.second); }
+        retired.clear();
         h = d = nullptr; cap = 0;
     }
 };

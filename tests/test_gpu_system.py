@@ -565,7 +565,7 @@ def test_timed_window_inside_one_pipelined_run(oracle):
         op, gp = osys.poses(), run.poses(g)
         assert len(op) == len(gp) and np.abs(op["p"] - gp["p"]).max() < POS_TOL
     # the window holds steps x groups completed frames; the stages started about as many inside it
-    assert 3 * steps - 6 <= fe_frames <= 3 * steps + 6
+    assert 3 * steps - 9 <= fe_frames <= 3 * steps + 12
     fe_sum = sum(ph[k] for k in R.Runner.FE_THREAD_PHASES)
     fe_win = sum(run.window(g)["fe_close"] - run.window(g)["fe_open"] for g in range(3))
     ekf_sum = sum(ph[k] for k in R.Runner.EKF_THREAD_PHASES)
