@@ -88,6 +88,18 @@ mskf_ctx *mskf_stream_ctx(mskf_stream *s);
  * thread and a filter thread can drive one VIO stream concurrently (they share no device buffers). */
 int mskf_stream_set_ekf_ctx(mskf_stream *s, mskf_ctx *ekf_ctx);
 mskf_ctx *mskf_stream_ekf_ctx(mskf_stream *s);
+/* Move a stream's front-end half and / or its filter half to other contexts of the same GPU (NULL = stays where it is) WITHOUT
+ * synchronising anything: for a scheduler that hands whole batches of streams to whichever worker (context + host thread) is
+ * free.  The caller guarantees that the half being moved has no work in flight that the new context's queue is not ordered
+ * behind: it has waited for the half's last batch (every *_end call does), or it chains the queues with
+ * mskf_ctx_record_point / mskf_ctx_wait_point. */
+int mskf_stream_rebind(mskf_stream *s, mskf_ctx *fe_ctx, mskf_ctx *ekf_ctx);
+/* Device-side ordering between two contexts' queues: record a point in `ctx`'s stream (the handle is created on first use
+ * and reused), make another context's stream wait for it.  No host wait on either side. */
+typedef struct mskf_point mskf_point;
+int mskf_ctx_record_point(mskf_ctx *ctx, mskf_point **point);
+int mskf_ctx_wait_point(mskf_ctx *ctx, mskf_point *point);
+void mskf_point_destroy(mskf_point *point);
 
 /* ------------------------------------------------------------------ front-end
  * Replaces, inside cg::ImageProcessor::stereoCallback (image_processor.cpp:139-203):

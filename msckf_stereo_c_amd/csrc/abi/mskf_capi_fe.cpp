@@ -291,6 +291,7 @@ extern "C" int mskf_stream_create(mskf_ctx *ctx, const mskf_calib *calib, const 
     mskf_stream *s = new mskf_stream();
     s->ctx = ctx;
     s->ctx_ekf = ctx;
+    s->home_ctx = ctx;
     s->calib = *calib; s->fe = *fe; s->ekf = *ekf;
     s->w = calib->width; s->h = calib->height;
     size_t off = 0;
@@ -353,6 +354,34 @@ extern "C" int mskf_stream_set_ekf_ctx(mskf_stream *s, mskf_ctx *c) {
     return MSKF_OK;
 }
 
+extern "C" int mskf_stream_rebind(mskf_stream *s, mskf_ctx *fe_ctx, mskf_ctx *ekf_ctx) {
+    if (!s) return MSKF_ERR_INVALID;
+    if ((fe_ctx && fe_ctx->device != s->home_ctx->device) || (ekf_ctx && ekf_ctx->device != s->home_ctx->device)) return MSKF_ERR_INVALID;
+    if (fe_ctx) s->ctx = fe_ctx;
+    if (ekf_ctx) s->ctx_ekf = ekf_ctx;
+    return MSKF_OK;
+}
+
+struct mskf_point { hipEvent_t ev = nullptr; };
+extern "C" int mskf_ctx_record_point(mskf_ctx *ctx, mskf_point **point) {
+    if (!ctx || !point) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    if (!*point) { *point = new mskf_point(); MSKF_HIPCHK(hipEventCreateWithFlags(&(*point)->ev, hipEventDisableTiming)); }
+    MSKF_HIPCHK(hipEventRecord((*point)->ev, ctx->stream));
+    return MSKF_OK;
+}
+extern "C" int mskf_ctx_wait_point(mskf_ctx *ctx, mskf_point *point) {
+    if (!ctx || !point || !point->ev) return MSKF_ERR_INVALID;
+    MSKF_HIPCHK(hipSetDevice(ctx->device));
+    MSKF_HIPCHK(hipStreamWaitEvent(ctx->stream, point->ev, 0));
+    return MSKF_OK;
+}
+extern "C" void mskf_point_destroy(mskf_point *point) {
+    if (!point) return;
+    if (point->ev) (void)hipEventDestroy(point->ev);
+    delete point;
+}
+
 extern "C" void mskf_stream_destroy(mskf_stream *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
@@ -361,7 +390,7 @@ extern "C" void mskf_stream_destroy(mskf_stream *s) {
     for (int i = 0; i < 3; ++i) if (s->pyr[i]) (void)hipFree(s->pyr[i]);
     if (s->book.mem) (void)hipFree(s->book.mem);
     mskf_ekf_stream_free(s);
-    auto &v = s->ctx->streams;
+    auto &v = s->home_ctx->streams;
     for (size_t i = 0; i < v.size(); ++i) if (v[i] == s) { v.erase(v.begin() + i); break; }
     delete s;
 }

@@ -124,6 +124,7 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record);
 struct mskf_stream {
     mskf_ctx *ctx = nullptr;
     mskf_ctx *ctx_ekf = nullptr;      // context the mskf_ekf_* calls run on (== ctx unless re-attached)
+    mskf_ctx *home_ctx = nullptr;     // the context the stream was created on (its bookkeeping list); ctx / ctx_ekf may move (mskf_stream_rebind)
     mskf_calib calib;
     mskf_fe_cfg fe;
     mskf_ekf_cfg ekf;

@@ -71,6 +71,7 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
         if (rc == MSKF_OK) rc = mskf_ctx_create_shared(half_[0].ctx_ekf, &half_[h].ctx_ekf);
     }
     if (rc != MSKF_OK) { error_ = mskf_last_error(); return; }
+    home_fe_ = half_[0].ctx; home_ekf_ = half_[0].ctx_ekf;
     for (int h = 0; h < nh; ++h) { half_[h].i0 = (int)((long long)n * h / nh); half_[h].n = (int)((long long)n * (h + 1) / nh) - half_[h].i0; }
     for (int i = 0; i < n; ++i) {
         const Half &H = half_[nh == 2 && i >= half_[1].i0 ? 1 : 0];
@@ -88,6 +89,8 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
 }
 
 BatchGroup::~BatchGroup() {
+    rebind_home();
+    if (ekf_tail_) mskf_point_destroy(ekf_tail_);
     systems_.clear();
     for (size_t h = half_.size(); h-- > 0;) {      // shared contexts first: they borrow half 0's streams
         if (half_[h].ctx_ekf) mskf_ctx_destroy(half_[h].ctx_ekf);
@@ -112,7 +115,8 @@ int BatchGroup::step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, 
     const int n = size();
     if (!ok_ || n == 0) return MSKF_ERR_INVALID;
     auto tp = std::chrono::steady_clock::now();
-    auto lap = [&](int ph) { auto t2 = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t2 - tp).count(); tp = t2; };
+    double *acc = acc_fe_ ? acc_fe_ : phase_s;
+    auto lap = [&](int ph) { auto t2 = std::chrono::steady_clock::now(); acc[ph] += std::chrono::duration<double>(t2 - tp).count(); tp = t2; };
     auto parh = [&](const Half &H, const std::function<void(int)> &fn) {
         if (pool_) pool_->run(H.n, [&](int k) { fn(H.i0 + k); }); else for (int i = H.i0; i < H.i0 + H.n; ++i) fn(i);
     };
@@ -181,7 +185,8 @@ int BatchGroup::step_fe(const uint8_t *const *cam0, const uint8_t *const *cam1, 
 int BatchGroup::step_ekf(const FrameBatch *fb) {
     const int n = size();
     auto tp = std::chrono::steady_clock::now();
-    auto lap = [&](int ph) { auto t2 = std::chrono::steady_clock::now(); phase_s[ph] += std::chrono::duration<double>(t2 - tp).count(); tp = t2; };
+    double *acc = acc_ekf_ ? acc_ekf_ : phase_s;
+    auto lap = [&](int ph) { auto t2 = std::chrono::steady_clock::now(); acc[ph] += std::chrono::duration<double>(t2 - tp).count(); tp = t2; };
     auto parh = [&](const Half &H, const std::function<void(int)> &fn) {
         if (pool_ekf_) pool_ekf_->run(H.n, [&](int k) { fn(H.i0 + k); }); else for (int i = H.i0; i < H.i0 + H.n; ++i) fn(i);
     };
@@ -331,6 +336,86 @@ int BatchGroup::run(int first, int n_frames) {
     return MSKF_OK;
 }
 
+// hand-off = a snapshot of every stream's message (live + stale entries + the first tail record); `fb` is recycled when given
+void BatchGroup::fill_handoff(int k, std::unique_ptr<FrameBatch> &fb) {
+    const int n = size();
+    if (!fb) fb.reset(new FrameBatch);
+    fb->frame = k;
+    fb->msg.resize(n); fb->tail_start.resize(n); fb->total.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const ImageProcessor &ip = *systems_[i]->imgproc_ptr_;
+        const CameraMeasurement &live = *ip.feature_msg_ptr_;
+        const size_t total = ip.messageSize(), start = ip.zeroTailStart();
+        const size_t keep = std::min(live.features.size(), start + 1);
+        if (!fb->msg[i] || fb->msg[i].use_count() > 1) fb->msg[i].reset(new CameraMeasurement);
+        fb->msg[i]->time_stamp = live.time_stamp;
+        fb->msg[i]->features.assign(live.features.begin(), live.features.begin() + keep);
+        fb->tail_start[i] = start; fb->total[i] = total;
+    }
+}
+
+void BatchGroup::snapshot_fe_mark() {
+    std::vector<ImageProcessor::FeatureIDType> ids;
+    systems_[0]->imgproc_ptr_->dumpCurrent(ids, mark_dump.life, mark_dump.c0, mark_dump.c1);
+    mark_dump.ids.assign(ids.begin(), ids.end());
+    mark_dump.fe_valid = true;
+}
+
+void BatchGroup::snapshot_ekf_mark() {
+    const IMUState &st = systems_[0]->msckfvio_ptr()->imuState();
+    int k = 0;
+    for (int i = 0; i < 4; ++i) mark_dump.imu[k++] = st.orientation.q[i];
+    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.position[i];
+    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.velocity[i];
+    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.gyro_bias[i];
+    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.acc_bias[i];
+    for (int i = 0; i < 9; ++i) mark_dump.imu[k++] = st.R_imu_cam0.m[i];
+    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.t_cam0_imu[i];
+    mark_dump.ekf_valid = true;
+}
+
+void BatchGroup::rebind_home() {
+    if (!home_fe_ || !home_ekf_) return;
+    half_[0].ctx = home_fe_; half_[0].ctx_ekf = home_ekf_;
+    for (mskf_stream *s : streams_) mskf_stream_rebind(s, home_fe_, home_ekf_);
+    acc_fe_ = acc_ekf_ = nullptr;
+}
+
+// front-end stage of frame k on a borrowed context (the caller has made sure nothing of this batch's front-end is in flight)
+int BatchGroup::fe_stage(mskf_ctx *ctx, int k, double *acc, std::unique_ptr<FrameBatch> &out) {
+    if (half_.size() != 1) { error_ = "the balanced runner needs one batch per stage (MSKF_HALVES=1)"; return MSKF_ERR_UNSUPPORTED; }
+    if (half_[0].ctx != ctx) { half_[0].ctx = ctx; for (mskf_stream *s : streams_) mskf_stream_rebind(s, ctx, nullptr); }
+    acc_fe_ = acc;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = feed_imu(k, true, false);
+    const auto t1 = std::chrono::steady_clock::now();
+    acc[PH_IMU] += std::chrono::duration<double>(t1 - t0).count();
+    if (rc == MSKF_OK) rc = step_fe(p0_.data(), p1_.data(), seq[0].on_device, t_.data(), false);
+    if (rc != MSKF_OK) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+    fill_handoff(k, out);
+    acc[PH_HANDOFF] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+    return MSKF_OK;
+}
+
+// filter stage of a handed-off frame on a borrowed context.  The stage ends with work it does not wait for (clone removal):
+// when the next frame of this batch runs on another context, that context's queue is ordered behind it.
+int BatchGroup::ekf_stage(mskf_ctx *ctx, FrameBatch *fb, double *acc) {
+    if (half_.size() != 1) { error_ = "the balanced runner needs one batch per stage (MSKF_HALVES=1)"; return MSKF_ERR_UNSUPPORTED; }
+    if (half_[0].ctx_ekf != ctx) { half_[0].ctx_ekf = ctx; for (mskf_stream *s : streams_) mskf_stream_rebind(s, nullptr, ctx); }
+    if (ekf_tail_ && ekf_tail_ctx_ && ekf_tail_ctx_ != ctx) { const int wrc = mskf_ctx_wait_point(ctx, ekf_tail_); if (wrc != MSKF_OK) { error_ = mskf_last_error(); return wrc; } }
+    acc_ekf_ = acc;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = feed_imu(fb->frame, false, true);
+    acc[PH_IMU_EKF] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == MSKF_OK) rc = step_ekf(fb);
+    if (rc != MSKF_OK) return rc;
+    rc = mskf_ctx_record_point(ctx, &ekf_tail_);
+    ekf_tail_ctx_ = ctx;
+    if (rc != MSKF_OK) error_ = mskf_last_error();
+    return rc;
+}
+
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void BatchGroup::set_gates(bool on) {
@@ -338,7 +423,6 @@ void BatchGroup::set_gates(bool on) {
 }
 
 int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *pacer, int pacer_slot) {
-    const int n = size();
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<FrameBatch>> queue;
@@ -395,18 +479,7 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
                 if (c == sh->target_close) { sh->t_close = now_s(); sh->phase.store(2, std::memory_order_release); }
             }
             if (win && fb->frame == win->mark_end - 1) {
-                if (rc == MSKF_OK) {
-                    const IMUState &st = systems_[0]->msckfvio_ptr()->imuState();
-                    int k = 0;
-                    for (int i = 0; i < 4; ++i) mark_dump.imu[k++] = st.orientation.q[i];
-                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.position[i];
-                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.velocity[i];
-                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.gyro_bias[i];
-                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.acc_bias[i];
-                    for (int i = 0; i < 9; ++i) mark_dump.imu[k++] = st.R_imu_cam0.m[i];
-                    for (int i = 0; i < 3; ++i) mark_dump.imu[k++] = st.t_cam0_imu[i];
-                    mark_dump.ekf_valid = true;
-                }
+                if (rc == MSKF_OK) snapshot_ekf_mark();
             }
             { std::lock_guard<std::mutex> lk(mu); pool.push_back(std::move(fb)); }
         }
@@ -446,19 +519,7 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
             std::lock_guard<std::mutex> lk(mu);
             if (!pool.empty()) { fb = std::move(pool.back()); pool.pop_back(); }
         }
-        if (!fb) fb.reset(new FrameBatch);
-        fb->frame = k;
-        fb->msg.resize(n); fb->tail_start.resize(n); fb->total.resize(n);
-        for (int i = 0; i < n; ++i) {
-            const ImageProcessor &ip = *systems_[i]->imgproc_ptr_;
-            const CameraMeasurement &live = *ip.feature_msg_ptr_;
-            const size_t total = ip.messageSize(), start = ip.zeroTailStart();
-            const size_t keep = std::min(live.features.size(), start + 1);
-            if (!fb->msg[i] || fb->msg[i].use_count() > 1) fb->msg[i].reset(new CameraMeasurement);
-            fb->msg[i]->time_stamp = live.time_stamp;
-            fb->msg[i]->features.assign(live.features.begin(), live.features.begin() + keep);
-            fb->tail_start[i] = start; fb->total[i] = total;
-        }
+        fill_handoff(k, fb);
         const double tw = now_s();
         phase_s[PH_HANDOFF] += tw - th;
         {
@@ -470,10 +531,7 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
         phase_s[PH_FE_QWAIT] += now_s() - tw;
         if (pacer) pacer->done[pacer_slot].store(k + 1 >= first + n_frames ? 0x7fffffff : k + 1 - first, std::memory_order_relaxed);
         if (win && k == win->mark_end - 1) {
-            std::vector<ImageProcessor::FeatureIDType> ids;
-            systems_[0]->imgproc_ptr_->dumpCurrent(ids, mark_dump.life, mark_dump.c0, mark_dump.c1);
-            mark_dump.ids.assign(ids.begin(), ids.end());
-            mark_dump.fe_valid = true;
+            snapshot_fe_mark();
         }
     }
     if (win && fe_mine == 1) { win->t_fe_end = now_s(); gate(true, false); fe_mine = 2; }
@@ -572,6 +630,7 @@ int MultiRunner::pace_slack() {
 }
 
 int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s) {
+    if (n_groups_ > 1 && balance_enabled() && groups_[0]->n_halves() == 1) return run_balanced(first, warmup, steps, max_extra, elapsed_s);
     std::vector<int> rcs(n_groups_, MSKF_OK);
     TimedShared shared;
     shared.target_open = (long)n_groups_ * warmup;
@@ -603,6 +662,174 @@ int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, doub
     }
     for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
     if (shared.phase.load() != 2) return MSKF_ERR_INVALID;        // the window never closed
+    if (elapsed_s) *elapsed_s = shared.t_close - shared.t_open;
+    return MSKF_OK;
+}
+
+bool MultiRunner::balance_enabled() {
+    static const bool v = [] { const char *e = std::getenv("MSKF_BALANCE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s) {
+    const int nb = n_groups_;
+    TimedShared shared;
+    shared.target_open = (long)nb * warmup;
+    shared.target_close = (long)nb * (warmup + steps);
+    if (warmup <= 0) { shared.t_open = now_s(); shared.phase.store(1); }
+    // per batch: frames [from, from + cnt) are its own, then it keeps going while the window is open (at most max_extra)
+    struct Batch { int from = 0, cnt = 0, fe_next = 0, mark_end = 0; bool fe_busy = false, ekf_busy = false, fe_done = false; };
+    std::vector<Batch> B(nb);
+    for (int g = 0; g < nb; ++g) {
+        B[g].from = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
+        B[g].cnt = first + off_[g] + warmup + steps - B[g].from;
+        B[g].fe_next = B[g].from;
+        B[g].mark_end = first + off_[g] + warmup + steps;
+        win_[g] = TimedWindow();
+        win_[g].shared = &shared;
+        groups_[g]->set_gates(false);
+        groups_[g]->mark_dump.fe_valid = groups_[g]->mark_dump.ekf_valid = false;
+        groups_[g]->handoff.clear();
+        for (int k = 0; k < BatchGroup::PH_COUNT; ++k) groups_[g]->window_phase_s[k] = 0;
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> err{MSKF_OK};
+    // a worker's accounting follows the shared window at its frame boundaries (as a stage does in run_pipelined); the phase
+    // times of worker w are kept in group w's arrays whichever batches it ran
+    static const int fe_phases[] = {BatchGroup::PH_PUSH, BatchGroup::PH_PREP1, BatchGroup::PH_TRACK1, BatchGroup::PH_AFTER1, BatchGroup::PH_TRACK2,
+                                    BatchGroup::PH_AFTER2, BatchGroup::PH_IMU, BatchGroup::PH_HANDOFF, BatchGroup::PH_FE_QWAIT, BatchGroup::PH_FE_PACE};
+    static const int ekf_phases[] = {BatchGroup::PH_EKF_A, BatchGroup::PH_UPD1, BatchGroup::PH_EKF_B, BatchGroup::PH_UPD2, BatchGroup::PH_EKF_C,
+                                     BatchGroup::PH_POSVAR, BatchGroup::PH_EKF_QWAIT, BatchGroup::PH_IMU_EKF};
+    std::vector<mskf_ctx *> fe_ctx(nb), ekf_ctx(nb);      // worker w = the two contexts group w created (captured before any batch moves)
+    for (int w = 0; w < nb; ++w) { fe_ctx[w] = groups_[w]->ctx(); ekf_ctx[w] = groups_[w]->ekf_ctx(); }
+    auto gate = [&](int w, bool fe, bool on) {
+        BatchGroup &G = *groups_[w];
+        mskf_ctx_timing_gate(fe ? fe_ctx[w] : ekf_ctx[w], on ? 1 : 0);
+        hostprof::enabled() = on;
+        const int *ph = fe ? fe_phases : ekf_phases;
+        const int cnt = fe ? (int)(sizeof(fe_phases) / sizeof(int)) : (int)(sizeof(ekf_phases) / sizeof(int));
+        for (int k = 0; k < cnt; ++k) G.window_phase_s[ph[k]] = on ? -G.phase_s[ph[k]] : G.window_phase_s[ph[k]] + G.phase_s[ph[k]];
+    };
+    auto follow = [&](int w, bool fe, int &mine, double &t_begin, double &t_end) {
+        const int ph = shared.phase.load(std::memory_order_acquire);
+        if (mine == 0 && ph >= 1) { t_begin = now_s(); gate(w, fe, true); mine = 1; }
+        if (mine == 1 && ph == 2) { t_end = now_s(); gate(w, fe, false); mine = 2; }
+    };
+    std::vector<std::thread> th;
+    // ---- front-end workers: the batch that is furthest behind, not being worked on, with room in its hand-off queue
+    for (int w = 0; w < nb; ++w) th.emplace_back([&, w]() {
+        hostprof::enabled() = false;
+        int mine = 0;
+        double *acc = groups_[w]->phase_s;
+        TimedWindow &W = win_[w];
+        for (;;) {
+            int b = -1;
+            {
+                const double tq = now_s();
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (err.load() != MSKF_OK) return;
+                    b = -1;
+                    bool all_done = true;
+                    for (int g = 0; g < nb; ++g) {
+                        Batch &X = B[g];
+                        if (X.fe_done) continue;
+                        const bool own = X.fe_next < X.from + X.cnt;
+                        if (!own && (shared.phase.load() == 2 || X.fe_next >= X.from + X.cnt + max_extra)) { X.fe_done = true; cv.notify_all(); continue; }
+                        all_done = false;
+                        if (X.fe_busy || groups_[g]->handoff.size() >= 2) continue;
+                        if (b < 0 || X.fe_next - X.from < B[b].fe_next - B[b].from) b = g;
+                    }
+                    if (b >= 0 || all_done) break;
+                    cv.wait(lk);
+                }
+                if (b < 0) break;
+                B[b].fe_busy = true;
+                acc[BatchGroup::PH_FE_QWAIT] += now_s() - tq;
+            }
+            follow(w, true, mine, W.t_fe_begin, W.t_fe_end);
+            if (mine == 1) ++W.fe_frames;
+            const int k = B[b].fe_next;
+            std::unique_ptr<FrameBatch> fb;
+            { std::lock_guard<std::mutex> lk(mu); auto &pool = groups_[b]->handoff_pool; if (!pool.empty()) { fb = std::move(pool.back()); pool.pop_back(); } }
+            const int rc = groups_[b]->fe_stage(fe_ctx[w], k, acc, fb);
+            if (rc == MSKF_OK && k == B[b].mark_end - 1) groups_[b]->snapshot_fe_mark();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != MSKF_OK) err.store(rc);
+                else { groups_[b]->handoff.push_back(std::move(fb)); ++B[b].fe_next; }
+                B[b].fe_busy = false;
+            }
+            cv.notify_all();
+            if (rc != MSKF_OK) return;
+        }
+        if (mine == 1) { W.t_fe_end = now_s(); gate(w, true, false); }
+    });
+    // ---- filter workers: the oldest handed-off frame of a batch whose filter is not being worked on
+    for (int w = 0; w < nb; ++w) th.emplace_back([&, w]() {
+        hostprof::enabled() = false;
+        int mine = 0;
+        double *acc = groups_[w]->phase_s;
+        TimedWindow &W = win_[w];
+        for (;;) {
+            int b = -1;
+            std::unique_ptr<FrameBatch> fb;
+            {
+                const double tq = now_s();
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (err.load() != MSKF_OK) return;
+                    b = -1;
+                    bool pending = false;
+                    for (int g = 0; g < nb; ++g) {
+                        if (!B[g].fe_done || !groups_[g]->handoff.empty() || B[g].ekf_busy) pending = true;
+                        if (B[g].ekf_busy || groups_[g]->handoff.empty()) continue;
+                        if (b < 0 || groups_[g]->handoff.front()->frame - B[g].from < groups_[b]->handoff.front()->frame - B[b].from) b = g;
+                    }
+                    if (b >= 0 || !pending) break;
+                    cv.wait(lk);
+                }
+                if (b < 0) break;
+                B[b].ekf_busy = true;
+                fb = std::move(groups_[b]->handoff.front());
+                groups_[b]->handoff.pop_front();
+                acc[BatchGroup::PH_EKF_QWAIT] += now_s() - tq;
+            }
+            cv.notify_all();
+            follow(w, false, mine, W.t_ekf_begin, W.t_ekf_end);
+            if (mine == 1) ++W.ekf_frames;
+            const int frame = fb->frame;
+            const int rc = groups_[b]->ekf_stage(ekf_ctx[w], fb.get(), acc);
+            if (rc == MSKF_OK) {
+                const long c = shared.completed.fetch_add(1) + 1;
+                if (c == shared.target_open) { shared.t_open = now_s(); shared.phase.store(1, std::memory_order_release); }
+                if (c == shared.target_close) { shared.t_close = now_s(); shared.phase.store(2, std::memory_order_release); }
+                if (frame == B[b].mark_end - 1) groups_[b]->snapshot_ekf_mark();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != MSKF_OK) err.store(rc);
+                groups_[b]->handoff_pool.push_back(std::move(fb));
+                B[b].ekf_busy = false;
+                win_[b].frames_done = frame + 1 - B[b].from;
+            }
+            cv.notify_all();
+            if (rc != MSKF_OK) return;
+        }
+        if (mine == 1) { W.t_ekf_end = now_s(); gate(w, false, false); }
+    });
+    for (auto &t : th) t.join();
+    hostprof::enabled() = true;
+    // every worker's queue is drained (the last clone removals are not waited for by their stage), then the batches go home
+    for (int w = 0; w < nb; ++w) { mskf_ctx_sync(fe_ctx[w]); mskf_ctx_sync(ekf_ctx[w]); }
+    for (int g = 0; g < nb; ++g) {
+        groups_[g]->rebind_home();
+        groups_[g]->set_gates(true);
+        next_[g] = B[g].from + win_[g].frames_done;
+    }
+    if (err.load() != MSKF_OK) return err.load();
+    if (shared.phase.load() != 2) return MSKF_ERR_INVALID;
     if (elapsed_s) *elapsed_s = shared.t_close - shared.t_open;
     return MSKF_OK;
 }

@@ -6,6 +6,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -106,6 +107,18 @@ class BatchGroup {
     // same frames as a two-stage pipeline: a front-end thread (context ctx()) and a filter thread (context
     // ekf_ctx()); the front-end never reads filter state, so the results are identical to run()
     int run_pipelined(int first, int n, TimedWindow *win = nullptr, Pacer *pacer = nullptr, int pacer_slot = 0);
+    // ---- the two stages of a frame as separate calls on BORROWED contexts, for the balanced runner (MultiRunner::run_balanced):
+    // a batch (this object's streams and host state) is handed to whichever worker (a context + a host thread) is free.
+    // fe_stage: IMU feed + front-end of frame k + the hand-off snapshot; ekf_stage: IMU feed + filter of a snapshot.  `acc`
+    // receives the phase times (the worker's accounting, PH_*).  A stage of a batch is run by one worker at a time.
+    int fe_stage(mskf_ctx *ctx, int k, double *acc, std::unique_ptr<FrameBatch> &out);
+    int ekf_stage(mskf_ctx *ctx, FrameBatch *fb, double *acc);
+    void rebind_home();                       // streams back on the group's own contexts (after a balanced run)
+    void fill_handoff(int k, std::unique_ptr<FrameBatch> &fb);
+    void snapshot_fe_mark();                  // mark_dump: front-end half / filter half of local stream 0
+    void snapshot_ekf_mark();
+    std::deque<std::unique_ptr<FrameBatch>> handoff;          // balanced runner: frames through the front-end, waiting for the filter
+    std::vector<std::unique_ptr<FrameBatch>> handoff_pool;
     // device contexts: the streams of a group are driven as up to two half-batches, each with its own staging
     // context; the halves of a stage share one HIP stream (mskf_ctx_create_shared), so a group still uses two queues
     int n_halves() const { return (int)half_.size(); }
@@ -142,6 +155,10 @@ class BatchGroup {
         bool any = false, upd_pending = false, pv_pending = false;
     };
     std::vector<Half> half_;
+    mskf_ctx *home_fe_ = nullptr, *home_ekf_ = nullptr;       // the contexts this group created (half_[0] may point at borrowed ones)
+    double *acc_fe_ = nullptr, *acc_ekf_ = nullptr;           // where step_fe / step_ekf account their phases (default: phase_s)
+    mskf_point *ekf_tail_ = nullptr;                          // the filter stage's last enqueued work (clone removal is not waited for)
+    mskf_ctx *ekf_tail_ctx_ = nullptr;
     bool ok_ = false;
     std::string error_;
     std::vector<std::unique_ptr<System>> systems_;
@@ -173,6 +190,14 @@ class MultiRunner {
     // ONE pipelined run of every group (no fill / drain at the warm-up / timed boundary): *elapsed_s = the time in which the
     // groups together completed frames n_groups x warmup + 1 ... n_groups x (warmup + steps) of the run (TimedShared).
     int run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s);
+    // The same measurement with the batches NOT tied to queues: every group contributes a front-end worker and a filter worker
+    // (its two contexts and two threads), and a worker takes, frame by frame, the batch that is furthest behind and ready for its
+    // stage.  The hardware queues of a device are not served evenly, and which ones fall behind changes from run to run (measured:
+    // 78 k to 99 k stereo frames/s for the same code with fixed batch-to-queue binding, some groups at 10 ms per frame and others
+    // at 26); a slow queue then simply takes fewer batches, all streams advance at the same pace, and the device stays loaded.
+    // Results are identical (a stream's arithmetic does not depend on the queue it runs on).  MSKF_BALANCE=0 selects the fixed binding.
+    int run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s);
+    static bool balance_enabled();
     int frames_done(int g) const { return next_[g]; }          // next frame index of group g (absolute)
     static int pace_slack();                                   // MSKF_PACE = slack in frames (default 0: groups are not paced)
     const TimedWindow &window(int g) const { return win_[g]; }
