@@ -632,6 +632,8 @@ def main(argv=None):
                        "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "filter_host_threads_per_group": int(os.environ.get("MSKF_EKF_HOST_THREADS", args.host_threads)),
+                       "scheduler": ("balanced: a group's queues and threads take, frame by frame, the batch of streams that is furthest behind"
+                                     if (pipe and n_groups > 1 and os.environ.get("MSKF_BALANCE", "1")[0] != "0") else "fixed: every batch of streams on its own group's queues"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "id_mismatch": id_mismatch,
             "roofline": roof, "mfma": mfma, "kernels": kernels,

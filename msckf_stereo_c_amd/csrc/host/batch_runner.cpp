@@ -601,6 +601,7 @@ int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
         for (int g = 0; g < n_groups_; ++g) { rcs[g] = one(g); if (rcs[g] != MSKF_OK) return rcs[g]; }
         return MSKF_OK;
     }
+    if (pipelined && balance_enabled() && groups_[0]->n_halves() == 1 && pace_slack() == 0) return run_balanced(first, 0, n, 0, nullptr, true);
     // pipelined groups are paced against each other (MSKF_PACE = slack in frames, 0 = off); catch-up runs of staggered
     // groups have different lengths and are not
     std::unique_ptr<Pacer> pacer;
@@ -671,12 +672,17 @@ bool MultiRunner::balance_enabled() {
     return v;
 }
 
-int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s) {
+int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s, bool plain) {
     const int nb = n_groups_;
     TimedShared shared;
     shared.target_open = (long)nb * warmup;
     shared.target_close = (long)nb * (warmup + steps);
-    if (warmup <= 0) { shared.t_open = now_s(); shared.phase.store(1); }
+    if (plain) {     // an ordinary run: every batch does exactly its own frames (catch-up of staggered groups included), accounting on throughout
+        shared.target_open = 0; shared.target_close = 0; max_extra = 0;
+        for (int g = 0; g < nb; ++g) { const int from = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first; shared.target_close += first + off_[g] + warmup + steps - from; }
+        if (shared.target_close <= 0) return MSKF_OK;
+    }
+    if (shared.target_open <= 0) { shared.t_open = now_s(); shared.phase.store(1); }
     // per batch: frames [from, from + cnt) are its own, then it keeps going while the window is open (at most max_extra)
     struct Batch { int from = 0, cnt = 0, fe_next = 0, mark_end = 0; bool fe_busy = false, ekf_busy = false, fe_done = false; };
     std::vector<Batch> B(nb);
@@ -744,9 +750,9 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
                     if (b >= 0 || all_done) break;
                     cv.wait(lk);
                 }
+                acc[BatchGroup::PH_FE_QWAIT] += now_s() - tq;
                 if (b < 0) break;
                 B[b].fe_busy = true;
-                acc[BatchGroup::PH_FE_QWAIT] += now_s() - tq;
             }
             follow(w, true, mine, W.t_fe_begin, W.t_fe_end);
             if (mine == 1) ++W.fe_frames;
@@ -790,11 +796,11 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
                     if (b >= 0 || !pending) break;
                     cv.wait(lk);
                 }
+                acc[BatchGroup::PH_EKF_QWAIT] += now_s() - tq;
                 if (b < 0) break;
                 B[b].ekf_busy = true;
                 fb = std::move(groups_[b]->handoff.front());
                 groups_[b]->handoff.pop_front();
-                acc[BatchGroup::PH_EKF_QWAIT] += now_s() - tq;
             }
             cv.notify_all();
             follow(w, false, mine, W.t_ekf_begin, W.t_ekf_end);

@@ -196,7 +196,7 @@ class MultiRunner {
     // 78 k to 99 k stereo frames/s for the same code with fixed batch-to-queue binding, some groups at 10 ms per frame and others
     // at 26); a slow queue then simply takes fewer batches, all streams advance at the same pace, and the device stays loaded.
     // Results are identical (a stream's arithmetic does not depend on the queue it runs on).  MSKF_BALANCE=0 selects the fixed binding.
-    int run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s);
+    int run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s, bool plain = false);
     static bool balance_enabled();
     int frames_done(int g) const { return next_[g]; }          // next frame index of group g (absolute)
     static int pace_slack();                                   // MSKF_PACE = slack in frames (default 0: groups are not paced)

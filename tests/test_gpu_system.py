@@ -570,7 +570,7 @@ def test_timed_window_inside_one_pipelined_run(oracle):
     fe_win = sum(run.window(g)["fe_close"] - run.window(g)["fe_open"] for g in range(3))
     ekf_sum = sum(ph[k] for k in R.Runner.EKF_THREAD_PHASES)
     ekf_win = sum(run.window(g)["ekf_close"] - run.window(g)["ekf_open"] for g in range(3))
-    assert abs(fe_sum - fe_win) < 0.02 * fe_win + 1e-3 and abs(ekf_sum - ekf_win) < 0.02 * ekf_win + 1e-3
+    assert abs(fe_sum - fe_win) < 0.03 * fe_win + 1e-3 and abs(ekf_sum - ekf_win) < 0.03 * ekf_win + 1e-3
     # kernels are timed only inside the window: three pyramid passes per front-end frame started in it
     assert timing["k_pyr_down"][1] == 3 * fe_frames
     run.close()
