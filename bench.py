@@ -52,11 +52,11 @@ PMC_MFMA_FILE = _profile("pmc_mfma_c2")
 CONFIGS = {
     "c2": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=1536, groups=8, loop=60, cpu_frames=150, cpu_all_frames=80,
                name="configs[1] Single MI355X: 752x480 stereo, 30 cam clones, 400 features/frame, 200 Hz IMU"),
-    "c3": dict(width=1280, height=720, clones=50, grid="10x20x4x5", streams=128, groups=4, loop=60, cpu_frames=60, cpu_all_frames=30,
+    "c3": dict(width=1280, height=720, clones=50, grid="10x20x4x5", streams=768, groups=8, loop=60, cpu_frames=60, cpu_all_frames=30,
                name="configs[2] Single MI355X stress: 1280x720 stereo, 50 cam clones, 1000 features/frame"),
     "c4": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=8, groups=1, loop=100, cpu_frames=150, cpu_all_frames=80,
                name="configs[3] 8xMI355X: 64 EuRoC-shaped streams sharded 8/GPU"),
-    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=8, groups=2, loop=30, cpu_frames=40, cpu_all_frames=6,
+    "c5": dict(width=3840, height=2160, clones=60, grid="20x25x4x5", streams=64, groups=4, loop=30, cpu_frames=40, cpu_all_frames=6,
                name="configs[4] 4K stereo streams, 2000 features/frame, 60 cam clones"),
 }
 
@@ -381,9 +381,10 @@ def main(argv=None):
         os.environ["MSKF_WAIT"] = "block"
     # The front-end of a group is one device call per frame, its thread mostly waits; the filter stage still has per-stream
     # host work between its device calls (observation tables, update descriptors): it gets a helper thread when the
-    # cores are there (measured: 86.7 k -> 90.0 k stereo frames/s on the pool's 16-core share)
+    # cores are there (measured: 86.7 k -> 90.0 k stereo frames/s on the pool's 16-core share; round 3, with the device
+    # the limit: two helpers shorten the host phases by a third and the device waits grow by as much, 99 k vs 103 k)
     if "MSKF_EKF_HOST_THREADS" not in os.environ and args.host_threads == 1 and 2 * args.groups * local_world <= host_cores_available():
-        os.environ["MSKF_EKF_HOST_THREADS"] = "2"
+        os.environ["MSKF_EKF_HOST_THREADS"] = "3" if local_world == 1 and host_cores_available() >= 16 else "2"
     import numpy as np
     import torch
     import torch.distributed as dist

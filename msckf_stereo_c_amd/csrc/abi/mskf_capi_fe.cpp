@@ -1,4 +1,6 @@
 // mskf_capi_fe.cpp — C-ABI: contexts, streams and the front-end entry points (include/mskf_hip.h).
+#include <sys/prctl.h>
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +29,17 @@ extern "C" int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **ou
     mskf_ctx *c = new mskf_ctx();
     c->device = device;
     hipError_t e;
+    // Experiment switch MSKF_CU_SPLIT=n: the urgent (filter) contexts get a stream restricted to the first n compute units of
+    // the device's mask order and the others the rest, so that the filter's short serial kernels never share a SIMD with
+    // the front-end's wide ones (hipExtStreamCreateWithCUMask; such a stream has no priority).
+    static const int cu_split = [] { const char *v = std::getenv("MSKF_CU_SPLIT"); return v ? std::atoi(v) : 0; }();
+    int n_cu = 0;
+    if (cu_split > 0) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    if (cu_split > 0 && cu_split < n_cu) {
+        uint32_t mask[16] = {0};
+        for (int k = 0; k < n_cu && k < 512; ++k) if ((k < cu_split) == (high_priority != 0)) mask[k >> 5] |= 1u << (k & 31);
+        e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)((n_cu + 31) / 32), mask);
+    } else
     if (high_priority) {
         int lo = 0, hi = 0;   // numerically lower = more urgent
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -115,13 +128,29 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
     // a mark that never arrives (device fault, lost queue) must not hang the caller for ever: after MSKF_WAIT_TIMEOUT_S
     // seconds (default 120) the stream is asked for its error state and the wait fails
     static const double limit_s = [] { const char *e = std::getenv("MSKF_WAIT_TIMEOUT_S"); const double v = e ? std::atof(e) : 120.0; return v > 0 ? v : 120.0; }();
-    unsigned long long spins = 0;
+    // MSKF_WAIT=nap[:us]: the same mark, polled between short sleeps (default 40 us) instead of spun on: a wait of some
+    // milliseconds then costs the core a few per cent of its time and the waiter at most one sleep of latency, which leaves a
+    // host that runs under a CPU quota its cores for the other groups' host phases
+    static const long nap_ns = [] {
+        const char *e = std::getenv("MSKF_WAIT");
+        if (!e || std::strncmp(e, "nap", 3) != 0) return 0L;
+        const long us = e[3] == ':' ? std::atol(e + 4) : 40L;
+        return 1000L * (us > 0 ? us : 40L);
+    }();
+    if (nap_ns) {
+        static thread_local bool slack_set = false;
+        if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }     // (the default slack of 50 us would double every sleep)
+    }
+    unsigned long long spins = 0, naps = 0;
+    bool timing = false;
     std::chrono::steady_clock::time_point t0;
     while ((int)(__atomic_load_n((const unsigned int *)w, __ATOMIC_ACQUIRE) - want) < 0) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xFFFFFULL) == 0) {                       // about every 10 ms
+        bool check;
+        if (nap_ns && spins >= 64) { const struct timespec ts = {0, nap_ns}; (void)nanosleep(&ts, nullptr); check = (++naps & 0xFFULL) == 0; }
+        else { __builtin_ia32_pause(); check = (++spins & 0xFFFFFULL) == 0; }
+        if (check) {                                             // about every 10 ms
             const auto now = std::chrono::steady_clock::now();
-            if (spins == 0x100000ULL) t0 = now;
+            if (!timing) { t0 = now; timing = true; }
             else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
                 const hipError_t e = hipStreamQuery(c->stream);
                 mskf_set_error(e != hipSuccess && e != hipErrorNotReady ? hipGetErrorString(e) : "completion mark not written within the wait limit");

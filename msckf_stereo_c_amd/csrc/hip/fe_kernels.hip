@@ -12,6 +12,7 @@
 // window), one workgroup per 32x32 detector tile, one workgroup per 64x16 pyramid output tile; the
 // stream index of the batch is blockIdx.y / blockIdx.z, so a launch covers every VIO stream of a
 // context and fills the chip only when many streams are batched.
+#include <stdlib.h>
 #include <mutex>
 #include "fe_device.h"
 
@@ -82,13 +83,8 @@ extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_d
 
 // ------------------------------------------------------------------------------------------ detector
 #define DET_BORDER 8
-#define DTW 32                 // detector tile: 32 x 32 output pixels
-#define DTH 32
-#define DPW 40                 // gradient-product plane of a tile: image (ty0-4 .. ty0+35, tx0-4 .. tx0+35)
-#define DPS 41                 // row stride of a product plane in LDS words: the rows a half-wave touches in the horizontal pass land in different banks
-#define DET_SLOTS 64           // per-tile cell slots in LDS (cells of >= 5x5 px); smaller cells go straight to global atomics
-#define DSW 48                 // staged bytes per row: image x in [tx0-8, tx0+40)
-#define DSH 42                 // staged rows:          image y in [ty0-5, ty0+37)
+#define DS_LANES 14            // lanes of a 16-lane strip that produce outputs (the two on the right only feed their neighbours)
+#define DS_COLS (4 * DS_LANES) // output columns of a strip
 
 // Per-cell maxima are merged as 64-bit keys  gen (8 bits) | score (24 bits) | ~order (32 bits):
 //   score  = integer Shi-Tomasi score (< 2^24: two sums of 64 squared differences of bytes),
@@ -107,197 +103,208 @@ __device__ __forceinline__ unsigned int isqrt48(unsigned long long v, double vd)
     return r;
 }
 
-struct DetLds {
-    int P[3][DPW * DPS];           // gradient products, then (in place) their horizontal 8-sums
-    unsigned long long key[DET_SLOTS];
-    int cx[DTW], cy[DTH];
-};
+template <int CTRL> __device__ __forceinline__ int det_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // lanes without a source read 0
+template <int CTRL> __device__ __forceinline__ unsigned long long det_dpp0_64(unsigned long long v) {
+    const unsigned int lo = (unsigned int)det_dpp0<CTRL>((int)(unsigned int)v), hi = (unsigned int)det_dpp0<CTRL>((int)(unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
-// cg::CornerDetector per-cell maxima of one 32 x 32 tile at image (tx0, ty0).  t8 points at the staged byte of image
-// (ty0 - 5, tx0 - 8), rows `stride` bytes apart, border pixels replicated.  The three gradient products dx*dx, dx*dy, dy*dy
-// are formed once per pixel, the 8x8 box sums are separable with sliding windows (horizontal runs of 8, vertical runs of
-// 4), the integer Shi-Tomasi score (a + c) - isqrt((a - c)^2 + 4 b^2) is exact.  All 256 threads of the workgroup call this.
-__device__ __forceinline__ void detect_tile(const FeStreamDev &S, const uint8_t *t8, int stride, int tx0, int ty0, unsigned int gen, DetLds &L) {
+// Horizontal 8-sums of one gradient product for the lane's four output columns: the lane holds the products p[0..3] of its
+// four columns, lane r + 1 the next four, lane r + 2 the four after (row_shl DPP inside the 16-lane strip):
+//   H0 = p0..p3 + (all four of lane r+1);  H(j) = H(j-1) - p(j-1) + p(j-1) of lane r+2.
+__device__ __forceinline__ void det_hsum(const int p[4], int H[4]) {
+    const int S = (p[0] + p[1]) + (p[2] + p[3]);
+    H[0] = S + det_dpp0<0x101>(S);
+    H[1] = H[0] + (det_dpp0<0x102>(p[0]) - p[0]);
+    H[2] = H[1] + (det_dpp0<0x102>(p[1]) - p[1]);
+    H[3] = H[2] + (det_dpp0<0x102>(p[2]) - p[2]);
+}
+
+struct DetPix { uint32_t lo, hi; };     // eight pixels of an image row: columns c - 4 .. c - 1 and c .. c + 3 of the lane's first column c
+
+// Gradient products dx*dx, dx*dy, dy*dy (central differences) of the lane's four columns in the row `mid`, and their
+// horizontal 8-sums.
+__device__ __forceinline__ void det_hrow(uint32_t up, DetPix mid, uint32_t dn, int Ha[4], int Hb[4], int Hc[4]) {
+    const uint32_t rn = (uint32_t)det_dpp0<0x101>((int)mid.hi);          // the first pixel of lane r + 1
+    const int m[6] = {(int)(mid.lo >> 24), (int)(mid.hi & 255u), (int)((mid.hi >> 8) & 255u), (int)((mid.hi >> 16) & 255u), (int)(mid.hi >> 24), (int)(rn & 255u)};
+    int pa[4], pb[4], pc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dx = m[j + 2] - m[j];
+        const int dy = (int)((dn >> (8 * j)) & 255u) - (int)((up >> (8 * j)) & 255u);
+        pa[j] = __mul24(dx, dx); pb[j] = __mul24(dx, dy); pc[j] = __mul24(dy, dy);
+    }
+    det_hsum(pa, Ha); det_hsum(pb, Hb); det_hsum(pc, Hc);
+}
+
+// cg::CornerDetector per-cell maxima of cam0 level 0 (image_processor.cpp:259, :657): integer Shi-Tomasi score
+// (a + c) - isqrt((a - c)^2 + 4 b^2) of the 8x8 box sums a, b, c of the gradient products, maximum per detector cell with
+// ties going to the first pixel in row-major order.
+// Round 2 staged a 32x32 tile in LDS and ran three barrier-separated LDS passes over three product planes (24 LDS words
+// per pixel, 124 VALU instructions per pixel, 304 us alone for 192 streams).  This version keeps everything in registers:
+// a 16-lane DPP row is a STRIP of 64 columns (four per lane, 56 outputs) marched down a SEGMENT of rows.  Per row a lane
+// loads eight bytes, forms its twelve products, the horizontal 8-sums come from the two lanes to the right (row_shl), and
+// the vertical 8-sums are running sums: the row entering the window is added, the row leaving it is RECOMPUTED from its
+// pixels (re-read through L1/L2) and subtracted - cheaper than a ring of eight rows of twelve sums in registers, and there
+// is no LDS, no barrier and no inter-wave traffic at all.  The exact score test needs the square root only for a pixel
+// that beats the best score its own column has seen in the current cell (disc < (a + c - best)^2 is decided first), so
+// after the first rows of a cell almost no pixel takes the expensive path.  At the bottom of a cell row the lanes of a
+// strip merge their keys with a segmented DPP max (runs of lanes in the same cell) and the first lane of each run issues
+// the one atomicMax.
+// Block -> (stream, four jobs): the jobs (strip, segment) of ONE stream get block ids congruent modulo 8, so an image
+// travels through the L2 of one XCD (blocks b and b + 8 share an XCD).
+__global__ __launch_bounds__(64) void k_detect_cells(const FeStreamDev *streams, int n_streams, int strips, int seg_rows, int waves, unsigned int gen) {
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int si = xcd + 8 * (qb / waves), wi = qb - (qb / waves) * waves;
+    if (si >= n_streams) return;
+    const FeStreamDev &S = streams[si];
     const int W = S.curr0.w[0], H = S.curr0.h[0];
-    const int cw = S.cell_w, ch = S.cell_h;
-    const int tid = threadIdx.x;
-    if (tid < DTW) L.cx[tid] = (tx0 + tid) / cw;
-    else if (tid < DTW + DTH) L.cy[tid - DTW] = (ty0 + tid - DTW) / ch;
-    if (tid < DET_SLOTS) L.key[tid] = 0ULL;
-    // ---- gradient products at image (ty0-4+r, tx0-4+c): staged position (r+1, c+4).  Item = (row, four pixels): five dword
-    //      reads (the row's bytes c+3 .. c+8, the dwords above and below) instead of sixteen byte reads.  `stride` is DSW.
-    {
-        const uint32_t *t32 = (const uint32_t *)t8;
-        constexpr int SW = DSW / 4;
-        for (int it = tid; it < DPW * (DPW / 4); it += 256) {
-            const int r = it / (DPW / 4), k = it - r * (DPW / 4);
-            const uint32_t *row = t32 + (r + 1) * SW + k;
-            const uint32_t m0 = row[0], m1 = row[1], m2 = row[2], up = row[1 - SW], dn = row[1 + SW];
-            // bytes c+3 .. c+8 of the row: b[0] = m0 >> 24, b[1..4] = m1, b[5] = m2 & 255
-            const int b0 = (int)(m0 >> 24), b1 = (int)(m1 & 255u), b2 = (int)((m1 >> 8) & 255u), b3 = (int)((m1 >> 16) & 255u),
-                      b4 = (int)(m1 >> 24), b5 = (int)(m2 & 255u);
-            const int dx[4] = {b2 - b0, b3 - b1, b4 - b2, b5 - b3};
-            int *p0 = L.P[0] + r * DPS + 4 * k, *p1 = L.P[1] + r * DPS + 4 * k, *p2 = L.P[2] + r * DPS + 4 * k;
+    const int cw = S.cell_w, ch = S.cell_h, det_cols = S.det_cols, det_floor = S.det_floor;
+    unsigned long long *const cell_keys = S.cell_keys;
+    const int lane = threadIdx.x, r = lane & 15;
+    const int job = 4 * wi + (lane >> 4);
+    const int seg = job / strips, strip = job - seg * strips;
+    const int xs = DET_BORDER + DS_COLS * strip;                 // first output column of the strip
+    const int ys = DET_BORDER + seg_rows * seg;                  // first output row of the segment
+    const int y_end = min(ys + seg_rows, H - DET_BORDER);
+    const bool job_on = xs < W - DET_BORDER && ys < y_end;
+    if (!__any(job_on)) return;
+    // the lane's four product columns c0 .. c0 + 3 (outputs x = c0 + 4 + j); a lane right of the image reads clamped
+    // addresses: its products only reach outputs that are not valid either
+    const int c0 = xs - 4 + 4 * r;
+    const int cl = min(c0, W - 4);
+    const uint8_t *img = S.curr0.lvl[0];
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    auto load = [&](int row) -> DetPix {
+        const uint8_t *p = img + (size_t)min(max(row, 0), H - 1) * W + cl;
+        DetPix v; v.lo = *(const u32u *)(p - 4); v.hi = *(const u32u *)p; return v;
+    };
+    int xin[4], cx[4];
+    bool col_ok[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int dy = (int)((dn >> (8 * j)) & 255u) - (int)((up >> (8 * j)) & 255u);
-                p0[j] = dx[j] * dx[j]; p1[j] = dx[j] * dy; p2[j] = dy * dy;
-            }
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int x = c0 + 4 + j;
+        cx[j] = x / cw; xin[j] = x - cx[j] * cw;
+        col_ok[j] = job_on && r < DS_LANES && x < W - DET_BORDER;
     }
-    __syncthreads();
-    // ---- horizontal 8-sums: item = (plane, row, run of 8 outputs), IN PLACE over the product planes (the sums of a row
-    //      overwrite its first 32 products): every item first takes its 15 products into registers, the workgroup syncs,
-    //      then the sums are written.  Without a second set of planes a workgroup needs 22 KB of LDS instead of 38 KB:
-    //      seven per CU instead of four, and the kernel is bound by latency (three barrier-separated passes).
-    {
-        constexpr int ITEMS = 3 * DPW * (DTW / 8);          // 480: at most two per thread
-        int v[2][15];
+    int Va[4] = {0, 0, 0, 0}, Vb[4] = {0, 0, 0, 0}, Vc[4] = {0, 0, 0, 0};
+    // ---- fill the window: product rows ys - 4 .. ys + 2
+    int pr = ys - 4;
+    // (the rows are loaded two steps before they are used: e_nx / l_nx are in flight while a step computes)
+    DetPix e_mid = load(pr), e_dn = load(pr + 1), e_nx = load(pr + 2);
+    uint32_t e_up = load(pr - 1).hi;
+#pragma unroll 1
+    for (int k = 0; k < 7; ++k) {
+        const DetPix nx = load(pr + 3);
+        int Ha[4], Hb[4], Hc[4];
+        det_hrow(e_up, e_mid, e_dn.hi, Ha, Hb, Hc);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int it = tid + 256 * k;
-            if (it < ITEMS) {
-                const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
-                const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
-                const int *src = L.P[pl] + r * DPS + 8 * q;
-#pragma unroll
-                for (int u = 0; u < 15; ++u) v[k][u] = src[u];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int it = tid + 256 * k;
-            if (it < ITEMS) {
-                const int pl = it / (DPW * (DTW / 8)), rem = it - pl * (DPW * (DTW / 8));
-                const int r = rem / (DTW / 8), q = rem - r * (DTW / 8);
-                int acc = ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
-                int *dst = L.P[pl] + r * DPS + 8 * q;
-                dst[0] = acc;
-#pragma unroll
-                for (int u = 1; u < 8; ++u) { acc += v[k][u + 7] - v[k][u - 1]; dst[u] = acc; }
-            }
-        }
+        for (int j = 0; j < 4; ++j) { Va[j] += Ha[j]; Vb[j] += Hb[j]; Vc[j] += Hc[j]; }
+        e_up = e_mid.hi; e_mid = e_dn; e_dn = e_nx; e_nx = nx; ++pr;
     }
-    __syncthreads();
-    // ---- vertical 8-sums + score: thread = (column c, run of 4 rows)
-    {
-        const int c = tid & (DTW - 1), q = tid >> 5;          // 32 columns x 8 runs
-        const int x = tx0 + c;
-        int sa[4], sb[4], sc[4];
+    // ---- steady state: the row pr enters, output row y = pr - 3, the row y - 4 leaves
+    uint32_t l_up = load(ys - 5).hi;
+    DetPix l_mid = load(ys - 4), l_dn = load(ys - 3), l_nx = load(ys - 2);
+    int cy = ys / ch, yin = ys - cy * ch;
+    int bs[4] = {0, 0, 0, 0};                                    // best score of the column in the current cell
+    unsigned long long bk[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+    const int n_rows = seg_rows;                                 // (uniform trip count; rows past y_end are masked)
+#pragma unroll 1
+    for (int k = 0; k < n_rows; ++k) {
+        const int y = ys + k;
+        const bool row_ok = y < y_end;
+        const DetPix enx = load(pr + 3), lnx = load(y - 1);
         {
-            int v0[11], v1[11], v2[11];
+            int Ha[4], Hb[4], Hc[4];
+            det_hrow(e_up, e_mid, e_dn.hi, Ha, Hb, Hc);
 #pragma unroll
-            for (int u = 0; u < 11; ++u) {
-                const int o = (4 * q + u) * DPS + c;
-                v0[u] = L.P[0][o]; v1[u] = L.P[1][o]; v2[u] = L.P[2][o];
-            }
-            int a = 0, b = 0, d = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a += v0[u]; b += v1[u]; d += v2[u]; }
-            sa[0] = a; sb[0] = b; sc[0] = d;
-#pragma unroll
-            for (int u = 1; u < 4; ++u) {
-                a += v0[u + 7] - v0[u - 1]; b += v1[u + 7] - v1[u - 1]; d += v2[u + 7] - v2[u - 1];
-                sa[u] = a; sb[u] = b; sc[u] = d;
-            }
+            for (int j = 0; j < 4; ++j) { Va[j] += Ha[j]; Vb[j] += Hb[j]; Vc[j] += Hc[j]; }
+            e_up = e_mid.hi; e_mid = e_dn; e_dn = e_nx; e_nx = enx; ++pr;
         }
-        const int cx = L.cx[c];
-        const int cx_first = L.cx[0], cy_first = L.cy[0];
-        const int ncx = L.cx[DTW - 1] - cx_first + 1, ncy = L.cy[DTH - 1] - cy_first + 1;
-        const bool use_lds = ncx * ncy <= DET_SLOTS;
-        const bool x_ok = x >= DET_BORDER && x < W - DET_BORDER;
-        int cur_cell = -1, cur_slot = 0;
-        unsigned long long cur_key = 0ULL;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int y = ty0 + 4 * q + u;
-            if (!x_ok || y < DET_BORDER || y >= H - DET_BORDER) continue;
-            const int a = sa[u], b = sb[u], d = sc[u];
-            const int df = a - d;
-            // score = (a + d) - isqrt(disc) > floor  <=>  isqrt(disc) < X := a + d - floor  <=>  disc < X^2 (X > 0): decided
-            // exactly in doubles (everything is below 2^50) before the square root, which most pixels then never need
-            const int X = (a + d) - S.det_floor;
+        for (int j = 0; j < 4; ++j) {
+            if (!(col_ok[j] && row_ok)) continue;
+            const int a = Va[j], b = Vb[j], d = Vc[j];
+            // score > T  <=>  isqrt(disc) < X := a + d - T  <=>  disc < X^2 (X > 0): decided exactly (everything is below
+            // 2^50) before the square root.  T = the detection floor or the best score of this column in this cell: a
+            // later pixel of the column only replaces the best with a strictly larger score (ties go to the first).
+            const int X = (a + d) - max(det_floor, bs[j]);
             if (X <= 0) continue;
+            const int df = a - d;
+            if (abs(df) >= X || 2 * abs(b) >= X) continue;       // each term of disc alone already reaches X^2
             const double discd = (double)df * (double)df + 4.0 * ((double)b * (double)b);   // exact: < 2^48
             if (discd >= (double)X * (double)X) continue;
             const long long disc = (long long)df * df + 4LL * ((long long)b * b);
             const int score = (a + d) - (int)isqrt48((unsigned long long)disc, discd);
-            const int cy = L.cy[4 * q + u];
-            const int cell = cy * S.det_cols + cx;
-            const unsigned int order = (unsigned int)((y - cy * ch) * cw + (x - cx * cw));
-            const unsigned long long key = det_key(gen, score, order);
-            if (cell != cur_cell) {
-                if (cur_key) {
-                    if (use_lds) atomicMax(&L.key[cur_slot], cur_key);
-                    else atomicMax(&S.cell_keys[cur_cell], cur_key);
+            bs[j] = score;
+            bk[j] = det_key(gen, score, (unsigned int)(yin * cw + xin[j]));
+        }
+        {
+            int Ha[4], Hb[4], Hc[4];
+            det_hrow(l_up, l_mid, l_dn.hi, Ha, Hb, Hc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { Va[j] -= Ha[j]; Vb[j] -= Hb[j]; Vc[j] -= Hc[j]; }
+            l_up = l_mid.hi; l_mid = l_dn; l_dn = l_nx; l_nx = lnx;
+        }
+        // ---- bottom of a cell row (or of the segment): merge the strip's keys per cell, one atomicMax per cell
+        ++yin;
+        const bool flush = job_on && row_ok && (yin == ch || y + 1 == y_end);
+        if (__any(flush)) {
+            // a lane's four columns lie in at most two cells (cells are at least four pixels wide): A = the cell of its
+            // first column, B = the cell of its last one when that differs
+            unsigned long long ka = 0ULL, kb = 0ULL;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long v = flush ? bk[j] : 0ULL;
+                if (cx[j] == cx[0]) ka = v > ka ? v : ka; else kb = v > kb ? v : kb;
+            }
+            const bool two = cx[3] != cx[0];
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                unsigned long long kk = pass ? kb : ka;
+                const int id = flush ? (pass ? (two ? cx[3] : -1 - r) : cx[0]) : -1 - r;     // (negative ids never match a neighbour)
+                if (pass && !__any(flush && two)) break;
+                // segmented max over runs of lanes with the same cell id: after the steps 1, 2, 4, 8 the first lane of a
+                // run holds the maximum of the run
+                {
+                    const int o = det_dpp0<0x101>(id + 0x40000000) - 0x40000000; const unsigned long long v = det_dpp0_64<0x101>(kk);
+                    if (o == id && v > kk) kk = v;
                 }
-                cur_cell = cell; cur_slot = (cy - cy_first) * ncx + (cx - cx_first); cur_key = key;
-            } else if (key > cur_key) cur_key = key;
-        }
-        if (cur_key) {
-            if (use_lds) atomicMax(&L.key[cur_slot], cur_key);
-            else atomicMax(&S.cell_keys[cur_cell], cur_key);
-        }
-        __syncthreads();
-        if (use_lds && tid < ncx * ncy) {
-            const unsigned long long k = L.key[tid];
-            if (k) {
-                const int ly = tid / ncx, lx = tid - ly * ncx;
-                atomicMax(&S.cell_keys[(cy_first + ly) * S.det_cols + (cx_first + lx)], k);
+                {
+                    const int o = det_dpp0<0x102>(id + 0x40000000) - 0x40000000; const unsigned long long v = det_dpp0_64<0x102>(kk);
+                    if (o == id && v > kk) kk = v;
+                }
+                {
+                    const int o = det_dpp0<0x104>(id + 0x40000000) - 0x40000000; const unsigned long long v = det_dpp0_64<0x104>(kk);
+                    if (o == id && v > kk) kk = v;
+                }
+                {
+                    const int o = det_dpp0<0x108>(id + 0x40000000) - 0x40000000; const unsigned long long v = det_dpp0_64<0x108>(kk);
+                    if (o == id && v > kk) kk = v;
+                }
+                const int left = det_dpp0<0x111>(id + 0x40000000) - 0x40000000;          // row_shr:1: the lane to the left (none: -2^30)
+                if (id >= 0 && left != id && kk) atomicMax(&cell_keys[cy * det_cols + id], kk);
+            }
+            if (flush) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bs[j] = 0; bk[j] = 0ULL; }
             }
         }
+        if (yin == ch) { yin = 0; ++cy; }
     }
-    __syncthreads();
-}
-
-// cg::CornerDetector per-cell maxima of cam0 level 0: one workgroup per 32 x 32 pixel tile, its 48 x 42 byte footprint
-// staged in LDS once (border pixels replicated).
-// (Tried and dropped, round 2: fusing this pass into the level-1 pyr_down tile pass — one workgroup staging a 128 x 32
-// region of level 0, writing its level-1 tile and scoring the region as four sub-tiles.  It removes a launch and the
-// second read of cam0, but the detector is LDS / latency bound, not bandwidth bound: four serial sub-tiles per workgroup
-// at 46 KB of LDS ran 33 % slower than the two separate kernels, 315 vs 237 ms per 40 steps.)
-// Block -> (stream, tile): workgroups are dealt to the eight XCDs round robin (b and b + 8 share one), and each XCD has its
-// own L2.  With the tiles of an image spread over all of them every XCD fetched the 8-pixel halo rows / columns of its tiles
-// from memory again: 2.8 x the image bytes (profiles/r02_pmc_hbm_traffic.json).  The tiles of ONE stream now get block ids
-// that are congruent modulo 8, so an image travels through one L2 and the halo of a tile is its neighbour's hit.
-__global__ __launch_bounds__(256) void k_detect_cells(const FeStreamDev *streams, int n_streams, int tiles_x, int tiles, unsigned int gen) {
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int si = xcd + 8 * (qb / tiles), ti = qb - (qb / tiles) * tiles;
-    if (si >= n_streams) return;
-    const FeStreamDev &S = streams[si];
-    const int W = S.curr0.w[0], H = S.curr0.h[0];
-    const int tyi = ti / tiles_x, txi = ti - tyi * tiles_x;
-    const int tx0 = txi * DTW, ty0 = tyi * DTH;
-    if (tx0 >= W || ty0 >= H) return;
-    const uint8_t *img = S.curr0.lvl[0];
-    __shared__ uint32_t s_tile[DSW / 4 * DSH];
-    __shared__ DetLds s_det;
-    const int tid = threadIdx.x;
-    const int sx0 = tx0 - 8, sy0 = ty0 - 5;
-    const bool fast = sx0 >= 0 && sy0 >= 0 && sx0 + DSW <= W && sy0 + DSH <= H;
-    if (fast) {
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        for (int i = tid; i < DSW / 4 * DSH; i += 256) {
-            const int r = i / (DSW / 4), c = i - r * (DSW / 4);
-            s_tile[i] = *(const u32u *)(img + (size_t)(sy0 + r) * W + sx0 + 4 * c);
-        }
-    } else {
-        uint8_t *t8 = (uint8_t *)s_tile;
-        for (int i = tid; i < DSW * DSH; i += 256) {
-            const int r = i / DSW, c = i - r * DSW;
-            const int gx = min(max(sx0 + c, 0), W - 1), gy = min(max(sy0 + r, 0), H - 1);
-            t8[i] = img[(size_t)gy * W + gx];
-        }
-    }
-    __syncthreads();
-    detect_tile(S, (const uint8_t *)s_tile, DSW, tx0, ty0, gen, s_det);
 }
 
 extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st) {
-    const int tiles_x = (max_w + DTW - 1) / DTW, tiles_y = (max_h + DTH - 1) / DTH;
-    const int tiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_detect_cells, dim3(8 * ((n_streams + 7) / 8) * tiles), dim3(256), 0, st, streams_dev, n_streams, tiles_x, tiles, gen);
+    // rows per segment: short segments give more wavefronts (a launch should fill the device several times over) but every
+    // segment pays seven window-filling rows; MSKF_DETECT_SEG_ROWS overrides the choice
+    static const int seg_env = [] { const char *e = getenv("MSKF_DETECT_SEG_ROWS"); return e ? atoi(e) : 0; }();
+    const int strips = (max_w - 2 * DET_BORDER + DS_COLS - 1) / DS_COLS, rows = max_h - 2 * DET_BORDER;
+    if (strips <= 0 || rows <= 0) return;
+    int seg_rows = seg_env > 0 ? seg_env : 32;
+    if (seg_env <= 0) while (seg_rows < 128 && (long long)n_streams * strips * ((rows + seg_rows - 1) / seg_rows) / 4 > 32768) seg_rows *= 2;
+    const int segs = (rows + seg_rows - 1) / seg_rows;
+    const int waves = (strips * segs + 3) / 4;
+    hipLaunchKernelGGL(k_detect_cells, dim3(8 * ((n_streams + 7) / 8) * waves), dim3(64), 0, st, streams_dev, n_streams, strips, seg_rows, waves, gen);
 }
 
 // ------------------------------------------------------------------------------------------ point math
@@ -794,6 +801,9 @@ __device__ __forceinline__ void l4_track(const PyrDev &A, const PyrDev &B, bool 
 // stereo match accepted; a point that fails the temporal half gets out1 = und0 = und1 = 0 and status 0.
 // Block -> (stream, point group): the blocks b and b + 8 share an XCD (round-robin dispatch, speed only), so the point
 // groups of ONE stream are given ids that are congruent modulo 8: a stream's pyramid levels then travel through one L2.
+#ifdef TRACK_WAVES
+__attribute__((amdgpu_waves_per_eu(TRACK_WAVES, TRACK_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void k_track4(const FeStreamDev *streams, int n_streams, int groups_per_stream) {
     const int x = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int si = x + 8 * (qb / groups_per_stream), gi = qb - (qb / groups_per_stream) * groups_per_stream;
@@ -920,5 +930,8 @@ extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hi
 extern "C" void fe_launch_track(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st) {
     if (max_pts <= 0) return;
     const int gps = (max_pts + 3) / 4;
-    hipLaunchKernelGGL(k_track4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), 0, st, streams_dev, n_streams, gps);
+    // MSKF_TRACK_LDS_PAD=bytes (experiment): unused dynamic LDS per one-wave workgroup, which caps the waves of this kernel on
+    // a CU (160 KB / (3.7 KB + pad)) and so leaves registers and wave slots to the filter's kernels of the other groups
+    static const unsigned pad = [] { const char *e = getenv("MSKF_TRACK_LDS_PAD"); const long v = e ? atol(e) : 0; return (unsigned)(v > 0 && v < 60000 ? v : 0); }();
+    hipLaunchKernelGGL(k_track4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), pad, st, streams_dev, n_streams, gps);
 }

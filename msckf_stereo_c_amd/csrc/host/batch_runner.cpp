@@ -722,9 +722,15 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
         if (mine == 0 && ph >= 1) { t_begin = now_s(); gate(w, fe, true); mine = 1; }
         if (mine == 1 && ph == 2) { t_end = now_s(); gate(w, fe, false); mine = 2; }
     };
+    // Workers and batches are different things: there may be fewer workers of a kind than batches (MSKF_FE_WORKERS /
+    // MSKF_EKF_WORKERS, default one of each per batch; worker w uses the contexts group w created).  The filter stage is the longer
+    // one, so e.g. 12 batches can be served by 4 front-end and 12 filter workers on the device's 16 hardware queues.
+    int n_few = nb, n_ekw = nb;
+    if (const char *e = std::getenv("MSKF_FE_WORKERS")) n_few = std::max(1, std::min(nb, std::atoi(e)));
+    if (const char *e = std::getenv("MSKF_EKF_WORKERS")) n_ekw = std::max(1, std::min(nb, std::atoi(e)));
     std::vector<std::thread> th;
     // ---- front-end workers: the batch that is furthest behind, not being worked on, with room in its hand-off queue
-    for (int w = 0; w < nb; ++w) th.emplace_back([&, w]() {
+    for (int w = 0; w < n_few; ++w) th.emplace_back([&, w]() {
         hostprof::enabled() = false;
         int mine = 0;
         double *acc = groups_[w]->phase_s;
@@ -773,7 +779,7 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
         if (mine == 1) { W.t_fe_end = now_s(); gate(w, true, false); }
     });
     // ---- filter workers: the oldest handed-off frame of a batch whose filter is not being worked on
-    for (int w = 0; w < nb; ++w) th.emplace_back([&, w]() {
+    for (int w = 0; w < n_ekw; ++w) th.emplace_back([&, w]() {
         hostprof::enabled() = false;
         int mine = 0;
         double *acc = groups_[w]->phase_s;
