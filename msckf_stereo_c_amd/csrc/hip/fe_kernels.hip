@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(const PyrJob *jobs) {
     const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
     if (ox0 >= job.dw || oy0 >= job.dh) return;
     constexpr int SW = 2 * PD_TW + 4, SH = 2 * PD_TH + 4;
-    __shared__ uint8_t s_src[SH][SW + 4];
-    __shared__ uint16_t s_h[SH][PD_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SH][SW + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[SH][PD_TW];
     const int tid = threadIdx.x;
     const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
     if (sx0 >= 0 && sy0 >= 0 && sx0 + SW <= job.sw && sy0 + SH <= job.sh) {
@@ -60,18 +60,39 @@ __global__ __launch_bounds__(256) void k_pyr_down(const PyrJob *jobs) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < SH * PD_TW; i += 256) {
-        const int r = i / PD_TW, c = i - r * PD_TW;
-        const uint8_t *p = &s_src[r][2 * c];
-        s_h[r][c] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    // horizontal [1 4 6 4 1]: an item is four neighbouring outputs of a row (source bytes 8q .. 8q+10 as three LDS dwords,
+    // the four sums as one 8-byte LDS write) instead of one output from five byte reads
+    for (int i = tid; i < SH * (PD_TW / 4); i += 256) {
+        const int r = i / (PD_TW / 4), q = i - r * (PD_TW / 4);
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(&s_src[r][8 * q]);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        const int b0 = w0 & 255u, b1 = (w0 >> 8) & 255u, b2 = (w0 >> 16) & 255u, b3 = w0 >> 24, b4 = w1 & 255u, b5 = (w1 >> 8) & 255u,
+                  b6 = (w1 >> 16) & 255u, b7 = w1 >> 24, b8 = w2 & 255u, b9 = (w2 >> 8) & 255u, b10 = (w2 >> 16) & 255u;
+        const uint32_t h0 = (uint32_t)(b0 + 4 * b1 + 6 * b2 + 4 * b3 + b4), h1 = (uint32_t)(b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6);
+        const uint32_t h2 = (uint32_t)(b4 + 4 * b5 + 6 * b6 + 4 * b7 + b8), h3 = (uint32_t)(b6 + 4 * b7 + 6 * b8 + 4 * b9 + b10);
+        uint2 o; o.x = h0 | (h1 << 16); o.y = h2 | (h3 << 16);
+        *reinterpret_cast<uint2 *>(&s_h[r][4 * q]) = o;
     }
     __syncthreads();
-    for (int i = tid; i < PD_TW * PD_TH; i += 256) {
-        const int r = i / PD_TW, c = i - r * PD_TW;
-        const int ox = ox0 + c, oy = oy0 + r;
+    // vertical pass: one item per thread = four neighbouring outputs of a row, stored as one dword.  The sums of two columns
+    // share a register as 16-bit lanes (s + 128 <= 16 * 16 * 255 + 128 < 2^16, so the lanes never carry into each other)
+    {
+        const int r = tid / (PD_TW / 4), q = tid - r * (PD_TW / 4);
+        const int ox = ox0 + 4 * q, oy = oy0 + r;
         if (ox < job.dw && oy < job.dh) {
-            const int s = s_h[2 * r][c] + 4 * s_h[2 * r + 1][c] + 6 * s_h[2 * r + 2][c] + 4 * s_h[2 * r + 3][c] + s_h[2 * r + 4][c];
-            job.dst[(size_t)oy * job.dw + ox] = (uint8_t)((s + 128) >> 8);
+            uint2 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const uint2 *>(&s_h[2 * r + k][4 * q]);
+            const uint32_t lo = (v[0].x + v[4].x) + 4u * (v[1].x + v[3].x) + 6u * v[2].x + 0x00800080u;
+            const uint32_t hi = (v[0].y + v[4].y) + 4u * (v[1].y + v[3].y) + 6u * v[2].y + 0x00800080u;
+            const uint32_t px = ((lo >> 8) & 255u) | ((lo >> 24) << 8) | (((hi >> 8) & 255u) << 16) | ((hi >> 24) << 24);
+            uint8_t *d = job.dst + (size_t)oy * job.dw + ox;
+            if (ox + 3 < job.dw) {
+                typedef uint32_t __attribute__((aligned(1))) u32u;
+                *reinterpret_cast<u32u *>(d) = px;
+            } else {
+                for (int k = 0; ox + k < job.dw; ++k) d[k] = (uint8_t)(px >> (8 * k));
+            }
         }
     }
 }
@@ -109,32 +130,41 @@ template <int CTRL> __device__ __forceinline__ unsigned long long det_dpp0_64(un
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Horizontal 8-sums of one gradient product for the lane's four output columns: the lane holds the products p[0..3] of its
-// four columns, lane r + 1 the next four, lane r + 2 the four after (row_shl DPP inside the 16-lane strip):
-//   H0 = p0..p3 + (all four of lane r+1);  H(j) = H(j-1) - p(j-1) + p(j-1) of lane r+2.
-__device__ __forceinline__ void det_hsum(const int p[4], int H[4]) {
-    const int S = (p[0] + p[1]) + (p[2] + p[3]);
+typedef short det_v2s __attribute__((ext_vector_type(2)));
+// a.lo * b.lo + a.hi * b.hi of two pairs of 16-bit lanes (three-operand form with an inline-constant addend: no move)
+__device__ __forceinline__ int det_dot2(int a, int b) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(det_v2s, a), __builtin_bit_cast(det_v2s, b), 0, true); }
+__device__ __forceinline__ int det_pksub(uint32_t a, uint32_t b) { return __builtin_bit_cast(int, (det_v2s)(__builtin_bit_cast(det_v2s, a) - __builtin_bit_cast(det_v2s, b))); }
+
+// Horizontal 8-sums of one gradient product for the lane's four output columns.  The lane holds the products of its four
+// columns as the pair sums P01 = p0 + p1, P23 = p2 + p3 and the single products p0, p2; lane r + 1 holds the next four
+// columns, lane r + 2 the four after (row_shl DPP inside the 16-lane strip):
+//   H0 = P01 + P23 + (the same of lane r+1),  H2 = H0 - P01 + P01 of lane r+2,  H1 = H0 - p0 + p0'',  H3 = H2 - p2 + p2''.
+__device__ __forceinline__ void det_hsum(int P01, int P23, int p0, int p2, int H[4]) {
+    const int S = P01 + P23;
     H[0] = S + det_dpp0<0x101>(S);
-    H[1] = H[0] + (det_dpp0<0x102>(p[0]) - p[0]);
-    H[2] = H[1] + (det_dpp0<0x102>(p[1]) - p[1]);
-    H[3] = H[2] + (det_dpp0<0x102>(p[2]) - p[2]);
+    H[2] = H[0] + (det_dpp0<0x102>(P01) - P01);
+    H[1] = H[0] + (det_dpp0<0x102>(p0) - p0);
+    H[3] = H[2] + (det_dpp0<0x102>(p2) - p2);
 }
 
 struct DetPix { uint32_t lo, hi; };     // eight pixels of an image row: columns c - 4 .. c - 1 and c .. c + 3 of the lane's first column c
 
 // Gradient products dx*dx, dx*dy, dy*dy (central differences) of the lane's four columns in the row `mid`, and their
-// horizontal 8-sums.
+// horizontal 8-sums.  The differences are formed two at a time in 16-bit lanes (byte permutes + packed subtract), the
+// products and their pair sums are 16-bit dot products: 64 instructions per row instead of 90 with 32-bit arithmetic.
 __device__ __forceinline__ void det_hrow(uint32_t up, DetPix mid, uint32_t dn, int Ha[4], int Hb[4], int Hc[4]) {
-    const uint32_t rn = (uint32_t)det_dpp0<0x101>((int)mid.hi);          // the first pixel of lane r + 1
-    const int m[6] = {(int)(mid.lo >> 24), (int)(mid.hi & 255u), (int)((mid.hi >> 8) & 255u), (int)((mid.hi >> 16) & 255u), (int)(mid.hi >> 24), (int)(rn & 255u)};
-    int pa[4], pb[4], pc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int dx = m[j + 2] - m[j];
-        const int dy = (int)((dn >> (8 * j)) & 255u) - (int)((up >> (8 * j)) & 255u);
-        pa[j] = __mul24(dx, dx); pb[j] = __mul24(dx, dy); pc[j] = __mul24(dy, dy);
-    }
-    det_hsum(pa, Ha); det_hsum(pb, Hb); det_hsum(pc, Hc);
+    const uint32_t rn = (uint32_t)det_dpp0<0x101>((int)mid.hi);          // the pixels of lane r + 1 (its first one is needed)
+    // pixels m0 .. m5 = columns c - 1 .. c + 4 as pairs of 16-bit lanes
+    const uint32_t m01 = __builtin_amdgcn_perm(mid.hi, mid.lo, 0x0c040c03u);   // (lo.b3, hi.b0)
+    const uint32_t m23 = __builtin_amdgcn_perm(0u, mid.hi, 0x0c020c01u);       // (hi.b1, hi.b2)
+    const uint32_t m45 = __builtin_amdgcn_perm(rn, mid.hi, 0x0c040c03u);       // (hi.b3, rn.b0)
+    const int D01 = det_pksub(m23, m01), D23 = det_pksub(m45, m23);            // dx of columns (0, 1) and (2, 3)
+    const int E01 = det_pksub(__builtin_amdgcn_perm(0u, dn, 0x0c010c00u), __builtin_amdgcn_perm(0u, up, 0x0c010c00u));
+    const int E23 = det_pksub(__builtin_amdgcn_perm(0u, dn, 0x0c030c02u), __builtin_amdgcn_perm(0u, up, 0x0c030c02u));
+    const int D0 = D01 & 0xffff, D2 = D23 & 0xffff, E0 = E01 & 0xffff, E2 = E23 & 0xffff;   // (d, 0): picks the product of the even column
+    det_hsum(det_dot2(D01, D01), det_dot2(D23, D23), det_dot2(D0, D01), det_dot2(D2, D23), Ha);
+    det_hsum(det_dot2(D01, E01), det_dot2(D23, E23), det_dot2(D0, E01), det_dot2(D2, E23), Hb);
+    det_hsum(det_dot2(E01, E01), det_dot2(E23, E23), det_dot2(E0, E01), det_dot2(E2, E23), Hc);
 }
 
 // cg::CornerDetector per-cell maxima of cam0 level 0 (image_processor.cpp:259, :657): integer Shi-Tomasi score
