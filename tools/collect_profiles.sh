@@ -21,8 +21,8 @@ if [ "$WHAT" = lines ]; then
   timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --compression tsqr > "$OUT/bench_tsqr.json" 2>> "$OUT/log.txt" || exit 3
   timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --host-images > "$OUT/bench_host_images.json" 2>> "$OUT/log.txt" || exit 4
   echo "c2 variants done"
-  timeout -k 10 300 python bench.py --config c3 > "$OUT/bench_c3.json" 2>> "$OUT/log.txt" || exit 5
-  timeout -k 10 300 python bench.py --config c5 > "$OUT/bench_c5.json" 2>> "$OUT/log.txt" || exit 6
+  timeout -k 10 400 python bench.py --config c3 > "$OUT/bench_c3.json" 2>> "$OUT/log.txt" || exit 5
+  timeout -k 10 400 python bench.py --config c5 --unique 8 > "$OUT/bench_c5.json" 2>> "$OUT/log.txt" || exit 6
   echo "c3 c5 done"
   # two ranks (gloo) sharing the box's one GPU at the DEFAULT preset: what the host share costs when ranks multiply
   timeout -k 10 400 python bench.py --gpus 2 --backend gloo --no-cpu --steps 20 --warmup 5 > "$OUT/bench_2rank_gloo_one_gpu.json" 2>> "$OUT/log.txt" || exit 7
