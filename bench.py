@@ -629,9 +629,11 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (host-resident images, PCIe-inclusive)" if args.host_images else ""),
             "config": {"workload": "%s [%s]: %dx%d stereo, %d cam clones, grid %s (%d features/frame realised), 200 Hz IMU; "
-                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads%s); %s"
+                                   "KLT + EKF update on-GPU; %d independent streams per GPU batched per launch (%d host groups x %d threads%s); %s; "
+                                   "pose_out.txt is not written and the reference's ever-growing path / point lists (Q20) are kept only for the %d streams whose trajectories "
+                                   "are compared with the CPU oracle"
                                    % (CONFIGS[args.config]["name"], args.config, args.width, args.height, args.clones, args.grid, n_feat, n_streams,
-                                      n_groups, args.host_threads, ", FE|EKF pipelined" if pipe else "", seq_note),
+                                      n_groups, args.host_threads, ", FE|EKF pipelined" if pipe else "", seq_note, n_pose_streams),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
                        "compression": args.compression, "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": run.num_tsqr_updates(0),
                        "ekf_uncompressed_updates_stream0": run.num_uncompressed_updates(0),

@@ -522,6 +522,50 @@ def test_staggered_groups_run_ahead(oracle):
     run.close()
 
 
+def test_balanced_runner_with_fewer_workers_than_batches(oracle, monkeypatch):
+    """MultiRunner::run_balanced: batches of streams are not tied to queues - a front-end worker takes the batch that is
+    furthest behind, a filter worker the oldest handed-off frame.  With ONE front-end worker and TWO filter workers for three
+    batches (MSKF_FE_WORKERS / MSKF_EKF_WORKERS) every batch is run by borrowed contexts most of the time; each must still
+    equal the oracle fed the same frames (ids and pixels bit-exact, poses within tolerance), and the streams must be back
+    on their own contexts afterwards (a second, ordinary run continues them)."""
+    w, h, n_frames, delta = 376, 240, 44, 4
+    fe, ekf = default_fe_cfg(), default_ekf_cfg(max_cam_state_size=10)
+    syn = oracle.Synth(seed=0x5EED0063, width=w, height=h)
+    keep = []
+    run = R.Runner(syn.calib, fe, ekf, 3, 1, host_threads=1)
+    _attach_sequences(oracle, run, [syn, syn, syn], n_frames + 2 * delta + 8, keep)
+    run.set_stagger(delta)
+    monkeypatch.setenv("MSKF_FE_WORKERS", "1")
+    monkeypatch.setenv("MSKF_EKF_WORKERS", "2")
+    run.run(0, 30, threaded=True, pipelined=True)
+    monkeypatch.delenv("MSKF_FE_WORKERS")
+    monkeypatch.delenv("MSKF_EKF_WORKERS")
+    run.run(30, n_frames - 30, threaded=True, pipelined=True)
+    for g in range(3):
+        osys = oracle.OracleSystem(syn.calib, fe, ekf)
+        syn.feed(osys, n_frames + g * delta)
+        for x, y in zip(osys.dump()[:4], run.dump(g)[:4]):
+            assert np.array_equal(x, y)
+        op, gp = osys.poses(), run.poses(g)
+        assert len(op) == len(gp) and np.abs(op["p"] - gp["p"]).max() < POS_TOL
+    run.close()
+
+
+def test_nap_wait_mode_in_a_child_process():
+    """MSKF_WAIT=nap (the completion mark is polled between short sleeps instead of spun on) and MSKF_WAIT=block (parked on a
+    blocking-sync event): the mode is read once per process, so each runs tests/child_wait_mode.py - three batches through
+    the balanced runner against the oracle - in a child of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("nap:25", "block"):
+        env = dict(os.environ, MSKF_WAIT=mode)
+        res = subprocess.run([sys.executable, os.path.join(root, "tests", "child_wait_mode.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        assert ("OK wait=%s" % mode) in res.stdout
+
+
 def test_timed_window_inside_one_pipelined_run(oracle):
     """MultiRunner::run_timed (bench.py): warm-up + timed steps in ONE pipelined run.  The window is defined on the work
     (it opens when the groups together have completed n_groups x warm-up frames and closes at n_groups x (warm-up + steps)),
