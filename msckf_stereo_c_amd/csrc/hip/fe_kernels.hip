@@ -597,8 +597,13 @@ __device__ __forceinline__ void l4_stage(const uint8_t *img, int w, int h, int x
         }
         return;
     }
-    // at the border: element-wise, pixels outside the image replicated from the edge
+    // at the border: pixels outside the image are replicated from the edge.  x0 is a multiple of four, so a staged dword lies
+    // inside its row, or left of it (four copies of the first pixel), or right of it / across its end (the row's last four
+    // pixels shifted down, the last pixel repeated): ONE dword load at a clamped position per element and a byte alignment.
+    // (Round 2 loaded four clamped bytes per element: 230 instructions per call, and at the two coarse levels almost every
+    // wavefront has a point near the border - a quarter of all LK instructions were this path.)
     constexpr int N = ROWS * L4_DW, PER = (N + 15) / 16;
+    typedef uint32_t __attribute__((aligned(1))) l4_u32u;
     uint32_t v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -607,9 +612,10 @@ __device__ __forceinline__ void l4_stage(const uint8_t *img, int w, int h, int x
         if (on && e < N) {
             const int row = (e * 43) >> 8, c = e - L4_DW * row;       // e / 6 for e < 128
             const uint8_t *rp = img + l4_mad24_vvv(min(max(y0 + row, 0), h - 1), w, 0);
-            const int xb = x0 + 4 * c;
-            v[i] = (uint32_t)rp[min(max(xb, 0), w - 1)] | ((uint32_t)rp[min(max(xb + 1, 0), w - 1)] << 8) |
-                   ((uint32_t)rp[min(max(xb + 2, 0), w - 1)] << 16) | ((uint32_t)rp[min(max(xb + 3, 0), w - 1)] << 24);
+            const int xb = x0 + 4 * c, xc = min(max(xb, 0), w - 4), sh = xb - xc;
+            const uint32_t D = *(const l4_u32u *)(rp + xc);
+            const uint32_t first = (D & 255u) * 0x01010101u, last = (D >> 24) * 0x01010101u;
+            v[i] = sh < 0 ? first : sh >= 4 ? last : __builtin_amdgcn_alignbyte(last, D, (uint32_t)sh);
         }
     }
 #pragma unroll
