@@ -90,10 +90,32 @@ class MapServer {
     double *z(int clone_slot, int slot) { return &z_[((size_t)clone_slot * row_cap_ + (size_t)slot) * 4]; }
     const double *z(int clone_slot, int slot) const { return &z_[((size_t)clone_slot * row_cap_ + (size_t)slot) * 4]; }
 
+    // ---- software prefetch.  A stream's tables are ~1 MB and a host thread walks the tables of hundreds of streams per frame:
+    // every per-feature access is a cache miss, and the loops over ranks know their slots ahead of time (slots_ is sequential).
+    void prefetch_rank(size_t rank) const {                     // mask / init flag of the feature at `rank`
+        if (rank < slots_.size()) { const int s = slots_[rank]; __builtin_prefetch(&mask_[s]); __builtin_prefetch(&init_[s]); }
+    }
+    void prefetch_obs(size_t rank, int row_a, int row_b) const {    // its observations in two clone rows and its position
+        if (rank < slots_.size()) { const int s = slots_[rank]; __builtin_prefetch(z(row_a, s)); __builtin_prefetch(z(row_b, s)); __builtin_prefetch(&pos_[s]); }
+    }
+    void prefetch_all_obs(size_t rank, uint64_t skip_bit, const std::vector<int> &row_of_order) const {   // every observation of a feature that lost track
+        if (rank >= slots_.size()) return;
+        const int s = slots_[rank];
+        const uint64_t m = mask_[s];
+        if ((m & skip_bit) || __builtin_popcountll(m) < 3) return;
+        __builtin_prefetch(&pos_[s]);
+        for (uint64_t b = m; b; b &= b - 1) __builtin_prefetch(z(row_of_order[__builtin_ctzll(b)], s));
+    }
+    void prefetch_id(FeatureIDType id) const {                  // the hash bucket of `id`
+        if (!hkey_.empty()) { const size_t h = hash(id) & (hkey_.size() - 1); __builtin_prefetch(&hkey_[h]); __builtin_prefetch(&hval_[h]); }
+    }
+    void prefetch_slot(int clone_slot, int slot) const { __builtin_prefetch(&mask_[slot], 1); __builtin_prefetch(z(clone_slot, slot), 1); }
+
     // remove bit position k (a clone leaving the window) from every mask: bits above k move down by one
     void remove_clone_bit(int k) {
         const uint64_t low = (k == 0) ? 0ULL : (~0ULL >> (64 - k));
         for (size_t r = 0; r < slots_.size(); ++r) {
+            if (r + 16 < slots_.size()) __builtin_prefetch(&mask_[slots_[r + 16]], 1);
             uint64_t &m = mask_[slots_[r]];
             m = (m & low) | ((m >> 1) & ~low);
         }

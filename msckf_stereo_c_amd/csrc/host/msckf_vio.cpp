@@ -321,6 +321,9 @@ void MsckfVio::addFeatureObservations(const CameraMeasurementConstPtr &msg) {
     const int cs = newest.slot;
     const uint64_t bit = 1ULL << (state_server.cam_states.size() - 1);
     for (size_t k = 0; k < n_full; ++k) {
+        // two-stage prefetch: the hash bucket of the feature 12 ahead, then (bucket in cache) the rows of the feature 6 ahead
+        if (k + 12 < n_full) map_server.prefetch_id((FeatureIDType)msg->features[k + 12].id);
+        if (k + 6 < n_full) { const int s6 = map_server.find((FeatureIDType)msg->features[k + 6].id); if (s6 >= 0) map_server.prefetch_slot(cs, s6); }
         const FeatureMeasurement &f = msg->features[k];
         bool created = false;
         const int s = map_server.find_or_add((FeatureIDType)f.id, created);
@@ -409,6 +412,8 @@ void MsckfVio::buildLostFeatureUpdate(mskf_ekf_update_args &upd) {
     const uint64_t cur_bit = 1ULL << (clones_.size() - 1);       // the clone of this frame
     const size_t nf = map_server.size();
     for (size_t rank = 0; rank < nf; ++rank) {
+        map_server.prefetch_rank(rank + 24);
+        map_server.prefetch_all_obs(rank + 8, cur_bit, order_slot_);
         const int slot = map_server.slot_at(rank);
         const uint64_t m = map_server.mask(slot);
         if (m & cur_bit) continue;                                // still tracked
@@ -588,6 +593,8 @@ void MsckfVio::buildPruneUpdate(mskf_ekf_update_args &upd) {
     const int row_a = order_slot_[ka], row_b = order_slot_[kb];
     const size_t nf = map_server.size();
     for (size_t rank = 0; rank < nf; ++rank) {
+        map_server.prefetch_rank(rank + 24);
+        map_server.prefetch_obs(rank + 8, row_a, row_b);
         const int slot = map_server.slot_at(rank);
         const uint64_t m = map_server.mask(slot);
         // a feature observed by only one of the two loses that observation (:1096-1101), one observed by both but
