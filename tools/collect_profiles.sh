@@ -3,6 +3,7 @@
 # granted for at most 20 minutes):
 #   tools/collect_profiles.sh <out dir under gpurun_out/> lines      bench lines: the driver's command, 60 steps, C3, C5,
 #                                                                    TSQR compression, host-resident images, two ranks on one GPU
+#   tools/collect_profiles.sh <out dir under gpurun_out/> stats      only the first step of "counters" (kernel stats + occupancy)
 #   tools/collect_profiles.sh <out dir under gpurun_out/> counters   the driver's command under rocprofv3 --kernel-trace --stats
 #                                                                    and the PMC passes (each counter group in its own run,
 #                                                                    python directly after "--")
@@ -32,6 +33,7 @@ else
   echo "stats done"
   python tools/trace_busy.py "$OUT"/stats/*/*_kernel_trace.csv > "$OUT/trace_occupancy.txt" 2>> "$OUT/log.txt"
   rm -f "$OUT"/stats/*/*_kernel_trace.csv
+  [ "$WHAT" = stats ] && { echo "stats only"; exit 0; }
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $SOLO > /dev/null 2>> "$OUT/log.txt" || exit 3
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $SOLO > /dev/null 2>> "$OUT/log.txt" || exit 4
   echo "hbm done"
