@@ -279,7 +279,17 @@ __global__ __launch_bounds__(64) void k_detect_cells(const FeStreamDev *streams,
         // ---- bottom of a cell row (or of the segment): merge the strip's keys per cell, one atomicMax per cell
         ++yin;
         const bool flush = job_on && row_ok && (yin == ch || y + 1 == y_end);
-        if (__any(flush)) {
+        if (cw < 4) {
+            // cells narrower than a lane's four columns (images below 188 pixels with the 47-column detector grid): a lane may
+            // touch three cells, so every column sends its own key
+            if (flush) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (bk[j]) atomicMax(&cell_keys[cy * det_cols + cx[j]], bk[j]);
+                    bs[j] = 0; bk[j] = 0ULL;
+                }
+            }
+        } else if (__any(flush)) {
             // a lane's four columns lie in at most two cells (cells are at least four pixels wide): A = the cell of its
             // first column, B = the cell of its last one when that differs
             unsigned long long ka = 0ULL, kb = 0ULL;

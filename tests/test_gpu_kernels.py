@@ -305,6 +305,26 @@ def test_detector_large_cells(gpu_ctx, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("w,h", [(128, 96), (70, 64), (190, 130), (750, 478)])
+def test_detector_small_and_odd_geometries(gpu_ctx, oracle, w, h):
+    """Detector cells narrower than four pixels (width < 188 with the 47 x 30 grid: a lane's four columns touch up to three
+    cells), cells that are not multiples of four, and image widths that are not multiples of four (the strip's last loads are
+    clamped and unaligned)."""
+    rng = np.random.default_rng(w * 1000 + h)
+    base = rng.integers(0, 256, (h // 6 + 1, w // 6 + 1), dtype=np.uint8)
+    img = np.kron(base, np.ones((6, 6), np.uint8))[:h, :w].copy()
+    img = (img.astype(np.int32) + rng.integers(-9, 10, img.shape)).clip(0, 255).astype(np.uint8)
+    s, _ = _stream(gpu_ctx, oracle, w, h)
+    s.push_stereo(img, img)
+    got, ref = s.cell_maxima(), oracle.cell_maxima(img)
+    for k in ("score", "x", "y"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert (ref["score"] > 0).sum() > 20
+    for lvl in range(4):
+        assert np.array_equal(s.get_level(1, lvl), oracle.build_pyramid(img)[lvl])
+    s.close()
+
+
 @pytest.mark.parametrize("n_clones,n_feat", [(29, 4), (13, 4), (24, 4), (30, 4), (10, 2), (19, 3)])
 def test_ekf_update_ill_conditioned(gpu_ctx, oracle, n_clones, n_feat):
     """Few features over many clones: the stacked Jacobian is rank deficient beyond the gauge and cond(H) ~ 1e6-1e7.
