@@ -383,8 +383,9 @@ def main(argv=None):
     # host work between its device calls (observation tables, update descriptors): it gets a helper thread when the
     # cores are there (measured: 86.7 k -> 90.0 k stereo frames/s on the pool's 16-core share; round 3, with the device
     # the limit: two helpers shorten the host phases by a third and the device waits grow by as much, 99 k vs 103 k)
-    if "MSKF_EKF_HOST_THREADS" not in os.environ and args.host_threads == 1 and 2 * args.groups * local_world <= host_cores_available():
-        os.environ["MSKF_EKF_HOST_THREADS"] = "3" if local_world == 1 and host_cores_available() >= 16 else "2"
+    ekf_host_threads = int(os.environ.get("MSKF_BENCH_EKF_HOST_THREADS", "0"))
+    if not ekf_host_threads and args.host_threads == 1 and 2 * args.groups * local_world <= host_cores_available():
+        ekf_host_threads = 3 if local_world == 1 and host_cores_available() >= 16 else 2
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -429,7 +430,7 @@ def main(argv=None):
         base, on_device = d_frames.data_ptr(), 2              # borrowed in place
         del frames                                            # the host copy (GBs per rank) is not needed any more
     calib = syns[0].calib
-    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads)
+    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads, ekf_host_threads=ekf_host_threads)
     # pose_out.txt / path_ / points3d_ growth (msckf_vio.cpp:1296-1302, Q20) is off for the batch; the streams whose
     # trajectories are compared with the CPU oracle after the run keep theirs
     run.keep_trajectory(False)
@@ -516,6 +517,7 @@ def main(argv=None):
     n_clones = run.num_clones(0)
     n_upd = run.num_updates(0)
 
+    status = 0
     if rank == 0:
         value = frames_total / elapsed
         # ---- roofline of the dominant kernel (largest HIP-event time inside the timed region)
@@ -614,7 +616,10 @@ def main(argv=None):
                                       window=round(sum(w["ekf_close"] - w["ekf_open"] for w in windows) * 1e3 / args.steps / n_groups, 3)),
                 "frames_started_in_window": {"front_end": int(sum(w["fe_frames"] for w in windows)), "filter": int(sum(w["ekf_frames"] for w in windows)),
                                              "counted": args.steps * n_groups},
-                "frames_run_by_group": frames_by_group,      # each >= W + K; the spread is how unevenly the groups' queues were served
+                # each >= W + K: a batch finishes its own frames and keeps stepping (drain) until the window has closed; how far
+                # the batches were apart INSIDE the window is frames_completed_at_close_by_group (sums to groups x (W + K))
+                "frames_run_by_group": frames_by_group,
+                "frames_completed_at_close_by_group": [int(w["frames_at_close"]) for w in windows],
                 "stage_ms_per_frame_by_group": {"front_end": [round((w["fe_close"] - w["fe_open"]) * 1e3 / max(w["fe_frames"], 1), 2) for w in windows],
                                                 "filter": [round((w["ekf_close"] - w["ekf_open"]) * 1e3 / max(w["ekf_frames"], 1), 2) for w in windows]},
                 "run_wall_ms": round(wall_run * 1e3, 1),
@@ -641,9 +646,9 @@ def main(argv=None):
                        "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1), "kernel_timing_period": timing_period,
                        "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
-                       "filter_host_threads_per_group": int(os.environ.get("MSKF_EKF_HOST_THREADS", args.host_threads)),
+                       "filter_host_threads_per_group": ekf_host_threads or args.host_threads,
                        "scheduler": ("balanced: a group's queues and threads take, frame by frame, the batch of streams that is furthest behind"
-                                     if (pipe and n_groups > 1 and os.environ.get("MSKF_BALANCE", "1")[0] != "0") else "fixed: every batch of streams on its own group's queues"),
+                                     if (pipe and n_groups > 1) else "fixed: every batch of streams on its own group's queues"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "id_mismatch": id_mismatch,
             "roofline": roof, "mfma": mfma, "kernels": kernels,
@@ -665,13 +670,32 @@ def main(argv=None):
                 out["pose_err_vs_cpu_ref"] = {"max_dp_m": max(p_["max_dp_m"] for p_ in pcs), "max_dq_rad": max(p_["max_dq_rad"] for p_ in pcs),
                                               "streams": max(p_.get("streams", 1) for p_ in pcs), "tolerance": 1e-4}
                 out["pose_within_tolerance"] = bool(out["pose_err_vs_cpu_ref"]["max_dp_m"] <= 1e-4 and out["pose_err_vs_cpu_ref"]["max_dq_rad"] <= 1e-4)
-                if not out["pose_within_tolerance"]:
-                    sys.stderr.write("bench.py: POSE CHECK FAILED against the CPU oracle: %s\n" % json.dumps(out["pose_err_vs_cpu_ref"]))
+        # a run whose results are wrong has no headline: every check that was made must hold, or the exit status says so
+        failed = []
+        if id_mismatch:
+            failed.append("id_mismatch=%d (sentinel stream differs across ranks)" % id_mismatch)
+        chk = out.get("id_check_vs_oracle") or {}
+        for k in ("ids_equal", "lifetimes_equal", "pixels_equal"):
+            if k in chk and not chk[k]:
+                failed.append("id_check_vs_oracle.%s" % k)
+        for k in ("pose_stream0", "pose_batch"):
+            if k in chk and chk[k].get("stamps_equal") is False:
+                failed.append("id_check_vs_oracle.%s.stamps_equal" % k)
+        if out.get("pose_within_tolerance") is False:
+            failed.append("pose_within_tolerance %s" % json.dumps(out["pose_err_vs_cpu_ref"]))
+        out["checks_failed"] = failed
         print(json.dumps(out), flush=True)
+        if failed:
+            sys.stderr.write("bench.py: RESULT CHECKS FAILED: %s\n" % "; ".join(failed))
+            status = 1
     run.close()
     if world > 1:
+        # every rank leaves with rank 0's verdict (a launcher sees one status)
+        t = torch.tensor([status], dtype=torch.int32, device=red_dev)
+        dist.broadcast(t, src=0)
+        status = int(t.item())
         dist.destroy_process_group()
-    return 0
+    return status
 
 
 if __name__ == "__main__":

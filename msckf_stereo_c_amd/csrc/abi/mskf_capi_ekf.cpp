@@ -63,6 +63,7 @@ struct EkfExtra {  // lives behind EkfStreamState via the stream (kept out of th
     size_t small_cap = 0;
     hipEvent_t small_done = nullptr;
     bool small_pending = false;
+    std::vector<double *> retired_hs; // stacked-Jacobian blocks from hipMalloc that were outgrown: freed with the stream (hipFree inside a run waits for the whole device)
 };
 static EkfExtra *extra_of(mskf_stream *s) { return (EkfExtra *)s->ekf_extra; }
 
@@ -99,8 +100,10 @@ int mskf_ekf_stream_init(mskf_stream *s) {
         E.chi2 = q;
     }
     {
-        // stacked Jacobian + row masks: the lost-feature stack is capped at max_stack_rows + one block, the pruning stack is
-        // five rows per feature the map can hold (every live grid slot); sized once so that a run does not grow it
+        // stacked Jacobian + row masks: the APPLIED lost-feature stack is capped at max_stack_rows + one block and the pruning
+        // stack is five rows per feature the map can hold (every live grid slot), which is what this first block is sized for.
+        // The rows are laid out BEFORE the cap, though (every lost feature's block has its place): a frame that loses most of
+        // its features at once (a blackout) needs more and grows the buffer, stream-ordered (mskf_ekf_update_batch_begin)
         const int live = s->fe.grid_row * s->fe.grid_col * std::max(s->fe.grid_max_feature_num, 1) + 64;
         const int cap = std::min(kMaxRows, std::max(std::max(2048, s->ekf.max_stack_rows + 4 * E.max_clones + 64), 5 * live));
         if ((rc = dev_alloc(&E.Hs, (size_t)cap * E.ld + (size_t)cap, st)) != MSKF_OK) return rc;
@@ -125,6 +128,7 @@ void mskf_ekf_stream_free(mskf_stream *s) {
     if (E.h_out) (void)hipHostFree(E.h_out);
     if (E.d_out) (void)hipFree(E.d_out);
     if (EkfExtra *X = extra_of(s)) {
+        for (double *p : X->retired_hs) (void)hipFree(p);
         if (X->h_small) (void)hipHostFree(X->h_small);
         if (X->d_small) (void)hipFree(X->d_small);
         if (X->small_done) (void)hipEventDestroy(X->small_done);
@@ -565,11 +569,17 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             // group that grows a buffer in the middle of a run then waits until every other group's queue is idle (measured in
             // the round-3 bench: the two groups that met their largest pruning update inside the timed window stood still for
             // 0.3 s each).  The first allocation is sized for what a stream of this configuration can stack (stream init).
-            if (E.Hs) MSKF_HIPCHK(hipFreeAsync(E.Hs, st));      // (rs lives behind Hs in the same allocation)
-            E.Hs = E.rs = nullptr;
+            // The new block is allocated FIRST: if that fails the call fails with the stream's buffers as they were (a later,
+            // smaller update still finds a valid Hs of max_rows rows).  The old block goes back to the pool it came from: a
+            // stream-ordered free for a stream-ordered block, retirement until the stream is destroyed for the first one
+            // (hipMalloc'ed at stream creation; hipFreeAsync does not take such a pointer without a device-wide wait).
             const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
-            MSKF_HIPCHK(hipMallocAsync((void **)&E.Hs, ((size_t)cap * E.ld + (size_t)cap) * sizeof(double), st));
-            MSKF_HIPCHK(hipMemsetAsync(E.Hs, 0, ((size_t)cap * E.ld + (size_t)cap) * sizeof(double), st));
+            const size_t bytes = ((size_t)cap * E.ld + (size_t)cap) * sizeof(double);
+            double *grown = nullptr;
+            MSKF_HIPCHK(hipMallocAsync((void **)&grown, bytes, st));
+            if (hipMemsetAsync(grown, 0, bytes, st) != hipSuccess) { (void)hipFreeAsync(grown, st); mskf_set_error("hipMemsetAsync of the grown stacked-Jacobian buffer failed"); return MSKF_ERR_HIP; }
+            if (E.Hs) { if (E.hs_async) (void)hipFreeAsync(E.Hs, st); else extra_of(s)->retired_hs.push_back(E.Hs); }      // (rs lives behind Hs in the same allocation)
+            E.Hs = grown;
             E.rs = E.Hs + (size_t)cap * E.ld;
             E.max_rows = cap;
             E.hs_async = true;

@@ -29,17 +29,6 @@ extern "C" int mskf_ctx_create_prio(int device, int high_priority, mskf_ctx **ou
     mskf_ctx *c = new mskf_ctx();
     c->device = device;
     hipError_t e;
-    // Experiment switch MSKF_CU_SPLIT=n: the urgent (filter) contexts get a stream restricted to the first n compute units of
-    // the device's mask order and the others the rest, so that the filter's short serial kernels never share a SIMD with
-    // the front-end's wide ones (hipExtStreamCreateWithCUMask; such a stream has no priority).
-    static const int cu_split = [] { const char *v = std::getenv("MSKF_CU_SPLIT"); return v ? std::atoi(v) : 0; }();
-    int n_cu = 0;
-    if (cu_split > 0) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
-    if (cu_split > 0 && cu_split < n_cu) {
-        uint32_t mask[16] = {0};
-        for (int k = 0; k < n_cu && k < 512; ++k) if ((k < cu_split) == (high_priority != 0)) mask[k >> 5] |= 1u << (k & 31);
-        e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)((n_cu + 31) / 32), mask);
-    } else
     if (high_priority) {
         int lo = 0, hi = 0;   // numerically lower = more urgent
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -89,6 +78,7 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
 }
 
 extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hipStream_t st);
+extern "C" size_t fe_book_lds_budget(void);
 
 int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
     if (c->wait_block) {
@@ -111,9 +101,9 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
     volatile unsigned int *w = c->flag_h + 16 * k;
     if (record) {
         // the mark is a stream write-value command (no dispatch: a one-thread kernel waits 37 us for a CU slot on a busy
-        // device, profiles/r02_kernel_stats.csv of the kernel-mark build); MSKF_MARK=kernel, or a runtime that refuses the
-        // command on pinned host memory, falls back to the one-thread kernel k_mark
-        static std::atomic<bool> use_write{[] { const char *e = std::getenv("MSKF_MARK"); return !(e && e[0] == 'k'); }()};   // (contexts are driven from several host threads)
+        // device, profiles/r02_kernel_stats.csv of the kernel-mark build); a runtime that refuses the command on pinned host
+        // memory falls back to the one-thread kernel k_mark
+        static std::atomic<bool> use_write{true};   // (contexts are driven from several host threads)
         ++c->flag_seq[k];
         if (use_write.load(std::memory_order_relaxed)) {
             if (hipStreamWriteValue32(c->stream, (void *)w, c->flag_seq[k], 0) == hipSuccess) return MSKF_OK;
@@ -189,6 +179,12 @@ int mskf_t_begin(mskf_ctx *c, int kind) {
 void mskf_t_end(mskf_ctx *c, int slot, long long units) {
     if (slot < 0) return;
     (void)hipEventRecord(c->t_pending[slot].b, c->stream);
+    c->t_pending[slot].units = units;
+}
+// Units of a slot that was begun earlier: the slot index is only valid until the next mskf_t_collect (any synchronising
+// call of the context collects), so it is checked against the pending list and the kind it was begun with.
+void mskf_t_set_units(mskf_ctx *c, int slot, int kind, long long units) {
+    if (slot < 0 || (size_t)slot >= c->t_pending.size() || c->t_pending[slot].kind != kind) return;
     c->t_pending[slot].units = units;
 }
 void mskf_t_collect(mskf_ctx *c) {
@@ -271,6 +267,9 @@ static int book_alloc(mskf_stream *s) {
     const int cap = K.n_codes * std::max(fe.grid_max_feature_num, 1) + 8;
     const int cand_cap = K.n_cells * std::max(fe.grid_max_feature_num, 1) + 8;
     const int det_cap = fe.det_rows * fe.det_cols;
+    // the bookkeeping kernel keeps its lists in LDS: a configuration whose lists do not fit the budget the kernel can get
+    // (a very fine detector grid) keeps its books on the host
+    if (4 * fe_book_scratch_ints(cap, cand_cap, det_cap, K.n_codes, det_cap) > fe_book_lds_budget()) return MSKF_OK;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_st = take(sizeof(FeBookState));
@@ -448,6 +447,8 @@ extern "C" int mskf_fe_push_stereo_batch(mskf_ctx *ctx, int n, mskf_stream *cons
 // copy_cells = false: the per-cell maxima stay on the device (the bookkeeping kernel of a device frame reads them there)
 static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0, const uint8_t *const *cam1, int on_device, bool copy_cells) {
     if (!ctx || n <= 0 || !streams || !cam0 || !cam1) return MSKF_ERR_INVALID;
+    // the pinned staging of a pending batch (descriptors, pyramid jobs, the cell arena) may still be in flight
+    if (ctx->pend_frame.active || ctx->pend_trk.active) { mskf_set_error("a batch of this context is still pending"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc = ctx->jobs.ensure((size_t)n * 2 * (MSKF_LEVELS - 1));
@@ -632,6 +633,7 @@ extern "C" int mskf_fe_track_batch(mskf_ctx *ctx, int n, mskf_stream *const *str
 extern "C" int mskf_fe_track_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, const mskf_fe_track_args *args) {
     if (!ctx || n <= 0 || !streams || !args) return MSKF_ERR_INVALID;
     if (ctx->pend_trk.active) { mskf_set_error("a track batch of this context is still pending (call mskf_fe_track_batch_end)"); return MSKF_ERR_INVALID; }
+    if (ctx->pend_frame.active) { mskf_set_error("a device frame of this context is still pending (call mskf_fe_frame_batch_end)"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     const auto t_h0 = std::chrono::steady_clock::now();
     hipStream_t st = ctx->stream;
@@ -722,7 +724,7 @@ extern "C" int mskf_fe_track_batch_end(mskf_ctx *ctx) {
         if (a.do_temporal) { tracks_t += (long long)np; for (size_t k = 0; k < np; ++k) tracks_s += (a.status[k] & 1); }
         else tracks_s += (long long)np;
     }
-    if (ts >= 0) ctx->t_pending[ts].units = tracks_t + tracks_s;      // point tracks of the launch: temporal + stereo
+    mskf_t_set_units(ctx, ts, MSKF_K_LK, tracks_t + tracks_s);      // point tracks of the launch: temporal + stereo
     (void)pts;
     mskf_t_collect(ctx);
     if (ctx->t_gate) ctx->host_s[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
@@ -918,8 +920,8 @@ extern "C" int mskf_fe_frame_batch_end(mskf_ctx *ctx) {
         tracks2 += a.n_candidates;
         K.n_prev = m; K.n_cand_last = a.n_candidates;
     }
-    if (F.ts1 >= 0) ctx->t_pending[F.ts1].units = tracks1;
-    if (F.ts2 >= 0) ctx->t_pending[F.ts2].units = tracks2;
+    mskf_t_set_units(ctx, F.ts1, MSKF_K_LK, tracks1);
+    mskf_t_set_units(ctx, F.ts2, MSKF_K_LK, tracks2);
     mskf_t_collect(ctx);
     if (ctx->t_gate) ctx->host_s[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h1).count();
     if (overflow) { mskf_set_error("device bookkeeping reported a capacity overflow"); return MSKF_ERR_CAPACITY; }

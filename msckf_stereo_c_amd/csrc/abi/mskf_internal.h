@@ -168,6 +168,7 @@ struct mskf_stream {
 int mskf_t_begin(mskf_ctx *c, int kind);
 void mskf_t_end(mskf_ctx *c, int slot, long long units);
 void mskf_t_collect(mskf_ctx *c);   // call after the stream has been synchronised
+void mskf_t_set_units(mskf_ctx *c, int slot, int kind, long long units);   // units of a slot begun earlier (bounds- and kind-checked)
 void fill_pyr(const mskf_stream *s, int idx, PyrDev &p);
 int mskf_ekf_stream_init(mskf_stream *s);
 void mskf_ekf_stream_free(mskf_stream *s);

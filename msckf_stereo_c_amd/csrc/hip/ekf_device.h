@@ -5,16 +5,6 @@
 #include "../../../include/mskf_hip.h"
 
 #define EKF_IMU_DIM 21
-// The filter's kernels are the serial chain of a frame (a dozen short, latency-bound launches per update) and share the
-// device with the front-end's wide, VALU-bound kernels of the other groups.  -DEKF_WAVE_PRIO lets their waves ask for the
-// highest issue priority (s_setprio 3), so that on a SIMD they share with track / detector waves they are served first (the
-// stream priority only orders the dispatch).  Measured in round 3 on the default bench: 90.3 k / 94.9 k stereo frames/s
-// (20 / 60 steps) with it, 90.5 k / 97.6 k without: no gain, so it is off.
-#ifdef EKF_WAVE_PRIO
-#define EKF_PRIO() __builtin_amdgcn_s_setprio(3)
-#else
-#define EKF_PRIO() ((void)0)
-#endif
 #define EKF_SLOTS 64          // feature workgroups per stream and launch (each loops over its features)
 
 // Per feature of one update (device copy of mskf_ekf_feature + row offset of its block)

@@ -115,7 +115,6 @@ __device__ __forceinline__ void build_phi_q(const mskf_imu_step &st, const doubl
 // Phi_k, Q_k of every IMU step of every stream, one workgroup per (step, stream): they do not depend on the
 // covariance, so only the P recursion itself stays serial in k_ekf_propagate.
 __global__ __launch_bounds__(WG) void k_ekf_phiq(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     const int step = blockIdx.x;
     if (step >= S.n_steps || !S.imu_steps || !S.PhiQ) return;
@@ -132,7 +131,6 @@ __global__ __launch_bounds__(WG) void k_ekf_phiq(const EkfStreamDev *streams) {
 // P_CI <- P_IC^T.  With S.J set the state augmentation (rows/cols [d, d+6) = J [P_II P_IC], corner
 // sym(J P_II J^T)) is fused into the same pass.
 __global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_steps <= 0 && !S.J) return;
     double *P = S.P;
@@ -215,7 +213,6 @@ __global__ __launch_bounds__(WG) void k_ekf_propagate(const EkfStreamDev *stream
 // ------------------------------------------------------------------------------------ augment
 // rows/cols [d, d+6): [J P11, J P12], corner sym(J P11 J^T)
 __global__ __launch_bounds__(WG) void k_ekf_augment(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (!S.J) return;
     double *P = S.P;
@@ -247,7 +244,6 @@ __global__ __launch_bounds__(WG) void k_ekf_augment(const EkfStreamDev *streams)
 // ------------------------------------------------------------------------------------ remove clone
 // out-of-place: P_dst <- P with the rows/cols of one or two clones removed
 __global__ __launch_bounds__(WG) void k_ekf_remove_clone(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.remove_index < 0 || !S.P_dst) return;
     const int d = S.d, ld = S.ld;
@@ -265,7 +261,6 @@ __global__ __launch_bounds__(WG) void k_ekf_remove_clone(const EkfStreamDev *str
 // ------------------------------------------------------------------------------------ position variances
 // P(12,12), P(13,13), P(14,14) of every stream of the batch (onlineReset, msckf_vio.cpp:1194-1196)
 __global__ void k_ekf_posvar(const EkfStreamDev *streams, int n, double *out) {
-    EKF_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n) return;
     const EkfStreamDev &S = streams[i / 3];
@@ -275,7 +270,6 @@ __global__ void k_ekf_posvar(const EkfStreamDev *streams, int n, double *out) {
 
 // the same at the end of an update batch, into every stream's own result slot (mskf_ekf_update_args.pos_var_out)
 __global__ void k_ekf_posvar_upd(const EkfStreamDev *streams, int n) {
-    EKF_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n) return;
     const EkfStreamDev &S = streams[i / 3];
@@ -466,7 +460,6 @@ __device__ __forceinline__ size_t pk(int i, int j) { return (size_t)i * (i + 1) 
 #define FEAT_SMALL_CLONES 16
 template <int MAXC, bool WAVE, int TPB>
 __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDev *streams, const int *work, int n_work, int lds_rows, int arena_doubles, int cls_lo, int cls_hi) {
-    EKF_PRIO();
     constexpr int GS = WAVE ? 64 : TPB;         // threads per feature
     constexpr int NSUB = TPB / GS;              // features side by side in a workgroup
     const int gt = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -883,7 +876,6 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
 // Q^T [H_x | r] written in the twelve columns of the two clones + the residual column, gate on
 // gamma = r_o^T (H_o P_cc H_o^T + sigma^2 I)^-1 r_o against chi2[2 + dof_offset].
 __global__ __launch_bounds__(64) void k_ekf_triangulate(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (!(S.route & 1)) return;        // not a pair-route stream (the route is a property of the stream, ekf_device.h)
     __shared__ TriScratch sTri;
@@ -902,7 +894,6 @@ __global__ __launch_bounds__(64) void k_ekf_triangulate(const EkfStreamDev *stre
 
 #define PAIR_SLAB 153          // doubles per thread: X 8 x 13 (104) + H_f 8 x 3 (24) + V 3 x 8 (24) + 1 (odd stride: no bank conflicts)
 __global__ __launch_bounds__(64) void k_ekf_pair_blocks(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (!(S.route & 1)) return;
     const int d = S.d, ld = S.ld;
@@ -1108,7 +1099,6 @@ __global__ __launch_bounds__(64) void k_ekf_pair_blocks(const EkfStreamDev *stre
 // cap ends the stack.  Also produced here: the rowmask of every row (what k_ekf_gemm<GRAM> may read), the active
 // column list and the counters rows_out[0..2].
 __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     const int nf = S.n_feat;
     if (nf <= 0) return;

@@ -79,7 +79,6 @@ template <> struct GemmTraits<GM_PUPD> { static constexpr bool TA = true,  SYM =
 // round trip instead of an HBM/L2 round trip.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
-    EKF_PRIO();
     using TR = GemmTraits<MODE>;
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
@@ -354,7 +353,6 @@ __device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gr
 // last rows, columns [n, n+16) of the ld-wide row (ld - n >= 21: the IMU columns are not part of the compact block).
 #define CHOLG_THREADS 512
 __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *streams, int which, int pan_rs) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
@@ -442,7 +440,6 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 
 __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
@@ -548,7 +545,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
 #define TS_COLS 32
 #define TS_RB 16
 __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     const int n = S.rows_out[4], ld = S.ld, ncols = S.d + 1;      // rows of the compressed measurement, all d+1 columns
@@ -643,7 +639,6 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
 #define SU_MAX_NA 24
 #define SU_CH 128         // stacked rows per Gram chunk
 __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *streams) {
-    EKF_PRIO();
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || !(S.route & EKF_ROUTE_SMALL)) return;
     const int d = S.d, ld = S.ld, na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1];

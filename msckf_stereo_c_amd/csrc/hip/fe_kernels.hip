@@ -336,12 +336,11 @@ __global__ __launch_bounds__(64) void k_detect_cells(const FeStreamDev *streams,
 
 extern "C" void fe_launch_detect(const FeStreamDev *streams_dev, int n_streams, int max_w, int max_h, unsigned int gen, hipStream_t st) {
     // rows per segment: short segments give more wavefronts (a launch should fill the device several times over) but every
-    // segment pays seven window-filling rows; MSKF_DETECT_SEG_ROWS overrides the choice
-    static const int seg_env = [] { const char *e = getenv("MSKF_DETECT_SEG_ROWS"); return e ? atoi(e) : 0; }();
+    // segment pays seven window-filling rows
     const int strips = (max_w - 2 * DET_BORDER + DS_COLS - 1) / DS_COLS, rows = max_h - 2 * DET_BORDER;
     if (strips <= 0 || rows <= 0) return;
-    int seg_rows = seg_env > 0 ? seg_env : 32;
-    if (seg_env <= 0) while (seg_rows < 128 && (long long)n_streams * strips * ((rows + seg_rows - 1) / seg_rows) / 4 > 32768) seg_rows *= 2;
+    int seg_rows = 32;
+    while (seg_rows < 128 && (long long)n_streams * strips * ((rows + seg_rows - 1) / seg_rows) / 4 > 32768) seg_rows *= 2;
     const int segs = (rows + seg_rows - 1) / seg_rows;
     const int waves = (strips * segs + 3) / 4;
     hipLaunchKernelGGL(k_detect_cells, dim3(8 * ((n_streams + 7) / 8) * waves), dim3(64), 0, st, streams_dev, n_streams, strips, seg_rows, waves, gen);
@@ -847,9 +846,6 @@ __device__ __forceinline__ void l4_track(const PyrDev &A, const PyrDev &B, bool 
 // stereo match accepted; a point that fails the temporal half gets out1 = und0 = und1 = 0 and status 0.
 // Block -> (stream, point group): the blocks b and b + 8 share an XCD (round-robin dispatch, speed only), so the point
 // groups of ONE stream are given ids that are congruent modulo 8: a stream's pyramid levels then travel through one L2.
-#ifdef TRACK_WAVES
-__attribute__((amdgpu_waves_per_eu(TRACK_WAVES, TRACK_WAVES)))
-#endif
 __global__ __launch_bounds__(64) void k_track4(const FeStreamDev *streams, int n_streams, int groups_per_stream) {
     const int x = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int si = x + 8 * (qb / groups_per_stream), gi = qb - (qb / groups_per_stream) * groups_per_stream;
@@ -956,10 +952,18 @@ __global__ __launch_bounds__(256) void k_fe_book(const FeBookDev *books, int whi
     fe_book_scratch_init(L, s_book, B.cap, B.cand_cap, B.det_cap, B.n_codes, B.det_rows * B.det_cols);
     if (which == 0) fe_book1(B, L); else fe_book2(B, L);
 }
+// Dynamic LDS the bookkeeping kernel may use: 150 KiB once the attribute is granted (the 4K configuration's lists need more
+// than the 64 KiB a kernel gets by default), 64 KiB otherwise.  mskf_stream_create sizes the device books against it.
+extern "C" size_t fe_book_lds_budget(void) {
+    static const size_t budget = []() -> size_t {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fe_book), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) { (void)hipGetLastError(); return 64 * 1024; }
+        return 150 * 1024;
+    }();
+    return budget;
+}
 extern "C" void fe_launch_book(const FeBookDev *books_dev, int n_streams, int which, size_t scratch_bytes, hipStream_t st) {
-    // (the 4K configuration's lists need more than the 64 KiB a kernel gets by default)
-    static std::once_flag attr_once;
-    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fe_book), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+    (void)fe_book_lds_budget();
     hipLaunchKernelGGL(k_fe_book, dim3(n_streams), dim3(256), scratch_bytes, st, books_dev, which);
 }
 
@@ -976,8 +980,5 @@ extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hi
 extern "C" void fe_launch_track(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st) {
     if (max_pts <= 0) return;
     const int gps = (max_pts + 3) / 4;
-    // MSKF_TRACK_LDS_PAD=bytes (experiment): unused dynamic LDS per one-wave workgroup, which caps the waves of this kernel on
-    // a CU (160 KB / (3.7 KB + pad)) and so leaves registers and wave slots to the filter's kernels of the other groups
-    static const unsigned pad = [] { const char *e = getenv("MSKF_TRACK_LDS_PAD"); const long v = e ? atol(e) : 0; return (unsigned)(v > 0 && v < 60000 ? v : 0); }();
-    hipLaunchKernelGGL(k_track4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), pad, st, streams_dev, n_streams, gps);
+    hipLaunchKernelGGL(k_track4, dim3(8 * ((n_streams + 7) / 8) * gps), dim3(64), 0, st, streams_dev, n_streams, gps);
 }

@@ -43,29 +43,19 @@ void ForkJoin::run(int n, const std::function<void(int)> &fn) {
     while (done_.load() < nt_ - 1) std::this_thread::yield();
 }
 
-BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads, mskf_ctx *fe_queue) {
-    // per-stream host phases of a group are independent: optional helper threads for the front-end / filter halves
-    // (MSKF_FE_HOST_THREADS / MSKF_EKF_HOST_THREADS override the common host_threads argument)
-    int ht_fe = host_threads, ht_ekf = host_threads;
-    if (const char *e = std::getenv("MSKF_FE_HOST_THREADS")) ht_fe = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("MSKF_EKF_HOST_THREADS")) ht_ekf = std::max(1, std::atoi(e));
+BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads, int ekf_host_threads, int halves) {
+    // per-stream host phases of a group are independent: optional helper threads for the front-end / filter stages
+    const int ht_fe = std::max(1, host_threads), ht_ekf = std::max(1, ekf_host_threads > 0 ? ekf_host_threads : host_threads);
     if (ht_fe > 1) pool_.reset(new ForkJoin(ht_fe));
     if (ht_ekf > 1) pool_ekf_.reset(new ForkJoin(ht_ekf));
-    // one batch per group and stage.  MSKF_HALVES=2 splits it into two staggered half-batches (one half's host phase under
-    // the other's kernels): measured 54.5k vs 70.6k stereo frames/s at 8 groups x 192 streams, since the other groups
-    // already fill those gaps and twice the launches of half the size cost more than the overlap returns; it is kept
-    // for a single-group deployment.
-    int nh = 1;
-    if (const char *e = std::getenv("MSKF_HALVES")) nh = std::max(1, std::min(2, std::atoi(e)));
+    // one batch per group and stage; halves = 2 splits it into two staggered half-batches (one half's host phase under the
+    // other's kernels) for a single-group deployment.  With several groups the other groups already fill those gaps and
+    // twice the launches of half the size cost more than the overlap returns (54.5 k vs 70.6 k stereo frames/s, round 2).
+    int nh = std::max(1, std::min(2, halves));
     if (n < 2) nh = 1;
     half_.resize(nh);
-    int rc = fe_queue ? mskf_ctx_create_shared(fe_queue, &half_[0].ctx) : mskf_ctx_create(device, &half_[0].ctx);
-    if (rc == MSKF_OK) {
-        const char *pe = std::getenv("MSKF_EKF_PRIORITY");   // default on; MSKF_EKF_PRIORITY=0 disables
-        rc = mskf_ctx_create_prio(device, !(pe && pe[0] == '0'), &half_[0].ctx_ekf);
-    }
-    // MSKF_FE_WAIT=block: the front-end stage parks in its one wait per frame (device frames) instead of spinning on it
-    if (rc == MSKF_OK) { const char *fw = std::getenv("MSKF_FE_WAIT"); if (fw && fw[0] == 'b') mskf_ctx_set_wait_mode(half_[0].ctx, 1); }
+    int rc = mskf_ctx_create(device, &half_[0].ctx);
+    if (rc == MSKF_OK) rc = mskf_ctx_create_prio(device, 1, &half_[0].ctx_ekf);     // the filter is the serial chain of a frame: its queue is dispatched first
     for (int h = 1; h < nh && rc == MSKF_OK; ++h) {
         rc = mskf_ctx_create_shared(half_[0].ctx, &half_[h].ctx);
         if (rc == MSKF_OK) rc = mskf_ctx_create_shared(half_[0].ctx_ekf, &half_[h].ctx_ekf);
@@ -383,7 +373,7 @@ void BatchGroup::rebind_home() {
 
 // front-end stage of frame k on a borrowed context (the caller has made sure nothing of this batch's front-end is in flight)
 int BatchGroup::fe_stage(mskf_ctx *ctx, int k, double *acc, std::unique_ptr<FrameBatch> &out) {
-    if (half_.size() != 1) { error_ = "the balanced runner needs one batch per stage (MSKF_HALVES=1)"; return MSKF_ERR_UNSUPPORTED; }
+    if (half_.size() != 1) { error_ = "the balanced runner needs one batch per stage (halves = 1)"; return MSKF_ERR_UNSUPPORTED; }
     if (half_[0].ctx != ctx) { half_[0].ctx = ctx; for (mskf_stream *s : streams_) mskf_stream_rebind(s, ctx, nullptr); }
     acc_fe_ = acc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -401,7 +391,7 @@ int BatchGroup::fe_stage(mskf_ctx *ctx, int k, double *acc, std::unique_ptr<Fram
 // filter stage of a handed-off frame on a borrowed context.  The stage ends with work it does not wait for (clone removal):
 // when the next frame of this batch runs on another context, that context's queue is ordered behind it.
 int BatchGroup::ekf_stage(mskf_ctx *ctx, FrameBatch *fb, double *acc) {
-    if (half_.size() != 1) { error_ = "the balanced runner needs one batch per stage (MSKF_HALVES=1)"; return MSKF_ERR_UNSUPPORTED; }
+    if (half_.size() != 1) { error_ = "the balanced runner needs one batch per stage (halves = 1)"; return MSKF_ERR_UNSUPPORTED; }
     if (half_[0].ctx_ekf != ctx) { half_[0].ctx_ekf = ctx; for (mskf_stream *s : streams_) mskf_stream_rebind(s, nullptr, ctx); }
     if (ekf_tail_ && ekf_tail_ctx_ && ekf_tail_ctx_ != ctx) { const int wrc = mskf_ctx_wait_point(ctx, ekf_tail_); if (wrc != MSKF_OK) { error_ = mskf_last_error(); return wrc; } }
     acc_ekf_ = acc;
@@ -422,7 +412,7 @@ void BatchGroup::set_gates(bool on) {
     for (Half &H : half_) { mskf_ctx_timing_gate(H.ctx, on ? 1 : 0); mskf_ctx_timing_gate(H.ctx_ekf, on ? 1 : 0); }
 }
 
-int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *pacer, int pacer_slot) {
+int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win) {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<FrameBatch>> queue;
@@ -430,7 +420,7 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
     bool producer_done = false;
     std::atomic<int> ekf_rc{MSKF_OK};
     std::string ekf_err;
-    static const int fe_phases[] = {PH_PUSH, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_IMU, PH_HANDOFF, PH_FE_QWAIT, PH_FE_PACE};
+    static const int fe_phases[] = {PH_PUSH, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_IMU, PH_HANDOFF, PH_FE_QWAIT};
     static const int ekf_phases[] = {PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_EKF_QWAIT, PH_IMU_EKF};
     // a stage opens / closes its own accounting: kernel timing of its contexts, the host-profile slots of its thread, and the
     // phase times it owns (difference between the two marks)
@@ -476,7 +466,7 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
                 // the frame is through both stages: it counts; the thread that completes the opening / closing frame stamps the window
                 const long c = sh->completed.fetch_add(1) + 1;
                 if (c == sh->target_open) { sh->t_open = now_s(); sh->phase.store(1, std::memory_order_release); }
-                if (c == sh->target_close) { sh->t_close = now_s(); sh->phase.store(2, std::memory_order_release); }
+                if (c == sh->target_close) { sh->t_close = now_s(); sh->phase.store(2, std::memory_order_release); win->frames_at_close = fb->frame + 1 - first; }
             }
             if (win && fb->frame == win->mark_end - 1) {
                 if (rc == MSKF_OK) snapshot_ekf_mark();
@@ -496,15 +486,6 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
             if (!sh || sh->phase.load() == 2 || k >= first + n_frames + win->max_extra) break;
         }
         if (win) { follow(true, fe_mine, win->t_fe_begin, win->t_fe_end); if (fe_mine == 1) ++win->fe_frames; }
-        if (pacer && k < first + n_frames) {
-            // not more than `slack` frames ahead of the slowest group (cool-down frames are not paced: the others are finishing)
-            const double tp = now_s();
-            unsigned spins = 0;
-            while ((k - first) - pacer->slowest() > pacer->slack && ekf_rc.load() == MSKF_OK) {
-                if ((++spins & 63u) == 0) std::this_thread::yield(); else __builtin_ia32_pause();
-            }
-            phase_s[PH_FE_PACE] += now_s() - tp;
-        }
         const double ti = now_s();
         rc = feed_imu(k, true, false);
         phase_s[PH_IMU] += now_s() - ti;
@@ -529,13 +510,11 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
         }
         cv.notify_all();
         phase_s[PH_FE_QWAIT] += now_s() - tw;
-        if (pacer) pacer->done[pacer_slot].store(k + 1 >= first + n_frames ? 0x7fffffff : k + 1 - first, std::memory_order_relaxed);
         if (win && k == win->mark_end - 1) {
             snapshot_fe_mark();
         }
     }
     if (win && fe_mine == 1) { win->t_fe_end = now_s(); gate(true, false); fe_mine = 2; }
-    if (pacer) pacer->done[pacer_slot].store(0x7fffffff);      // (also on an error exit: nobody waits for this group any more)
     { std::lock_guard<std::mutex> lk(mu); producer_done = true; }
     cv.notify_all();
     consumer.join();
@@ -546,29 +525,13 @@ int BatchGroup::run_pipelined(int first, int n_frames, TimedWindow *win, Pacer *
 }
 
 MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
-                         int host_threads)
+                         int host_threads, int ekf_host_threads, int halves)
     : n_groups_(n_groups), per_group_(per_group), off_(n_groups, 0), next_(n_groups, 0), win_(n_groups) {
-    // A device offers 16 hardware queues before streams get multiplexed (GPU_MAX_HW_QUEUES).  Every group needs a queue of its own
-    // for its filter stage (the serial chain of the frame); its front-end stage is ONE device call per frame and idles most of the
-    // step, so several groups may share a front-end queue: MSKF_FE_QUEUES = n shares n front-end streams round robin among the
-    // groups (0 / unset: one per group), which lets 12 groups run on 12 + 4 queues.
-    // MSKF_DUMMY_STREAMS = k: k HIP streams created (and left idle) before the groups' own (experiment: the first streams a
-    // process creates were served measurably worse than the later ones)
-    if (const char *e = std::getenv("MSKF_DUMMY_STREAMS"))
-        for (int q = 0; q < std::atoi(e); ++q) { mskf_ctx *c = nullptr; if (mskf_ctx_create(device, &c) == MSKF_OK) { (void)mskf_ctx_sync(c); dummies_.push_back(c); } }   // (used once: the runtime binds a hardware queue at first use)
-    int nq = 0;
-    if (const char *e = std::getenv("MSKF_FE_QUEUES")) nq = std::max(0, std::atoi(e));
-    if (nq >= n_groups) nq = 0;
-    for (int q = 0; q < nq; ++q) { mskf_ctx *c = nullptr; if (mskf_ctx_create(device, &c) == MSKF_OK) fe_queues_.push_back(c); }
-    if ((int)fe_queues_.size() != nq) { for (mskf_ctx *c : fe_queues_) mskf_ctx_destroy(c); fe_queues_.clear(); nq = 0; }
-    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads, nq ? fe_queues_[g % nq] : nullptr));
+    // A device offers 16 hardware queues before streams get multiplexed (GPU_MAX_HW_QUEUES): two per group, front-end and filter
+    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads, ekf_host_threads, halves));
 }
 
-MultiRunner::~MultiRunner() {
-    groups_.clear();                                   // shared contexts first: they borrow the owners' streams
-    for (mskf_ctx *c : fe_queues_) mskf_ctx_destroy(c);
-    for (mskf_ctx *c : dummies_) mskf_ctx_destroy(c);
-}
+MultiRunner::~MultiRunner() { groups_.clear(); }
 
 bool MultiRunner::ok() const {
     for (const auto &g : groups_) if (!g->ok()) return false;
@@ -601,23 +564,7 @@ int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
         for (int g = 0; g < n_groups_; ++g) { rcs[g] = one(g); if (rcs[g] != MSKF_OK) return rcs[g]; }
         return MSKF_OK;
     }
-    if (pipelined && balance_enabled() && groups_[0]->n_halves() == 1 && pace_slack() == 0) return run_balanced(first, 0, n, 0, nullptr, true);
-    // pipelined groups are paced against each other (MSKF_PACE = slack in frames, 0 = off); catch-up runs of staggered
-    // groups have different lengths and are not
-    std::unique_ptr<Pacer> pacer;
-    {
-        bool same = pipelined;
-        std::vector<int> from(n_groups_), cnt(n_groups_);
-        for (int g = 0; g < n_groups_; ++g) { from[g] = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first; cnt[g] = first + off_[g] + n - from[g]; same = same && cnt[g] == cnt[0]; }
-        if (same && pace_slack() > 0) pacer.reset(new Pacer(n_groups_, pace_slack()));
-        if (pacer) {
-            std::vector<std::thread> th;
-            for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { next_[g] = from[g] + cnt[g]; rcs[g] = groups_[g]->run_pipelined(from[g], cnt[g], nullptr, pacer.get(), g); });
-            for (auto &t : th) t.join();
-            for (int g = 0; g < n_groups_; ++g) if (rcs[g] != MSKF_OK) return rcs[g];
-            return MSKF_OK;
-        }
-    }
+    if (pipelined && groups_[0]->n_halves() == 1) return run_balanced(first, 0, n, 0, nullptr, true);
     std::vector<std::thread> th;
     for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = one(g); });
     for (auto &t : th) t.join();
@@ -625,13 +572,8 @@ int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
     return MSKF_OK;
 }
 
-int MultiRunner::pace_slack() {
-    static const int v = [] { const char *e = std::getenv("MSKF_PACE"); const int x = e ? std::atoi(e) : 0; return x < 0 ? 0 : x; }();
-    return v;
-}
-
 int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, double *elapsed_s) {
-    if (n_groups_ > 1 && balance_enabled() && groups_[0]->n_halves() == 1) return run_balanced(first, warmup, steps, max_extra, elapsed_s);
+    if (n_groups_ > 1 && groups_[0]->n_halves() == 1) return run_balanced(first, warmup, steps, max_extra, elapsed_s);
     std::vector<int> rcs(n_groups_, MSKF_OK);
     TimedShared shared;
     shared.target_open = (long)n_groups_ * warmup;
@@ -648,14 +590,8 @@ int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, doub
         w.max_extra = max_extra;
         groups_[g]->set_gates(false);
     }
-    std::unique_ptr<Pacer> pacer;
-    {
-        bool same = true;
-        for (int g = 0; g < n_groups_; ++g) same = same && cnt[g] == cnt[0];
-        if (same && n_groups_ > 1 && pace_slack() > 0) pacer.reset(new Pacer(n_groups_, pace_slack()));
-    }
     std::vector<std::thread> th;
-    for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = groups_[g]->run_pipelined(from[g], cnt[g], &win_[g], pacer.get(), g); });
+    for (int g = 0; g < n_groups_; ++g) th.emplace_back([&, g]() { rcs[g] = groups_[g]->run_pipelined(from[g], cnt[g], &win_[g]); });
     for (auto &t : th) t.join();
     for (int g = 0; g < n_groups_; ++g) {
         next_[g] = from[g] + win_[g].frames_done;
@@ -665,11 +601,6 @@ int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, doub
     if (shared.phase.load() != 2) return MSKF_ERR_INVALID;        // the window never closed
     if (elapsed_s) *elapsed_s = shared.t_close - shared.t_open;
     return MSKF_OK;
-}
-
-bool MultiRunner::balance_enabled() {
-    static const bool v = [] { const char *e = std::getenv("MSKF_BALANCE"); return !(e && e[0] == '0'); }();
-    return v;
 }
 
 int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s, bool plain) {
@@ -704,7 +635,7 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
     // a worker's accounting follows the shared window at its frame boundaries (as a stage does in run_pipelined); the phase
     // times of worker w are kept in group w's arrays whichever batches it ran
     static const int fe_phases[] = {BatchGroup::PH_PUSH, BatchGroup::PH_PREP1, BatchGroup::PH_TRACK1, BatchGroup::PH_AFTER1, BatchGroup::PH_TRACK2,
-                                    BatchGroup::PH_AFTER2, BatchGroup::PH_IMU, BatchGroup::PH_HANDOFF, BatchGroup::PH_FE_QWAIT, BatchGroup::PH_FE_PACE};
+                                    BatchGroup::PH_AFTER2, BatchGroup::PH_IMU, BatchGroup::PH_HANDOFF, BatchGroup::PH_FE_QWAIT};
     static const int ekf_phases[] = {BatchGroup::PH_EKF_A, BatchGroup::PH_UPD1, BatchGroup::PH_EKF_B, BatchGroup::PH_UPD2, BatchGroup::PH_EKF_C,
                                      BatchGroup::PH_POSVAR, BatchGroup::PH_EKF_QWAIT, BatchGroup::PH_IMU_EKF};
     std::vector<mskf_ctx *> fe_ctx(nb), ekf_ctx(nb);      // worker w = the two contexts group w created (captured before any batch moves)
@@ -722,12 +653,9 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
         if (mine == 0 && ph >= 1) { t_begin = now_s(); gate(w, fe, true); mine = 1; }
         if (mine == 1 && ph == 2) { t_end = now_s(); gate(w, fe, false); mine = 2; }
     };
-    // Workers and batches are different things: there may be fewer workers of a kind than batches (MSKF_FE_WORKERS /
-    // MSKF_EKF_WORKERS, default one of each per batch; worker w uses the contexts group w created).  The filter stage is the longer
-    // one, so e.g. 12 batches can be served by 4 front-end and 12 filter workers on the device's 16 hardware queues.
-    int n_few = nb, n_ekw = nb;
-    if (const char *e = std::getenv("MSKF_FE_WORKERS")) n_few = std::max(1, std::min(nb, std::atoi(e)));
-    if (const char *e = std::getenv("MSKF_EKF_WORKERS")) n_ekw = std::max(1, std::min(nb, std::atoi(e)));
+    // Workers and batches are different things: there may be fewer workers of a kind than batches (set_workers; default one of
+    // each per batch; worker w uses the contexts group w created).
+    const int n_few = fe_workers_ > 0 ? std::min(nb, fe_workers_) : nb, n_ekw = ekf_workers_ > 0 ? std::min(nb, ekf_workers_) : nb;
     std::vector<std::thread> th;
     // ---- front-end workers: the batch that is furthest behind, not being worked on, with room in its hand-off queue
     for (int w = 0; w < n_few; ++w) th.emplace_back([&, w]() {
@@ -813,18 +741,24 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
             if (mine == 1) ++W.ekf_frames;
             const int frame = fb->frame;
             const int rc = groups_[b]->ekf_stage(ekf_ctx[w], fb.get(), acc);
-            if (rc == MSKF_OK) {
-                const long c = shared.completed.fetch_add(1) + 1;
-                if (c == shared.target_open) { shared.t_open = now_s(); shared.phase.store(1, std::memory_order_release); }
-                if (c == shared.target_close) { shared.t_close = now_s(); shared.phase.store(2, std::memory_order_release); }
-                if (frame == B[b].mark_end - 1) groups_[b]->snapshot_ekf_mark();
-            }
+            if (rc == MSKF_OK && frame == B[b].mark_end - 1) groups_[b]->snapshot_ekf_mark();     // (before the batch is released to the next worker)
             {
+                // the frame is through both stages: it counts.  Progress and the shared count move together under the lock, so the
+                // thread that completes the closing frame sees how far every batch had got at that moment (the frames a batch
+                // finishes after that are drain, done but not counted)
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc != MSKF_OK) err.store(rc);
+                else {
+                    win_[b].frames_done = frame + 1 - B[b].from;
+                    const long c = shared.completed.fetch_add(1) + 1;
+                    if (c == shared.target_open) { shared.t_open = now_s(); shared.phase.store(1, std::memory_order_release); }
+                    if (c == shared.target_close) {
+                        shared.t_close = now_s(); shared.phase.store(2, std::memory_order_release);
+                        for (int g = 0; g < nb; ++g) win_[g].frames_at_close = win_[g].frames_done;
+                    }
+                }
                 groups_[b]->handoff_pool.push_back(std::move(fb));
                 B[b].ekf_busy = false;
-                win_[b].frames_done = frame + 1 - B[b].from;
             }
             cv.notify_all();
             if (rc != MSKF_OK) return;

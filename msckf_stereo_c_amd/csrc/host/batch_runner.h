@@ -50,18 +50,7 @@ struct TimedWindow {
     double t_fe_begin = 0, t_fe_end = 0, t_ekf_begin = 0, t_ekf_end = 0;   // when the stages opened / closed their gates
     int fe_frames = 0, ekf_frames = 0;       // frames each stage started between its open and close
     int frames_done = 0;                     // frames the group processed in this run
-};
-
-// Pacing of the groups of a MultiRunner run: every group's front-end stage publishes how many frames of the run it has
-// finished, and no group starts a frame more than `slack` frames ahead of the slowest one.  The hardware queues of the
-// groups are not served evenly (measured: over 60 frames some groups finished 0.44 s before others, a third of the run,
-// and the last ones then had the device to themselves); a group that is held back leaves its share of the device to the
-// ones behind, so all of them finish together and the run takes the average pace instead of the slowest group's.
-struct Pacer {
-    explicit Pacer(int n, int slack_) : done(n), slack(slack_) { for (auto &d : done) d.store(0); }
-    std::vector<std::atomic<int>> done;      // frames of this run the group's front-end has finished (INT_MAX: out of the race)
-    int slack;
-    int slowest() const { int m = 0x7fffffff; for (const auto &d : done) { const int v = d.load(std::memory_order_relaxed); if (v < m) m = v; } return m; }
+    int frames_at_close = 0;                 // ... of which completed (both stages) when the shared window closed (balanced runner)
 };
 
 struct FrameBatch {           // what the front-end stage hands to the filter stage: one frame of every stream
@@ -93,8 +82,9 @@ class ForkJoin {
 
 class BatchGroup {
   public:
-    // fe_queue: a context whose HIP stream this group's front-end stage shares with other groups (nullptr: a stream of its own)
-    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1, mskf_ctx *fe_queue = nullptr);
+    // host_threads / ekf_host_threads: threads that share the per-stream host phases of the front-end / filter stage (0 = as
+    // host_threads); halves = 2: two staggered half-batches per stage on contexts sharing the stage's HIP stream
+    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1, int ekf_host_threads = 0, int halves = 1);
     ~BatchGroup();
     bool ok() const { return ok_; }
     int size() const { return (int)systems_.size(); }
@@ -106,7 +96,7 @@ class BatchGroup {
     int run(int first, int n);
     // same frames as a two-stage pipeline: a front-end thread (context ctx()) and a filter thread (context
     // ekf_ctx()); the front-end never reads filter state, so the results are identical to run()
-    int run_pipelined(int first, int n, TimedWindow *win = nullptr, Pacer *pacer = nullptr, int pacer_slot = 0);
+    int run_pipelined(int first, int n, TimedWindow *win = nullptr);
     // ---- the two stages of a frame as separate calls on BORROWED contexts, for the balanced runner (MultiRunner::run_balanced):
     // a batch (this object's streams and host state) is handed to whichever worker (a context + a host thread) is free.
     // fe_stage: IMU feed + front-end of frame k + the hand-off snapshot; ekf_stage: IMU feed + filter of a snapshot.  `acc`
@@ -128,7 +118,7 @@ class BatchGroup {
     const std::string &error() const { return error_; }
     // phases of the front-end thread: PH_IMU .. PH_FE_QWAIT (without PH_EKF_*); of the filter thread: PH_EKF_QWAIT, PH_IMU_EKF, PH_EKF_A .. PH_POSVAR
     enum { PH_PUSH = 0, PH_PREP1, PH_TRACK1, PH_AFTER1, PH_TRACK2, PH_AFTER2, PH_EKF_A, PH_UPD1, PH_EKF_B, PH_UPD2, PH_EKF_C, PH_POSVAR, PH_IMU,
-           PH_HANDOFF, PH_FE_QWAIT, PH_EKF_QWAIT, PH_IMU_EKF, PH_FE_PACE, PH_COUNT };
+           PH_HANDOFF, PH_FE_QWAIT, PH_EKF_QWAIT, PH_IMU_EKF, PH_COUNT };
     double phase_s[PH_COUNT] = {0};   // wall seconds per phase of step() (host bookkeeping vs device calls)
     double window_phase_s[PH_COUNT] = {0};   // the same inside the last TimedWindow (each stage between its own marks)
     // what local stream 0 had computed when the stages closed the window (the sentinel of bench.py): front-end state after
@@ -175,7 +165,7 @@ class BatchGroup {
 class MultiRunner {
   public:
     MultiRunner(int device, int n_groups, int per_group, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf,
-                int host_threads = 1);
+                int host_threads = 1, int ekf_host_threads = 0, int halves = 1);
     ~MultiRunner();
     bool ok() const;
     int n_streams() const { return n_groups_ * per_group_; }
@@ -195,11 +185,11 @@ class MultiRunner {
     // stage.  The hardware queues of a device are not served evenly, and which ones fall behind changes from run to run (measured:
     // 78 k to 99 k stereo frames/s for the same code with fixed batch-to-queue binding, some groups at 10 ms per frame and others
     // at 26); a slow queue then simply takes fewer batches, all streams advance at the same pace, and the device stays loaded.
-    // Results are identical (a stream's arithmetic does not depend on the queue it runs on).  MSKF_BALANCE=0 selects the fixed binding.
+    // Results are identical (a stream's arithmetic does not depend on the queue it runs on).
     int run_balanced(int first, int warmup, int steps, int max_extra, double *elapsed_s, bool plain = false);
-    static bool balance_enabled();
+    // workers of the balanced runner: front-end / filter workers for the n_groups batches (0 = one per batch)
+    void set_workers(int fe_workers, int ekf_workers) { fe_workers_ = fe_workers; ekf_workers_ = ekf_workers; }
     int frames_done(int g) const { return next_[g]; }          // next frame index of group g (absolute)
-    static int pace_slack();                                   // MSKF_PACE = slack in frames (default 0: groups are not paced)
     const TimedWindow &window(int g) const { return win_[g]; }
     // group g works `g * delta` frames ahead of the frame index passed to run(): replicas of one looping sequence in
     // different groups then never read the same stereo pair at the same time (no cache sharing across groups).  The
@@ -211,8 +201,7 @@ class MultiRunner {
   private:
     int n_groups_, per_group_;
     std::vector<std::unique_ptr<BatchGroup>> groups_;
-    std::vector<mskf_ctx *> dummies_;
-    std::vector<mskf_ctx *> fe_queues_;     // MSKF_FE_QUEUES: front-end streams shared by several groups (owners; the groups hold shared contexts)
+    int fe_workers_ = 0, ekf_workers_ = 0;
     std::vector<int> off_, next_;   // per group: frame offset, next frame not yet processed
     std::vector<TimedWindow> win_;
 };

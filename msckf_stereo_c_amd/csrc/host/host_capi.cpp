@@ -9,8 +9,8 @@ using namespace cg;
 extern "C" {
 
 void *mskfh_runner_create(int device, int n_groups, int per_group, const mskf_calib *calib, const mskf_fe_cfg *fe, const mskf_ekf_cfg *ekf,
-                          int host_threads) {
-    MultiRunner *r = new MultiRunner(device, n_groups, per_group, *calib, *fe, *ekf, host_threads);
+                          int host_threads, int ekf_host_threads, int halves) {
+    MultiRunner *r = new MultiRunner(device, n_groups, per_group, *calib, *fe, *ekf, host_threads, ekf_host_threads, halves);
     if (!r->ok()) {
         std::fprintf(stderr, "mskfh_runner_create: %s\n", r->error().c_str());
         delete r;
@@ -57,10 +57,12 @@ int mskfh_runner_run_timed(void *h, int first, int warmup, int steps, int max_ex
 }
 int mskfh_runner_frames_done(void *h, int g) { return ((MultiRunner *)h)->frames_done(g); }
 // group g's stages in the last timed window: [0] front-end open, [1] front-end close, [2] filter open, [3] filter close (steady
-// clock, s), [4] frames the front-end started inside, [5] frames the filter started inside
-void mskfh_runner_window(void *h, int g, double out[6]) {
+// clock, s), [4] frames the front-end started inside, [5] frames the filter started inside, [6] frames of the run the batch had
+// completed when the shared window closed (balanced runner; 0 otherwise)
+void mskfh_runner_window(void *h, int g, double out[7]) {
     const TimedWindow &w = ((MultiRunner *)h)->window(g);
     out[0] = w.t_fe_begin; out[1] = w.t_fe_end; out[2] = w.t_ekf_begin; out[3] = w.t_ekf_end; out[4] = w.fe_frames; out[5] = w.ekf_frames;
+    out[6] = w.frames_at_close;
 }
 // wall seconds per phase inside the last timed window, summed over groups (each stage between its own marks)
 void mskfh_runner_get_window_phases(void *h, double *out) {
@@ -88,6 +90,7 @@ void mskfh_runner_mark_dump(void *h, int g, uint64_t *ids, int32_t *lifetime, ms
 }
 void mskfh_runner_keep_trajectory_stream(void *h, int stream, int keep) { ((MultiRunner *)h)->system(stream).msckfvio_ptr()->keepTrajectory = keep != 0; }
 void mskfh_runner_set_stagger(void *h, int delta) { ((MultiRunner *)h)->set_stagger(delta); }
+void mskfh_runner_set_workers(void *h, int fe_workers, int ekf_workers) { ((MultiRunner *)h)->set_workers(fe_workers, ekf_workers); }
 int mskfh_runner_group_offset(void *h, int g) { return ((MultiRunner *)h)->group_offset(g); }
 void mskfh_runner_keep_trajectory(void *h, int keep) {
     MultiRunner *r = (MultiRunner *)h;

@@ -24,7 +24,8 @@ def lib():
             raise MskfError("libmskf_host.so is not built (run python -m msckf_stereo_c_amd.build); there is no CPU fallback")
         L = C.CDLL(p)
         L.mskfh_runner_create.restype = C.c_void_p
-        L.mskfh_runner_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Calib), C.POINTER(FeCfg), C.POINTER(EkfCfg), C.c_int]
+        L.mskfh_runner_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Calib), C.POINTER(FeCfg), C.POINTER(EkfCfg), C.c_int, C.c_int, C.c_int]
+        L.mskfh_runner_set_workers.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mskfh_runner_destroy.argtypes = [C.c_void_p]
         L.mskfh_runner_error.restype = C.c_char_p
         L.mskfh_runner_error.argtypes = [C.c_void_p]
@@ -83,12 +84,14 @@ def set_fe_books_on_host(on):
 class Runner:
     """n_groups x per_group independent VIO streams on one GPU."""
 
-    def __init__(self, calib, fe_cfg, ekf_cfg, n_groups=1, per_group=1, device=0, host_threads=1):
+    def __init__(self, calib, fe_cfg, ekf_cfg, n_groups=1, per_group=1, device=0, host_threads=1, ekf_host_threads=0, halves=1):
+        """host_threads / ekf_host_threads: threads sharing the per-stream host phases of a group's front-end / filter stage
+        (0 = as host_threads); halves = 2: two staggered half-batches per stage (BatchGroup)."""
         self.L = lib()
         self.calib, self.fe_cfg, self.ekf_cfg = calib, fe_cfg, ekf_cfg
         self.n = n_groups * per_group
         self.n_groups, self.per_group = n_groups, per_group
-        self.h = self.L.mskfh_runner_create(device, n_groups, per_group, C.byref(calib), C.byref(fe_cfg), C.byref(ekf_cfg), host_threads)
+        self.h = self.L.mskfh_runner_create(device, n_groups, per_group, C.byref(calib), C.byref(fe_cfg), C.byref(ekf_cfg), host_threads, ekf_host_threads, halves)
         if not self.h:
             raise MskfError("could not create the runner (no GPU / HIP library?): see stderr")
         self._keep = []
@@ -107,6 +110,11 @@ class Runner:
     def _chk(self, rc):
         if rc != 0:
             raise MskfError("runner status %d: %s" % (rc, self.L.mskfh_runner_error(self.h).decode()))
+
+    def set_workers(self, fe_workers=0, ekf_workers=0):
+        """Workers of the balanced runner (MultiRunner::run_balanced): front-end / filter workers that serve the n_groups
+        batches; 0 = one of a kind per batch."""
+        self.L.mskfh_runner_set_workers(self.h, int(fe_workers), int(ekf_workers))
 
     def imu(self, stream, sample):
         self.L.mskfh_runner_imu(self.h, stream, C.byref(sample))
@@ -145,9 +153,9 @@ class Runner:
         return self.L.mskfh_runner_frames_done(self.h, group)
 
     def window(self, group=0):
-        out = np.zeros(6)
+        out = np.zeros(7)
         self.L.mskfh_runner_window(self.h, group, _p(out))
-        return dict(zip(("fe_open", "fe_close", "ekf_open", "ekf_close", "fe_frames", "ekf_frames"), (float(x) for x in out)))
+        return dict(zip(("fe_open", "fe_close", "ekf_open", "ekf_close", "fe_frames", "ekf_frames", "frames_at_close"), (float(x) for x in out)))
 
     def mark_dump(self, group=0):
         """(ids, lifetimes, cam0, cam1, imu_state[28]) of local stream 0 of a group at the close of its timed window."""
@@ -191,8 +199,8 @@ class Runner:
         return {n: (float(ms[i]), int(launches[i]), int(units[i])) for i, n in enumerate(self.KERNELS)}
 
     PHASES = ["push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "ekf_A", "update1", "ekf_B", "update2",
-              "ekf_C", "posvar", "imu_feed", "handoff", "fe_queue_wait", "ekf_queue_wait", "imu_feed_ekf", "fe_pace_wait"]
-    FE_THREAD_PHASES = ["fe_pace_wait", "imu_feed", "push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "handoff", "fe_queue_wait"]
+              "ekf_C", "posvar", "imu_feed", "handoff", "fe_queue_wait", "ekf_queue_wait", "imu_feed_ekf"]
+    FE_THREAD_PHASES = ["imu_feed", "push", "fe_prepare1", "track1", "fe_after1", "track2", "fe_after2", "handoff", "fe_queue_wait"]
     EKF_THREAD_PHASES = ["ekf_queue_wait", "imu_feed_ekf", "ekf_A", "update1", "ekf_B", "update2", "ekf_C", "posvar"]
 
     def get_window_phases_group(self, g):
