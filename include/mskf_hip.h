@@ -39,7 +39,8 @@ typedef struct mskf_stream mskf_stream;
 
 const char *mskf_last_error(void);
 int mskf_abi_version(void);   /* 2: update args carry diag_out, mskf_ekf_cfg.compression_mode, *_begin / *_end entry points; 3 (round 3): update args carry
-                                 pos_var_out, mskf_fe_frame_batch_* (whole front-end frames on the device), mskf_ctx_timing_gate, mskf_ctx_set_wait_mode */
+                                 pos_var_out, mskf_fe_frame_batch_* (whole front-end frames on the device), mskf_ctx_timing_gate, mskf_ctx_set_wait_mode;
+                                 4 (round 4): the 2-point RANSAC inside the device frame (mskf_fe_frame_args.R_p_c / ransac_draws, mskf_fe_set_grid's draw counter) */
 
 int mskf_ctx_create(int device, mskf_ctx **out);
 /* Same, with the context's HIP stream created at the device's most urgent priority when high_priority != 0.
@@ -166,9 +167,11 @@ int mskf_fe_swap(mskf_stream *s);
  * between (survivors, occupancy, detections, per-cell sieve, candidates), the candidates' stereo track and the bookkeeping
  * after it (vacancy fill, ids, pruning), and returns the published grid: ids, lifetimes, pixels and the undistorted
  * points publish() writes into the message (:1137-1182).  One host wait per frame instead of two, no points travel to
- * the device.  Limits: grid_min / grid_max_feature_num <= 16 (mskf_fe_grid_capacity returns 0 otherwise) and no 2-point
- * RANSAC between the tracks (MSKF_COMPAT_Q5_NO_RANSAC set, as in the reference); the caller keeps those frames, and the
- * first frame of a stream, on the mskf_fe_track path and hands the grid over with mskf_fe_set_grid. */
+ * the device.  With MSKF_COMPAT_Q5_NO_RANSAC cleared the 2-point RANSAC of :482-500 / :911-1135 runs inside the call too,
+ * between the track of the previous features and the bookkeeping (its draws come from a counter the stream keeps on the
+ * device).  Limits: grid_min / grid_max_feature_num <= 16 and bookkeeping lists that fit the kernel's LDS
+ * (mskf_fe_grid_capacity returns 0 otherwise); the caller keeps such streams, and the first frame of every stream, on the
+ * mskf_fe_track path and hands the grid over with mskf_fe_set_grid. */
 typedef struct mskf_fe_frame_args {
     double Hpred[9];              /* in: K R_p_c K^-1 of this frame (image_processor.cpp:335-340) */
     int32_t capacity;             /* in: entries each output array holds, >= mskf_fe_grid_capacity(stream) */
@@ -180,13 +183,17 @@ typedef struct mskf_fe_frame_args {
     int32_t before_tracking, after_tracking, after_matching, after_ransac;   /* out: TrackingInfo (:514-530) */
     int32_t n_candidates, n_new;  /* out: candidates stereo-matched for the vacancies, features created */
     uint64_t next_feature_id;     /* out: the stream's id counter after this frame */
+    double R_p_c[2][9];           /* in: rotation previous -> current frame of cam0 and of cam1 (integrateImuData, :850-889); read by the
+                                   *     2-point RANSAC only (MSKF_COMPAT_Q5_NO_RANSAC cleared) */
+    uint64_t ransac_draws;        /* out: numbers the stream's RANSAC generator has drawn so far (a host-side frame continues from it) */
 } mskf_fe_frame_args;
 /* entries a published grid can have: (grid codes) x grid_max_feature_num; 0 = this stream keeps its books on the host */
 int mskf_fe_grid_capacity(mskf_stream *s);
-/* Hand the device the grid a host-side frame has published (the first frame of a stream), with the id counter and the
- * tracking counters that survive frames without features (:383).  Synchronous. */
+/* Hand the device the grid a host-side frame has published (the first frame of a stream), with the id counter, the
+ * tracking counters that survive frames without features (:383) and the draw counter of the RANSAC generator.  Synchronous. */
 int mskf_fe_set_grid(mskf_stream *s, int n, const uint64_t *id, const int32_t *lifetime, const mskf_point2f *cam0, const mskf_point2f *cam1,
-                     const mskf_point2f *und0, const mskf_point2f *und1, uint64_t next_feature_id, const int32_t tracking_counters[3]);
+                     const mskf_point2f *und0, const mskf_point2f *und1, uint64_t next_feature_id, const int32_t tracking_counters[3],
+                     uint64_t ransac_draws);
 /* streams / args must stay valid until _end; the pyramid swap of :194 is part of the call */
 int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *const *streams, const uint8_t *const *cam0, const uint8_t *const *cam1,
                               int on_device, mskf_fe_frame_args *args);

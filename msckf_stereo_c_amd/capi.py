@@ -43,7 +43,8 @@ class FeFrameArgs(C.Structure):   # mskf_fe_frame_args (include/mskf_hip.h)
     _fields_ = [("Hpred", C.c_double * 9), ("capacity", C.c_int32), ("n", C.c_int32),
                 ("id", C.c_void_p), ("lifetime", C.c_void_p), ("cam0", C.c_void_p), ("cam1", C.c_void_p), ("und0", C.c_void_p), ("und1", C.c_void_p),
                 ("before_tracking", C.c_int32), ("after_tracking", C.c_int32), ("after_matching", C.c_int32), ("after_ransac", C.c_int32),
-                ("n_candidates", C.c_int32), ("n_new", C.c_int32), ("next_feature_id", C.c_uint64)]
+                ("n_candidates", C.c_int32), ("n_new", C.c_int32), ("next_feature_id", C.c_uint64),
+                ("R_p_c", (C.c_double * 9) * 2), ("ransac_draws", C.c_uint64)]
 
 
 EXPORTS = [

@@ -1,6 +1,7 @@
 // mskf_capi_fe.cpp — C-ABI: contexts, streams and the front-end entry points (include/mskf_hip.h).
 #include <sys/prctl.h>
 #include <time.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,7 +14,7 @@ static thread_local std::string g_last_error;
 void mskf_set_error(const std::string &s) { g_last_error = s; }
 
 extern "C" const char *mskf_last_error(void) { return g_last_error.c_str(); }
-extern "C" int mskf_abi_version(void) { return 3; }   // 3: round 3 (mskf_ekf_update_args.pos_var_out, mskf_fe_frame_batch_*, timing gate, wait mode)
+extern "C" int mskf_abi_version(void) { return 4; }   // 4: round 4 (2-point RANSAC inside the device frame: mskf_fe_frame_args.R_p_c / ransac_draws, mskf_fe_set_grid's draw counter)
 
 extern "C" int mskf_ctx_create(int device, mskf_ctx **out) { return mskf_ctx_create_prio(device, 0, out); }
 
@@ -286,6 +287,7 @@ static int book_alloc(mskf_stream *s) {
     o_t[4] = take((size_t)cap);
     for (int q = 0; q < 4; ++q) o_c[q] = take(8 * (size_t)cand_cap);
     o_c[4] = take((size_t)cand_cap);
+    const size_t o_rs_pair = take(8 * 4 * (size_t)cap), o_rs_pt = take(4 * 4 * (size_t)cap), o_rs_sc = take(8 * 48);
     MSKF_HIPCHK(hipMalloc((void **)&K.mem, off));
     MSKF_HIPCHK(hipMemsetAsync(K.mem, 0, off, s->ctx->stream));
     MSKF_HIPCHK(hipStreamSynchronize(s->ctx->stream));
@@ -301,6 +303,7 @@ static int book_alloc(mskf_stream *s) {
     K.t_status = (uint8_t *)(m + o_t[4]);
     K.c_out0 = (mskf_point2f *)(m + o_c[0]); K.c_out1 = (mskf_point2f *)(m + o_c[1]); K.c_und0 = (mskf_point2f *)(m + o_c[2]); K.c_und1 = (mskf_point2f *)(m + o_c[3]);
     K.c_status = (uint8_t *)(m + o_c[4]);
+    K.rs_pair = (double *)(m + o_rs_pair); K.rs_pt = (float *)(m + o_rs_pt); K.rs_scalar = (double *)(m + o_rs_sc);
     K.cap = cap; K.cand_cap = cand_cap; K.det_cap = det_cap;
     return MSKF_OK;
 }
@@ -748,7 +751,8 @@ extern "C" int mskf_fe_swap(mskf_stream *s) {
 extern "C" int mskf_fe_grid_capacity(mskf_stream *s) { return s ? s->book.cap : 0; }
 
 extern "C" int mskf_fe_set_grid(mskf_stream *s, int n, const uint64_t *id, const int32_t *lifetime, const mskf_point2f *cam0, const mskf_point2f *cam1,
-                                const mskf_point2f *und0, const mskf_point2f *und1, uint64_t next_feature_id, const int32_t tracking_counters[3]) {
+                                const mskf_point2f *und0, const mskf_point2f *und1, uint64_t next_feature_id, const int32_t tracking_counters[3],
+                                uint64_t ransac_draws) {
     if (!s || n < 0 || (n && (!id || !lifetime || !cam0 || !cam1 || !und0 || !und1))) return MSKF_ERR_INVALID;
     mskf_stream::Book &K = s->book;
     if (!K.cap) { mskf_set_error("this stream keeps its books on the host (grid_min / grid_max above the device limit)"); return MSKF_ERR_UNSUPPORTED; }
@@ -768,6 +772,7 @@ extern "C" int mskf_fe_set_grid(mskf_stream *s, int n, const uint64_t *id, const
     FeBookState h;
     std::memset(&h, 0, sizeof(h));
     h.next_id = next_feature_id; h.n_prev = n; h.n_curr = n;
+    h.ransac_draws = ransac_draws;
     if (tracking_counters) { h.after_tracking = tracking_counters[0]; h.after_matching = tracking_counters[1]; h.after_ransac = tracking_counters[2]; }
     MSKF_HIPCHK(hipMemcpyAsync(K.st, &h, sizeof(h), hipMemcpyHostToDevice, st));
     MSKF_HIPCHK(hipStreamSynchronize(st));
@@ -786,7 +791,6 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
         if (!s || s->ctx != ctx) return MSKF_ERR_INVALID;
         if (!s->book.cap) { mskf_set_error("this stream keeps its books on the host (grid_min / grid_max above the device limit)"); return MSKF_ERR_UNSUPPORTED; }
         if (!s->book.grid_set) { mskf_set_error("no grid on the device yet: the first frame goes through mskf_fe_track + mskf_fe_set_grid"); return MSKF_ERR_INVALID; }
-        if (!(s->fe.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC)) { mskf_set_error("the 2-point RANSAC runs between the track calls on the host: use mskf_fe_track"); return MSKF_ERR_UNSUPPORTED; }
         const mskf_fe_frame_args &a = args[i];
         if (a.capacity < s->book.cap || !a.id || !a.lifetime || !a.cam0 || !a.cam1 || !a.und0 || !a.und1) return MSKF_ERR_INVALID;
     }
@@ -838,6 +842,13 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
         B.det_rows = fe.det_rows; B.det_cols = fe.det_cols; B.det_cw = s->det_cw; B.det_ch = s->det_ch;
         B.thr_score = fe.fast_threshold * 256;
         B.q4 = (fe.compat_flags & MSKF_COMPAT_Q4_RESPONSE_INDEX) ? 1 : 0;
+        // twoPointRansac between the tracks (:482-500; commented out in the reference, Q5): iterations as :920-921
+        B.ransac = (fe.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC) ? 0 : 1;
+        B.ransac_iters = static_cast<int>(std::ceil(std::log(1 - 0.99) / std::log(1 - 0.7 * 0.7)));
+        B.ransac_thr = fe.ransac_threshold;
+        B.ransac_npu[0] = 2.0 / (s->cam0.K[0] + s->cam0.K[1]); B.ransac_npu[1] = 2.0 / (s->cam1.K[0] + s->cam1.K[1]);
+        std::memcpy(B.R_p_c, args[i].R_p_c, sizeof(B.R_p_c));
+        B.rs_pair = K.rs_pair; B.rs_pt = K.rs_pt; B.rs_scalar = K.rs_scalar;
         B.cap = K.cap; B.cand_cap = K.cand_cap; B.det_cap = K.det_cap;
         B.gen = (unsigned int)((s->push_gen - 1) % 255ULL) + 1U;
         B.st = K.st;
@@ -909,6 +920,7 @@ extern "C" int mskf_fe_frame_batch_end(mskf_ctx *ctx) {
         a.before_tracking = info[2]; a.after_tracking = info[3]; a.after_matching = info[4]; a.after_ransac = info[5];
         a.next_feature_id = (uint64_t)(unsigned int)info[6] | ((uint64_t)(unsigned int)info[7] << 32);
         a.n_new = info[9];
+        a.ransac_draws = (uint64_t)(unsigned int)info[12] | ((uint64_t)(unsigned int)info[13] << 32);
         std::memcpy(a.id, o + 64, 8 * (size_t)m);
         std::memcpy(a.lifetime, o + 64 + 8 * (size_t)K.cap, 4 * (size_t)m);
         const char *p = o + 64 + 12 * (size_t)K.cap;

@@ -155,6 +155,7 @@ struct mskf_stream {
         mskf_point2f *cand_pt = nullptr; int *cand_index = nullptr, *cand_score = nullptr, *cand_off = nullptr, *cand_cnt = nullptr, *cell_count = nullptr;
         mskf_point2f *t_out0 = nullptr, *t_out1 = nullptr, *t_und0 = nullptr, *t_und1 = nullptr; uint8_t *t_status = nullptr;
         mskf_point2f *c_out0 = nullptr, *c_out1 = nullptr, *c_und0 = nullptr, *c_und1 = nullptr; uint8_t *c_status = nullptr;
+        double *rs_pair = nullptr, *rs_scalar = nullptr; float *rs_pt = nullptr;     // scratch of the 2-point RANSAC (fe_book.h)
         int parity = 0;                            // grid[parity] holds the published grid of the last frame
         int n_prev = 0, n_cand_last = -1;          // host copies of the counts (launch sizing)
         bool grid_set = false;

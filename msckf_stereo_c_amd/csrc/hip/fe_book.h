@@ -2,6 +2,8 @@
 // track calls of a frame (reference msckf_core/src/image_processor.cpp, lines cited per step):
 //
 //   fe_book1 (after the temporal + stereo track of the previous features)
+//     twoPointRansac            :911-1135  (call sites :482-500, commented out in the reference: quirk Q5; runs when
+//                                          MSKF_COMPAT_Q5_NO_RANSAC is cleared) inlier markers of the matched cam0 and cam1 pairs
 //     trackFeatures tail        :416-513   survivors in track order, lifetime + 1, grid code, per-cell counts, tracking info
 //     addNewFeatures head       :622-688   occupancy of the detector cells, detections in cell order, per-grid-cell sieve to
 //                                          grid_max by response (stable), the candidate list of the cells with a vacancy and
@@ -28,6 +30,7 @@
 // total orders (ties broken by the item's own index), which is also how the reference's stable sorts are reproduced.
 // The host run is therefore a faithful check of the logic.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include "../../../include/mskf_types.h"
 
@@ -68,6 +71,7 @@ struct FeBookState {        // per stream, persistent in HBM
     int n_tracked, n_det, n_cand, n_new, n_curr;
     int before_tracking, after_tracking, after_matching, after_ransac;   // TrackingInfo (:514-530); after_* survive frames without features (:383)
     int overflow;                       // a capacity was hit (cannot happen with the capacities mskf_stream_create derives; checked by the host)
+    unsigned long long ransac_draws;    // ImageProcessor::ransac_draws: numbers drawn so far by the counter-based generator of twoPointRansac
 };
 
 struct FeBookDev {          // everything the two kernels need for one stream (built by the host per frame)
@@ -79,6 +83,14 @@ struct FeBookDev {          // everything the two kernels need for one stream (b
     int q4;                             // MSKF_COMPAT_Q4_RESPONSE_INDEX
     int cap, cand_cap, det_cap;         // capacities: grid lists, candidate lists, detection lists
     unsigned int gen;                   // push generation the cell keys must carry
+    // 2-point RANSAC between the tracks (:482-500): on when `ransac` is set
+    int ransac, ransac_iters;           // iterations = ceil(log(1 - 0.99) / log(1 - 0.7^2)) (:920-921), computed by the host
+    double ransac_thr;                  // processor_config.ransac_threshold (inlier_error)
+    double ransac_npu[2];               // 2 / (fx + fy) of cam0, cam1 (:917)
+    double R_p_c[2][9];                 // rotation previous -> current frame of cam0, cam1 (integrateImuData, :850-889)
+    double *rs_pair;                    // scratch in HBM, 4 x cap doubles: per pair its length and the coefficients of (tx, ty, tz) (:949-1012)
+    float *rs_pt;                       // scratch, 4 x cap floats: rotated previous point (x, y) and the two norms rescalePoints sums (:888-908)
+    double *rs_scalar;                  // scratch, 16 + 4 x 8 doubles: scale, norm_pixel_unit, ..., the models of the hypotheses
     FeBookState *st;
     FeGridArr prev, tracked, curr;
     // results of the first track call, one per previous feature
@@ -98,7 +110,7 @@ struct FeBookDev {          // everything the two kernels need for one stream (b
     const uint8_t *c_status;
     int *cell_count;                    // tracked features per grid code, n_codes (written by fe_book1, read by fe_book2)
     // export: what the host receives (one D2H copy per batch)
-    int *x_info;                        // 16 ints: n_curr, n_cand, before/after tracking x4, next_id lo/hi, overflow
+    int *x_info;                        // 16 ints: n_curr, n_cand, before/after tracking x4, next_id lo/hi, overflow, n_new, n_det, n_tr, ransac_draws lo/hi
     unsigned long long *x_id;
     int *x_lifetime;
     mskf_point2f *x_cam0, *x_cam1, *x_und0, *x_und1;
@@ -110,16 +122,18 @@ struct FeBookScratch {
     int *b;                 // max(cap, det_cap): grid codes of the survivors; then of the detections
     int *c;                 // cand_cap: per candidate, the score it is ranked with (-1: no stereo match); then its rank among the cell's new features
     int *d;                 // cap: lifetimes of the survivors
+    int *e;                 // cap: RANSAC markers of the cam1 pairs
     int *tl;                // cap: survivors listed by grid cell (order inside a cell unspecified)
     int *dl;                // det_cap: detections listed by grid cell (order inside a cell unspecified)
     int *chunk;             // FB_NTH + 1: partial sums of the scans, [FB_NTH] = total
     int *cell[8];           // n_codes + 1 each
+    int *rs;                // 16: support counts of the RANSAC hypotheses
     unsigned char *occ;     // det_rows * det_cols
 };
 
 FB_FN size_t fe_book_scratch_ints(int cap, int cand_cap, int det_cap, int n_codes, int det_cells) {
     const int m = cap > det_cap ? cap : det_cap;
-    return (size_t)2 * m + cand_cap + 2 * (size_t)cap + det_cap + (FB_NTH + 1) + (size_t)8 * (n_codes + 1) + (size_t)(det_cells + 3) / 4 + 8;
+    return (size_t)2 * m + cand_cap + 3 * (size_t)cap + det_cap + (FB_NTH + 1) + (size_t)8 * (n_codes + 1) + 16 + (size_t)(det_cells + 3) / 4 + 8;
 }
 FB_FN void fe_book_scratch_init(FeBookScratch &L, int *mem, int cap, int cand_cap, int det_cap, int n_codes, int det_cells) {
     const int m = cap > det_cap ? cap : det_cap;
@@ -127,10 +141,12 @@ FB_FN void fe_book_scratch_init(FeBookScratch &L, int *mem, int cap, int cand_ca
     L.b = mem; mem += m;
     L.c = mem; mem += cand_cap;
     L.d = mem; mem += cap;
+    L.e = mem; mem += cap;
     L.tl = mem; mem += cap;
     L.dl = mem; mem += det_cap;
     L.chunk = mem; mem += FB_NTH + 1;
     for (int q = 0; q < 8; ++q) { L.cell[q] = mem; mem += n_codes + 1; }
+    L.rs = mem; mem += 16;
     L.occ = (unsigned char *)mem;
     (void)det_cells;
 }
@@ -171,6 +187,155 @@ FB_FN void fb_exclusive_scan(int *v, int n, int *chunk) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------ 2-point RANSAC (:911-1135)
+// cg::uniform_integer lives in the absent vikit_cg: the draws come from a counter-based generator (splitmix64 of the
+// stream's draw counter, shared with the host mirror and the oracle), so the j-th number ever drawn is a function of j
+// alone and the hypotheses of a call can be formed side by side.
+FB_FN int fb_uniform_int(unsigned long long draw, int lo, int hi) {
+    unsigned long long z = 0x5EED5EED5EED5EEDULL + 0x9E3779B97F4A7C15ULL * draw;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return lo + (int)(z % (unsigned long long)(hi - lo + 1));
+}
+// float square root / quotient through double: correctly rounded (53 >= 2 * 24 + 2 bits), whatever the float forms
+// of the target compile to
+FB_FN float fb_sqrtf(float v) { return (float)sqrt((double)v); }
+FB_FN float fb_divf(float a, float b) { return (float)((double)a / (double)b); }
+
+// Inlier markers of the `n` matched pairs of camera `cam`: pair k is previous feature list[k], its points are the
+// undistorted previous point of the published grid and the undistorted tracked point of this frame.  marker[k] = 1 / 0.
+// The arithmetic is the host mirror's (csrc/host/image_processor.cpp two_point_ransac: single precision where the reference
+// holds cg::Point2f, double elsewhere); what is a sum over the pairs in INDEX ORDER there - rescalePoints' float sum and the
+// mean length - is summed by one item in that order here, everything else is independent per pair or per hypothesis.
+// Every item of the workgroup takes the same path (the decisions are read from shared scratch after a barrier).
+FB_FN void fb_two_point_ransac(const FeBookDev &B, FeBookScratch &L, int cam, int n, const int *list, int *marker) {
+    if (n == 0) return;
+    const mskf_point2f *prev_und = cam == 0 ? B.prev.und0 : B.prev.und1;
+    const mskf_point2f *curr_und = cam == 0 ? B.t_und0 : B.t_und1;
+    const double *R = B.R_p_c[cam];
+    const int cap = B.cap;
+    double *len = B.rs_pair, *ctx = len + cap, *cty = ctx + cap, *ctz = cty + cap;
+    float *px = B.rs_pt, *py = px + cap, *n1 = py + cap, *n2 = n1 + cap;
+    double *sc = B.rs_scalar, *model = sc + 16;
+    enum { SC_SCALE = 0, SC_NPU, SC_MEAN, SC_CAND, SC_BEST };
+    // previous points compensated with the relative rotation (:936-944, no perspective division) and the norms of :893-897
+    FB_FOR(k, n) {
+        const int i = list[k];
+        const mskf_point2f p = prev_und[i], c = curr_und[i];
+        const double X = R[0] * (double)p.x + R[1] * (double)p.y + R[2] * 1.0;
+        const double Y = R[3] * (double)p.x + R[4] * (double)p.y + R[5] * 1.0;
+        const float fx = (float)X, fy = (float)Y;
+        px[k] = fx; py[k] = fy;
+        n1[k] = fb_sqrtf(fx * fx + fy * fy);
+        n2[k] = fb_sqrtf(c.x * c.x + c.y * c.y);
+    }
+    FB_SYNC();
+    FB_FOR(one, 1) {
+        float sum = 0.0f;
+        for (int k = 0; k < n; ++k) { sum += n1[k]; sum += n2[k]; }
+        const float scale = fb_divf((float)(n + n), sum) * fb_sqrtf(2.0f);
+        sc[SC_SCALE] = (double)scale;
+        sc[SC_NPU] = B.ransac_npu[cam] * (double)scale;
+    }
+    FB_SYNC();
+    const float scale = (float)sc[SC_SCALE];
+    const double npu = sc[SC_NPU];
+    FB_FOR(k, n) {
+        const mskf_point2f c0 = curr_und[list[k]];
+        const float ax = px[k] * scale, ay = py[k] * scale, bx = c0.x * scale, by = c0.y * scale;
+        const float dx = ax - bx, dy = ay - by;
+        const double l = sqrt((double)(dx * dx + dy * dy));
+        len[k] = l;
+        ctx[k] = (double)dy; cty[k] = (double)(-dx); ctz[k] = (double)(ax * by - ay * bx);
+        marker[k] = l > 50.0 * npu ? 0 : 1;                    // :961-967
+    }
+    FB_SYNC();
+    FB_FOR(one, 1) {
+        double length_sum = 0.0;
+        int candidates = 0;
+        for (int k = 0; k < n; ++k) if (marker[k]) { length_sum += len[k]; ++candidates; }
+        sc[SC_MEAN] = length_sum / candidates;
+        sc[SC_CAND] = (double)candidates;
+    }
+    FB_SYNC();
+    const int candidates = (int)sc[SC_CAND];
+    if (candidates < 3) {                                       // :974-977
+        FB_FOR(k, n) marker[k] = 0;
+        FB_SYNC();
+        return;
+    }
+    const double tol = B.ransac_thr * npu;
+    if (sc[SC_MEAN] < npu) {                                    // degenerate (pure rotation) case, :985-1001
+        FB_FOR(k, n) if (marker[k] && len[k] > tol) marker[k] = 0;
+        FB_SYNC();
+        return;
+    }
+    // the pool of pairs the hypotheses draw from: the marked pairs in index order (L.a: exclusive scan of the markers)
+    FB_FOR(k, n) L.a[k] = marker[k];
+    FB_SYNC();
+    fb_exclusive_scan(L.a, n, L.chunk);
+    const int m = L.chunk[FB_NTH];
+    FB_SYNC();
+    FB_FOR(k, n) if (marker[k]) L.b[L.a[k]] = k;               // pool[j] = j-th marked pair
+    const unsigned long long draw0 = B.st->ransac_draws;
+    const int iters = B.ransac_iters < 8 ? B.ransac_iters : 8;
+    FB_FOR(h, 16) L.rs[h] = 0;
+    FB_SYNC();
+    // the model of every hypothesis: two distinct pairs (:1025-1033), the coefficient column with the smallest L1 norm is
+    // fixed to 1 and the 2 x 2 system gives the other two (:1036-1065)
+    FB_FOR(h, iters) {
+        const int first = fb_uniform_int(draw0 + 2ULL * (unsigned)h + 1ULL, 0, m - 1);
+        const int step = fb_uniform_int(draw0 + 2ULL * (unsigned)h + 2ULL, 1, m - 1);
+        const int second = first + step < m ? first + step : first + step - m;
+        const int i1 = L.b[first], i2 = L.b[second];
+        const double c1[3] = {ctx[i1], cty[i1], ctz[i1]}, c2[3] = {ctx[i2], cty[i2], ctz[i2]};
+        double l1[3];
+        for (int q = 0; q < 3; ++q) l1[q] = fabs(c1[q]) + fabs(c2[q]);
+        int fixed = 0;
+        for (int q = 1; q < 3; ++q) if (l1[q] < l1[fixed]) fixed = q;
+        const int ka = fixed == 0 ? 1 : 0, kb = fixed == 2 ? 1 : 2;
+        const double a0 = c1[ka], a1 = c2[ka], b0 = c1[kb], b1 = c2[kb];
+        const double r0 = -c1[fixed], r1 = -c2[fixed];
+        const double det = a0 * b1 - b0 * a1;
+        const double v00 = b1 / det, v01 = -b0 / det, v10 = -a1 / det, v11 = a0 / det;
+        double t[3];
+        t[fixed] = 1.0;
+        t[ka] = v00 * r0 + v01 * r1;
+        t[kb] = v10 * r0 + v11 * r1;
+        model[4 * h + 0] = t[0]; model[4 * h + 1] = t[1]; model[4 * h + 2] = t[2];
+    }
+    FB_SYNC();
+    // support of every hypothesis (:1067-1076): bit h of L.a[k] = pair k agrees with hypothesis h
+    FB_FOR(k, n) {
+        int bits = 0;
+        if (marker[k])
+            for (int h = 0; h < iters; ++h) {
+                const double err = (ctx[k] * model[4 * h + 0] + cty[k] * model[4 * h + 1]) + ctz[k] * model[4 * h + 2];
+                if (fabs(err) < tol) { bits |= 1 << h; FB_INC(&L.rs[h]); }
+            }
+        L.a[k] = bits;
+    }
+    FB_SYNC();
+    // the first hypothesis with the largest support wins, hypotheses below 0.2 n are skipped (:1078-1079, :1123-1126; the
+    // refit of :1082-1121 only feeds an error nothing reads)
+    FB_FOR(one, 1) {
+        int best = -1, best_size = 0;
+        for (int h = 0; h < iters; ++h) {
+            const int sz = L.rs[h];
+            if ((double)sz < 0.2 * (double)n) continue;
+            if (sz > best_size) { best = h; best_size = sz; }
+        }
+        sc[SC_BEST] = (double)best;
+        B.st->ransac_draws = draw0 + 2ULL * (unsigned)iters;
+    }
+    FB_SYNC();
+    const int best = (int)sc[SC_BEST];
+    FB_FOR(k, n) marker[k] = best >= 0 ? ((L.a[k] >> best) & 1) : 0;
+    FB_SYNC();
+}
+
 // ------------------------------------------------------------------------------------------ after the first track call
 FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
     FeBookState &st = *B.st;
@@ -187,10 +352,30 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
     fb_exclusive_scan(L.b, n, L.chunk);                 // tracking info: features with bit 0
     const int n_bit0 = *tot;
     fb_exclusive_scan(L.a, n, L.chunk);
+    const int n_match = *tot;
+    FB_SYNC();
+    if (B.ransac) {
+        // :482-500 (Q5 cleared): the matched pairs of cam0 and of cam1 each go through twoPointRansac, a feature survives as
+        // an inlier of both.  L.tl = the matched features in order, L.d / L.e = the two marker lists (tl and d are only used
+        // by fe_book2)
+        int *list = L.tl, *in0 = L.d, *in1 = L.e;
+        FB_FOR(i, n) if ((B.t_status[i] & 3) == 3) list[L.a[i]] = i;
+        FB_SYNC();
+        fb_two_point_ransac(B, L, 0, n_match, list, in0);
+        fb_two_point_ransac(B, L, 1, n_match, list, in1);
+        FB_FOR(i, n) L.a[i] = 0;
+        FB_SYNC();
+        FB_FOR(k, n_match) L.a[list[k]] = (in0[k] && in1[k]) ? 1 : 0;
+        FB_SYNC();
+        FB_FOR(i, n) L.b[i] = L.a[i];                   // (b held the bit-0 scan: n_bit0 is taken)
+        FB_SYNC();
+        fb_exclusive_scan(L.a, n, L.chunk);
+    }
     const int n_tr = *tot;
     FB_SYNC();
     FB_FOR(i, n) {
         if ((B.t_status[i] & 3) != 3) continue;
+        if (B.ransac && !L.b[i]) continue;
         const int k = L.a[i];
         const mskf_point2f p = B.t_out0[i];
         int code = fb_grid_code(B, p.x, p.y);
@@ -215,7 +400,7 @@ FB_FN void fe_book1(const FeBookDev &B, FeBookScratch &L) {
     FB_FOR(one, 1) {
         st.n_tracked = n_tr;
         st.before_tracking = n;
-        if (n > 0) { st.after_tracking = n_bit0; st.after_matching = n_tr; st.after_ransac = n_tr; }   // (:383: nothing is touched without features)
+        if (n > 0) { st.after_tracking = n_bit0; st.after_matching = n_match; st.after_ransac = n_tr; }   // (:383: nothing is touched without features)
     }
     // ---- detections (:657): cells in order whose maximum beats the threshold and that hold no live feature
     FB_FOR(k, det_cells) {
@@ -411,6 +596,7 @@ FB_FN void fe_book2(const FeBookDev &B, FeBookScratch &L) {
         const unsigned long long nid = id0 + (unsigned long long)n_new;
         B.x_info[6] = (int)(unsigned int)(nid & 0xFFFFFFFFULL); B.x_info[7] = (int)(unsigned int)(nid >> 32);
         B.x_info[8] = st.overflow; B.x_info[9] = n_new; B.x_info[10] = st.n_det; B.x_info[11] = n_tr;
+        B.x_info[12] = (int)(unsigned int)(st.ransac_draws & 0xFFFFFFFFULL); B.x_info[13] = (int)(unsigned int)(st.ransac_draws >> 32);
     }
     FB_SYNC();
 }

@@ -204,6 +204,7 @@ void mskfh_get_imu_state(void *h, int stream, double *out) {   // same 28-double
     for (int i = 0; i < 9; ++i) out[k++] = s.R_imu_cam0.m[i];
     for (int i = 0; i < 3; ++i) out[k++] = s.t_cam0_imu[i];
 }
+long long mskfh_num_device_frames(void *h, int stream) { return ((MultiRunner *)h)->system(stream).imgproc_ptr_->deviceFrames(); }
 int mskfh_num_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numUpdates(); }
 int mskfh_num_tsqr_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numTsqrUpdates(); }
 int mskfh_num_uncompressed_updates(void *h, int stream) { return ((MultiRunner *)h)->system(stream).msckfvio_ptr()->numUncompressedUpdates(); }

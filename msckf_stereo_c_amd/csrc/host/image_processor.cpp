@@ -601,8 +601,7 @@ bool ImageProcessor::feBooksOnHost() {
 
 bool ImageProcessor::canDeviceFrame() const {
     if (feBooksOnHost() || !stream_ || is_first_img) return false;
-    if (!(cfg_.compat_flags & MSKF_COMPAT_Q5_NO_RANSAC)) return false;       // the RANSAC of :482-500 sits between the tracks, on the host
-    return mskf_fe_grid_capacity(stream_) > 0;
+    return mskf_fe_grid_capacity(stream_) > 0;       // (the RANSAC of :482-500, when switched on, runs inside the device frame too)
 }
 
 bool ImageProcessor::frameBegin(double time_stamp, mskf_fe_frame_args &a) {
@@ -614,7 +613,7 @@ bool ImageProcessor::frameBegin(double time_stamp, mskf_fe_frame_args &a) {
         // tracking counters that survive frames without features
         const int32_t counters[3] = {after_tracking, after_matching, after_ransac};
         const int rc = mskf_fe_set_grid(stream_, (int)prev_.size(), (const uint64_t *)prev_.id.data(), prev_.lifetime.data(), prev_.cam0.data(), prev_.cam1.data(),
-                                        prev_.und0.data(), prev_.und1.data(), (uint64_t)next_feature_id, counters);
+                                        prev_.und0.data(), prev_.und1.data(), (uint64_t)next_feature_id, counters, (uint64_t)ransac_draws);
         if (rc != MSKF_OK) { fail("mskf_fe_set_grid", rc); return false; }
         device_grid_valid_ = true;
     }
@@ -622,6 +621,8 @@ bool ImageProcessor::frameBegin(double time_stamp, mskf_fe_frame_args &a) {
     integrateImuData(cam0_R_p_c, cam1_R_p_c);                // :360 (the window is consumed even when nothing is tracked: the buffer must not grow)
     cam0_R_p_c_ = cam0_R_p_c; cam1_R_p_c_ = cam1_R_p_c;
     computeHpred(cam0_R_p_c, a.Hpred);
+    std::memcpy(a.R_p_c[0], cam0_R_p_c.m, sizeof(a.R_p_c[0]));   // twoPointRansac's rotation compensation (:936-944), when it is on
+    std::memcpy(a.R_p_c[1], cam1_R_p_c.m, sizeof(a.R_p_c[1]));
     const int cap = mskf_fe_grid_capacity(stream_);
     curr_.id.resize(cap); curr_.lifetime.resize(cap); curr_.code.resize(cap); curr_.response.resize(cap);
     curr_.cam0.resize(cap); curr_.cam1.resize(cap); curr_.und0.resize(cap); curr_.und1.resize(cap);
@@ -640,6 +641,8 @@ void ImageProcessor::frameEnd(const mskf_fe_frame_args &a, bool is_draw) {
     for (size_t k = 0; k < n; ++k) curr_.code[k] = gridCode(curr_.cam0[k]);      // (the host path's arrays stay complete: a later host frame may read them)
     before_tracking = a.before_tracking; after_tracking = a.after_tracking; after_matching = a.after_matching; after_ransac = a.after_ransac;
     next_feature_id = (FeatureIDType)a.next_feature_id;
+    ransac_draws = (unsigned long long)a.ransac_draws;
+    ++device_frames_;
     stage_ = 0;
     if (is_draw) {   // :163-184
         prev_ids_.assign(prev_.id.begin(), prev_.id.end());

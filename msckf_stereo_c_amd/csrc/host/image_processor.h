@@ -190,6 +190,10 @@ class ImageProcessor {
     size_t logical_size_ = 0;
     int stage_ = 0;   // 0 idle, 1 first-frame stereo pending, 2 temporal pending, 3 candidates pending
     bool device_grid_valid_ = false;   // the device's grid is the one this object published last (false after a host-side frame)
+    long long device_frames_ = 0;      // frames that ran as one device call (mskf_fe_frame_batch_*)
+  public:
+    long long deviceFrames() const { return device_frames_; }
+  private:
     std::ofstream debug_;
 };
 

@@ -57,6 +57,8 @@ def lib():
         L.mskfh_stacked_rows.restype = C.c_longlong
         L.mskfh_num_resets.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_num_resets.restype = C.c_longlong
+        L.mskfh_num_device_frames.argtypes = [C.c_void_p, C.c_int]
+        L.mskfh_num_device_frames.restype = C.c_longlong
         L.mskfh_get_dump.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(TrackingInfo)]
         L.mskfh_get_msg.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mskfh_get_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -278,6 +280,10 @@ class Runner:
 
     def num_updates(self, stream=0):
         return self.L.mskfh_num_updates(self.h, stream)
+
+    def num_device_frames(self, stream=0):
+        """Front-end frames of the stream that ran as ONE device call (mskf_fe_frame_batch_*), books and RANSAC included."""
+        return int(self.L.mskfh_num_device_frames(self.h, stream))
 
     def num_tsqr_updates(self, stream=0):
         """Updates of the stream whose QR compression ran as Householder TSQR (the rest: Gram + Cholesky)."""

@@ -22,7 +22,11 @@ typedef unsigned long long u64;
 struct Feat { u64 id = 0; float response = 0.f; int lifetime = 0; mskf_point2f cam0{0, 0}, cam1{0, 0}, und0{0, 0}, und1{0, 0}; };
 typedef std::map<int, std::vector<Feat>> Grid;
 
-struct Cfg { int W, H, grid_row, grid_col, grid_min, grid_max, det_rows, det_cols, thr, q4; };
+struct Cfg { int W, H, grid_row, grid_col, grid_min, grid_max, det_rows, det_cols, thr, q4; int ransac; double K[2][4], R[2][9], ransac_thr; };
+
+// the product's host implementation of twoPointRansac (csrc/host/image_processor.cpp; == the oracle's, tests/test_ransac.py)
+extern "C" void mskfh_two_point_ransac(int n, const mskf_point2f *pts1_und, const mskf_point2f *pts2_und, const double *R_p_c, const double *intrinsics,
+                                       double inlier_error, double success_probability, unsigned long long *draws, int32_t *markers);
 struct Info { int before = 0, after_tracking = 0, after_matching = 0, after_ransac = 0; };
 
 static unsigned hash2(float x, float y, unsigned salt) {
@@ -49,7 +53,7 @@ struct Frame {      // the inputs of one frame
 };
 
 // ---------------------------------------------------------------------------------------------- reference flow
-static void ref_frame(const Cfg &c, const Frame &f, const Grid &prev, Grid &curr, Info &info, u64 &next_id,
+static void ref_frame(const Cfg &c, const Frame &f, const Grid &prev, Grid &curr, Info &info, u64 &next_id, u64 &ransac_draws,
                       std::vector<mskf_point2f> &cand_sent, std::vector<int> &cand_sent_index) {
     const int grid_height = c.H / c.grid_row, grid_width = c.W / c.grid_col;
     const int det_ch = (c.H + c.det_rows - 1) / c.det_rows, det_cw = (c.W + c.det_cols - 1) / c.det_cols;
@@ -61,11 +65,27 @@ static void ref_frame(const Cfg &c, const Frame &f, const Grid &prev, Grid &curr
     info.before = (int)flat.size();
     if (!flat.empty()) {
         info.after_tracking = info.after_matching = info.after_ransac = 0;
+        // :482-500 (Q5 cleared): the matched cam0 and cam1 pairs through twoPointRansac, a feature must be an inlier of both
+        std::vector<int> keep(flat.size(), 1);
+        if (c.ransac) {
+            std::vector<size_t> idx;
+            std::vector<mskf_point2f> p0, c0, p1, c1;
+            for (size_t i = 0; i < flat.size(); ++i) {
+                if ((f.t_status[i] & 3) != 3) continue;
+                idx.push_back(i);
+                p0.push_back(flat[i].und0); p1.push_back(flat[i].und1); c0.push_back(f.t_und0[i]); c1.push_back(f.t_und1[i]);
+            }
+            std::vector<int32_t> in0(idx.size() + 1), in1(idx.size() + 1);
+            mskfh_two_point_ransac((int)idx.size(), p0.data(), c0.data(), c.R[0], c.K[0], c.ransac_thr, 0.99, &ransac_draws, in0.data());
+            mskfh_two_point_ransac((int)idx.size(), p1.data(), c1.data(), c.R[1], c.K[1], c.ransac_thr, 0.99, &ransac_draws, in1.data());
+            for (size_t k = 0; k < idx.size(); ++k) keep[idx[k]] = in0[k] != 0 && in1[k] != 0;
+        }
         for (size_t i = 0; i < flat.size(); ++i) {
             if (!(f.t_status[i] & 1)) continue;
             ++info.after_tracking;
             if (!(f.t_status[i] & 2)) continue;
             ++info.after_matching;
+            if (!keep[i]) continue;
             const int row = static_cast<int>(f.t_out0[i].y / grid_height), col = static_cast<int>(f.t_out0[i].x / grid_width);
             const int code = row * c.grid_col + col;
             Feat g = flat[i];
@@ -168,7 +188,7 @@ int main(int argc, char **argv) {
     const int trials = argc > 1 ? std::atoi(argv[1]) : 300;
     std::mt19937 rng(12345);
     auto U = [&](int lo, int hi) { return (int)(rng() % (unsigned)(hi - lo + 1)) + lo; };
-    long frames_checked = 0, feats_checked = 0, pruned_cells = 0, cand_total = 0;
+    long frames_checked = 0, feats_checked = 0, pruned_cells = 0, cand_total = 0, ransac_rejected = 0, draws_total = 0;
     for (int trial = 0; trial < trials; ++trial) {
         Cfg c;
         const int sizes[][2] = {{752, 480}, {376, 240}, {333, 251}, {1280, 720}, {640, 400}};
@@ -178,6 +198,14 @@ int main(int argc, char **argv) {
         c.grid_min = U(1, 6); c.grid_max = c.grid_min + U(0, 3);
         c.det_rows = 30; c.det_cols = 47;
         c.thr = 10 * 256; c.q4 = U(0, 1);
+        // every other trial runs the 2-point RANSAC between the tracks: cameras with EuRoC-like focal lengths, a small rotation
+        c.ransac = trial & 1; c.ransac_thr = 3.0;
+        for (int cam = 0; cam < 2; ++cam) {
+            c.K[cam][0] = 458.654 - 1.2 * cam; c.K[cam][1] = 457.296 - 0.8 * cam; c.K[cam][2] = 367.215; c.K[cam][3] = 248.375;
+            const double wx = 1e-3 * U(-5, 5), wy = 1e-3 * U(-5, 5), wz = 1e-3 * U(-5, 5);
+            const double Rm[9] = {1.0, -wz, wy, wz, 1.0, -wx, -wy, wx, 1.0};
+            std::memcpy(c.R[cam], Rm, sizeof(Rm));
+        }
         const int grid_h = c.H / c.grid_row, grid_w = c.W / c.grid_col;
         const int det_ch = (c.H + c.det_rows - 1) / c.det_rows, det_cw = (c.W + c.det_cols - 1) / c.det_cols;
         const int n_cells = c.grid_row * c.grid_col;
@@ -199,7 +227,9 @@ int main(int argc, char **argv) {
         // reference-side state
         Grid prev, curr;
         Info info;
-        u64 next_id = 0;
+        u64 next_id = 0, ref_draws = 0;
+        std::vector<double> rs_pair(4 * (size_t)cap), rs_scalar(48);
+        std::vector<float> rs_pt(4 * (size_t)cap);
         const int n_frames = U(3, 8);
         for (int fr = 0; fr < n_frames; ++fr) {
             Frame f;
@@ -209,6 +239,9 @@ int main(int argc, char **argv) {
             const int n = (int)flat.size();
             if (n != st.n_prev) { std::printf("FAIL trial %d frame %d: n_prev %d vs %d\n", trial, fr, st.n_prev, n); return 1; }
             const int loss = U(0, 100);       // percent of the features this frame loses (some frames lose everything)
+            // RANSAC trials: the undistorted points move by a common flow (0: pure rotation, the degenerate branch) plus noise, a
+            // few of them wildly; otherwise they are unrelated to the previous frame's
+            const float flow_x = c.ransac ? 0.0011f * (float)U(-4, 4) : 0.f, flow_y = c.ransac ? 0.0009f * (float)U(-4, 4) : 0.f;
             f.t_out0.resize(n); f.t_out1.resize(n); f.t_und0.resize(n); f.t_und1.resize(n); f.t_status.resize(n);
             for (int i = 0; i < n; ++i) {
                 const int r = U(0, 99);
@@ -223,6 +256,12 @@ int main(int argc, char **argv) {
                 f.t_out1[i] = mskf_point2f{x - 5.5f, y + 0.125f};
                 f.t_und0[i] = mskf_point2f{x * 0.001f, y * 0.001f};
                 f.t_und1[i] = mskf_point2f{x * 0.001f - 0.01f, y * 0.001f};
+                if (c.ransac) {
+                    const float wild = U(0, 9) == 0 ? 0.02f * (float)U(-3, 3) : 0.f;
+                    const float zx = flat[i].und0.x * 0.1f * (float)U(0, 3) * flow_x, zy = flat[i].und0.y * 0.1f * (float)U(0, 3) * flow_y;    // depth-like spread along the flow
+                    f.t_und0[i] = mskf_point2f{flat[i].und0.x + flow_x + zx + 1e-5f * (float)U(-20, 20) + wild, flat[i].und0.y + flow_y + zy + 1e-5f * (float)U(-20, 20)};
+                    f.t_und1[i] = mskf_point2f{flat[i].und1.x + flow_x + zx + 1e-5f * (float)U(-20, 20), flat[i].und1.y + flow_y + zy + 1e-5f * (float)U(-20, 20) - wild};
+                }
                 if (f.t_status[i] != 3) { f.t_out1[i] = mskf_point2f{0, 0}; }
             }
             f.keys.assign(det_cells, 0ULL);
@@ -240,7 +279,7 @@ int main(int argc, char **argv) {
             }
             // ---- reference
             std::vector<mskf_point2f> ref_cand; std::vector<int> ref_cand_index;
-            ref_frame(c, f, prev, curr, info, next_id, ref_cand, ref_cand_index);
+            ref_frame(c, f, prev, curr, info, next_id, ref_draws, ref_cand, ref_cand_index);
             // ---- device logic
             FeBookDev B;
             std::memset(&B, 0, sizeof(B));
@@ -253,6 +292,9 @@ int main(int argc, char **argv) {
             B.cand_pt = cand_pt.data(); B.cand_index = cand_index.data(); B.cand_score = cand_score.data(); B.cand_off = cand_off.data(); B.cand_cnt = cand_cnt.data();
             B.c_out0 = c_out0.data(); B.c_out1 = c_out1.data(); B.c_und0 = c_und0.data(); B.c_und1 = c_und1.data(); B.c_status = c_status.data();
             B.cell_count = cell_count.data();
+            B.ransac = c.ransac; B.ransac_iters = 7; B.ransac_thr = c.ransac_thr;
+            for (int cam = 0; cam < 2; ++cam) { B.ransac_npu[cam] = 2.0 / (c.K[cam][0] + c.K[cam][1]); std::memcpy(B.R_p_c[cam], c.R[cam], sizeof(B.R_p_c[cam])); }
+            B.rs_pair = rs_pair.data(); B.rs_pt = rs_pt.data(); B.rs_scalar = rs_scalar.data();
             B.x_info = x_info.data(); B.x_id = x_id.data(); B.x_lifetime = x_life.data(); B.x_cam0 = x_c0.data(); B.x_cam1 = x_c1.data(); B.x_und0 = x_u0.data(); B.x_und1 = x_u1.data();
             FeBookScratch L;
             fe_book_scratch_init(L, scratch.data(), cap, cand_cap, det_cap, n_codes, det_cells);
@@ -289,6 +331,9 @@ int main(int argc, char **argv) {
                     return 1;
                 }
             }
+            if (st.ransac_draws != ref_draws) { std::printf("FAIL trial %d frame %d: RANSAC draw counter %llu vs %llu\n", trial, fr, st.ransac_draws, ref_draws); return 1; }
+            ransac_rejected += info.after_matching - info.after_ransac;
+            if (fr == n_frames - 1) draws_total += (long)ref_draws;
             if (st.next_id != next_id) { std::printf("FAIL trial %d frame %d: next id %llu vs %llu\n", trial, fr, st.next_id, next_id); return 1; }
             if (st.before_tracking != info.before || st.after_tracking != info.after_tracking || st.after_matching != info.after_matching ||
                 st.after_ransac != info.after_ransac) { std::printf("FAIL trial %d frame %d: tracking info\n", trial, fr); return 1; }
@@ -298,6 +343,7 @@ int main(int argc, char **argv) {
             ip ^= 1;
         }
     }
-    std::printf("fe_book: %ld frames, %ld features, %ld candidates, %ld full cells: device logic == reference flow\n", frames_checked, feats_checked, cand_total, pruned_cells);
+    std::printf("fe_book: %ld frames, %ld features, %ld candidates, %ld full cells, %ld RANSAC rejections (%ld numbers drawn, counter checked every frame): device logic == reference flow\n",
+                frames_checked, feats_checked, cand_total, pruned_cells, ransac_rejected, draws_total);
     return 0;
 }

@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
-    assert L.mskf_abi_version() == 3
+    assert L.mskf_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_device():

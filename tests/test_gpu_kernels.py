@@ -614,15 +614,15 @@ def test_compression_mode_is_validated(gpu_ctx, oracle):
 
 
 def test_device_frame_entry_points_refuse_what_they_cannot_do(gpu_ctx, oracle):
-    """mskf_fe_frame_batch_* (whole front-end frames on the device): no grid handed over yet, output arrays too small, the
-    2-point RANSAC configuration (the RANSAC sits between the track calls, on the host) and per-cell limits above the
-    kernels' bound are refused with a status and a message, never silently."""
+    """mskf_fe_frame_batch_* (whole front-end frames on the device): no grid handed over yet, output arrays too small and
+    per-cell limits above the kernels' bound are refused with a status and a message, never silently; the 2-point RANSAC
+    configuration (refused until round 4, when the RANSAC moved from the host into the frame) is accepted."""
     import ctypes as C
     from msckf_stereo_c_amd.ctypes_types import COMPAT_REFERENCE, POINT2F
     L = gpu_ctx.L
     L.mskf_fe_grid_capacity.argtypes = [C.c_void_p]
     L.mskf_fe_frame_batch_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(capi.FeFrameArgs)]
-    L.mskf_fe_set_grid.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
+    L.mskf_fe_set_grid.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_uint64]
     w, h = 376, 240
     calib = oracle.euroc_calib(w, h)
     img = np.zeros((h, w), np.uint8)
@@ -643,15 +643,16 @@ def test_device_frame_entry_points_refuse_what_they_cannot_do(gpu_ctx, oracle):
     cap = L.mskf_fe_grid_capacity(s.h)
     assert cap >= 4 * 5 * 4
     assert frame(s, cap) == -1 and b"no grid on the device" in L.mskf_last_error()          # MSKF_ERR_INVALID: first frame goes the phased way
-    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None) == 0
+    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None, 0) == 0
     assert frame(s, cap - 1) == -1                                                          # output arrays too small
-    assert L.mskf_fe_set_grid(s.h, cap + 1, None, None, None, None, None, None, 0, None) == -1
+    assert L.mskf_fe_set_grid(s.h, cap + 1, None, None, None, None, None, None, 0, None, 0) == -1
     s.close()
     s = capi.Stream(gpu_ctx, calib, default_fe_cfg(compat=COMPAT_REFERENCE & ~8), default_ekf_cfg())     # Q5 cleared: RANSAC on
-    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None) == 0
-    assert frame(s, L.mskf_fe_grid_capacity(s.h)) == -3 and b"RANSAC" in L.mskf_last_error()   # MSKF_ERR_UNSUPPORTED
+    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None, 0) == 0
+    assert frame(s, L.mskf_fe_grid_capacity(s.h)) == 0                                       # accepted: the RANSAC runs inside the frame
+    assert L.mskf_fe_frame_batch_end(gpu_ctx.h) == 0
     s.close()
     s = capi.Stream(gpu_ctx, calib, default_fe_cfg(grid_min=17, grid_max=20), default_ekf_cfg())
     assert L.mskf_fe_grid_capacity(s.h) == 0
-    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None) == -3
+    assert L.mskf_fe_set_grid(s.h, 0, None, None, None, None, None, None, 0, None, 0) == -3
     s.close()

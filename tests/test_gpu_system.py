@@ -238,10 +238,12 @@ def _lockstep(oracle, syn, fe, ekf, n_frames, frame_hook=None, check_every=1, af
 
 def test_compat_switches_off(oracle):
     """compat_flags = 0: cleared message (no Q1), true previous timestamp (no Q2), sieve-order responses (no Q4) and the
-    2-point RANSAC of image_processor.cpp:911-1135 on both cameras (no Q5)."""
+    2-point RANSAC of image_processor.cpp:911-1135 on both cameras (no Q5).  Since round 4 the RANSAC runs
+    inside the device frame (fe_book1): every frame after the first is one device call."""
     syn = oracle.Synth(seed=0x5EED0030, width=376, height=240)
     fe, ekf = default_fe_cfg(compat=0), default_ekf_cfg()
     osys, run = _lockstep(oracle, syn, fe, ekf, 60)
+    assert run.num_device_frames() == 59
     compare_msgs(osys, run)
     assert len(run.msg()) == len(run.dump()[0])          # message holds exactly the live features
     compare_poses(osys, run)
@@ -276,6 +278,7 @@ def test_ransac_rejects_independently_moving_patch(oracle):
         rejected.append(info.after_matching - info.after_ransac)
 
     osys, run = _lockstep(oracle, syn, fe, ekf, 70, frame_hook=hook, after_frame=after)
+    assert run.num_device_frames() == 69                     # the RANSAC ran on the device, between the track kernels
     assert sum(rejected[:30]) <= 2                           # static scene: (almost) nothing to reject
     assert sum(rejected[31:]) >= 5, rejected                 # features riding on the patch are thrown out
     compare_msgs(osys, run)
@@ -681,9 +684,12 @@ def test_device_books_equal_host_books(oracle):
     the grid resident in device memory) against the phased path with the books on the host (mskf_fe_track + the host
     mirror's phaseAfter1 / phaseAfter2), on the same streams: identical grids in every frame, identical messages
     (Q1 tail included), identical tracking info, poses within rounding — and both equal the oracle.  Streams: a normal
-    one, a fast one (many lost features), and a grid with partial rows / columns (333 x 251, quirk Q7)."""
+    one, a fast one (many lost features), a grid with partial rows / columns (333 x 251, quirk Q7), and one with the
+    reference's quirks off, i.e. with the 2-point RANSAC between the tracks (host: cg::two_point_ransac after the first track
+    call; device: inside fe_book1)."""
     cases = [(376, 240, 0x5EED0080, 1.0, default_fe_cfg()), (376, 240, 0x5EED0081, 2.5, default_fe_cfg(grid_row=3, grid_col=4, grid_min=2, grid_max=3)),
-             (333, 251, 0x5EED0082, 1.0, default_fe_cfg(grid_row=4, grid_col=5, grid_min=3, grid_max=4))]
+             (333, 251, 0x5EED0082, 1.0, default_fe_cfg(grid_row=4, grid_col=5, grid_min=3, grid_max=4)),
+             (376, 240, 0x5EED0083, 1.5, default_fe_cfg(compat=0))]       # RANSAC on: host mirror's twoPointRansac vs fb_two_point_ransac in the kernel
     for w, h, seed, motion, fe in cases:
         ekf = default_ekf_cfg(max_cam_state_size=10)
         syn = oracle.Synth(seed=seed, width=w, height=h, motion_scale=motion)

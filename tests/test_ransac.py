@@ -76,3 +76,32 @@ def test_host_ransac_equals_oracle(oracle, seed, translation):
     assert draws.value == ref_draws
     assert np.array_equal(got, ref)
     assert 0 < got.sum() < len(got)
+
+
+@pytest.mark.parametrize("seed,translation", [(3, (0.04, -0.01, 0.02)), (4, (0.0, 0.0, 0.0)), (5, (0.2, 0.1, -0.05)), (6, (0.002, 0.0, 0.001)), (7, (0.01, 0.03, 0.0))])
+def test_device_book_ransac_equals_oracle(oracle, tmp_path, seed, translation):
+    """The DEVICE source of the RANSAC (fb_two_point_ransac in csrc/hip/fe_book.h: what the bookkeeping kernel of a device frame
+    runs between the track calls when MSKF_COMPAT_Q5_NO_RANSAC is cleared) executed on the CPU == oracle, marker for marker,
+    draw counter included: general motion, pure rotation (degenerate branch), large and tiny translations, and the small inputs
+    (0, 2 pairs).  On the device the per-pair and per-hypothesis phases run in parallel; the two index-order sums
+    (rescalePoints, mean length) are summed by one item in that order."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libfe_book_ransac.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I", root, "-o", so,
+                           os.path.join(root, "tests", "cpp", "fe_book_ransac.cpp")])
+    f = C.CDLL(so).fb_ransac_run
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    f.restype = None
+    calib, px1, px2, R_c_p = _scene(oracle, seed, translation=translation)
+    K, D = np.array(calib.cam0_intrinsics), np.array(calib.cam0_distortion)
+    R = np.ascontiguousarray(R_c_p, dtype=np.float64)
+    for n in (len(px1), 57, 2, 0):
+        ref, ref_draws = oracle.two_point_ransac(calib, default_fe_cfg(), 0, px1[:n], px2[:n], R_c_p, draws=1000 * seed + n)
+        u1 = np.ascontiguousarray(oracle.undistort(K, D, px1[:n]), dtype=np.float32).reshape(-1, 2)
+        u2 = np.ascontiguousarray(oracle.undistort(K, D, px2[:n]), dtype=np.float32).reshape(-1, 2)
+        got = np.zeros(max(n, 1), np.int32)
+        draws = C.c_ulonglong(1000 * seed + n)
+        f(n, u1.ctypes.data, u2.ctypes.data, R.ctypes.data, float(K[0]), float(K[1]), 3.0, 7, C.byref(draws), got.ctypes.data)
+        assert draws.value == ref_draws, (n, draws.value, ref_draws)
+        assert np.array_equal(got[:n], ref), (n, int(got[:n].sum()), int(ref.sum()))
