@@ -88,6 +88,9 @@ def parse(argv=None):
     ap.add_argument("--compression", choices=["auto", "gram", "tsqr"], default="auto",
                     help="QR compression of the stacked Jacobian (msckf_vio.cpp:795-817): auto = Gram + regularised Cholesky with the "
                          "Householder TSQR where the device decides it is needed (default), gram = Gram only, tsqr = the literal Householder path always")
+    ap.add_argument("--householder-steps", type=int, default=-1,
+                    help="steps of the SECOND timed window, run with the literal Householder compression on every update "
+                         "(value_householder in the JSON line); -1 = min(steps, 12) when the first window ran with --compression auto, 0 = off")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reductions, "
                     "JSON line) without any device work: for the gloo tests only, the line it prints says so")
@@ -96,6 +99,8 @@ def parse(argv=None):
     for k in ("width", "height", "clones", "grid", "streams", "groups", "loop", "cpu_frames", "cpu_all_frames"):
         if getattr(args, k) is None:
             setattr(args, k, preset[k] if k not in ("streams", "groups") else int(os.environ.get("MSKF_BENCH_" + k.upper(), preset[k])))
+    if args.householder_steps < 0:
+        args.householder_steps = min(args.steps, 12) if (args.compression == "auto" and not args.no_pipeline) else 0
     if args.prime is None:
         # static start, gravity / bias initialisation, clone window full — and one whole period of the looping trajectory, so that
         # every group has met its largest frame (staging buffers grow to their final size) before the timed steps
@@ -440,7 +445,9 @@ def main(argv=None):
     cooldown = (args.steps + 8) if n_groups > 1 else 0      # frames a group may step beyond its own W + K while the window is open
     if max_offset:
         run.set_stagger(args.stagger)
-    imus = [imu_array(s, (total_frames + max_offset + cooldown + 3) * 10 + 20) for s in syns]
+    hh_warm = 3
+    hh_frames = (hh_warm + args.householder_steps + cooldown + 8) if args.householder_steps > 0 else 0      # frames the second window may add
+    imus = [imu_array(s, (total_frames + max_offset + 2 * cooldown + hh_frames + 3) * 10 + 20) for s in syns]
     for s in range(n_streams):
         u = s % args.unique
         cam0 = base + (u * 2 + 0) * n_keys * frame_bytes
@@ -510,6 +517,7 @@ def main(argv=None):
         s_imu = run.imu_state(0)
     hashes = gather_hashes(state_hash(s_ids, s_life, s_c0, s_c1, s_imu), world, red_dev)
     id_mismatch = sum(1 for h in hashes if h != hashes[0])
+    frames_by_group = [run.frames_done(g) - run.group_offset(g) - args.prime for g in range(n_groups)] if pipe else []
 
     # sanity of the workload actually processed (steady state reached, filter alive)
     feats = [len(run.dump(s)[0]) for s in range(0, n_streams, max(1, n_streams // 16))]
@@ -518,6 +526,31 @@ def main(argv=None):
     n_upd = run.num_updates(0)
 
     status = 0
+    n_tsqr, n_uncompressed, n_rows, n_resets = run.num_tsqr_updates(0), run.num_uncompressed_updates(0), run.stacked_rows(0), run.num_resets(0)
+
+    # ---- second window: the same streams go on with the QR of msckf_vio.cpp:795-817 taken literally - Householder (TSQR) on
+    #      EVERY update instead of Gram + regularised Cholesky with TSQR where the device asks for it - so that the line carries
+    #      both rates from one run of the driver's command (the trajectories checked against the oracle below run through both)
+    hh = None
+    if pipe and args.householder_steps > 0:
+        run.set_compression(2)
+        first2 = max(run.frames_done(g) - run.group_offset(g) for g in range(n_groups))      # every batch catches up to here first
+        tsqr0 = run.num_tsqr_updates(0)
+        run.set_timing(timing_period)
+        run.get_timing(reset=True)
+        barrier()
+        el2 = run.run_timed(first2, hh_warm, args.householder_steps, max_extra=cooldown)
+        barrier()
+        timing2 = run.get_timing(reset=True)
+        run.set_timing(False)
+        run.set_compression({"auto": 0, "gram": 1, "tsqr": 2}[args.compression])
+        el2, frames2 = aggregate_throughput(el2, n_streams * args.householder_steps, world, device=red_dev)
+        dom2 = max(timing2, key=lambda k: timing2[k][0])
+        hh = {"value_householder": frames2 / el2, "steps": args.householder_steps, "warmup": hh_warm, "ms_per_step": el2 * 1e3 / args.householder_steps,
+              "tsqr_updates_stream0_in_window_and_warmup": run.num_tsqr_updates(0) - tsqr0,
+              "dominant_kernel": dom2, "kernels": {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)}
+                                                   for k, v in timing2.items() if v[1] and k.startswith("k_ekf")}}
+
     if rank == 0:
         value = frames_total / elapsed
         # ---- roofline of the dominant kernel (largest HIP-event time inside the timed region)
@@ -536,7 +569,8 @@ def main(argv=None):
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
         else:
-            per_unit = {"k_track4": LK_BYTES_PER_TRACK, "k_pyr_down": 5, "k_detect_cells": 1}.get(dom, 0)
+            # k_pyr_down (one launch for levels 1..3): level 0 read once + the three levels written = (64 / 21 + 1) bytes per output pixel
+            per_unit = {"k_track4": LK_BYTES_PER_TRACK, "k_pyr_down": 64.0 / 21.0 + 1.0, "k_detect_cells": 1}.get(dom, 0)
             achieved = units / max(launches, 1) * per_unit / avg_s / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
@@ -608,7 +642,6 @@ def main(argv=None):
             # (a thread's window = the span between its first frame boundary inside the timed window and the first one after
             # it; summed over the groups and divided by K x groups it is that thread's wall time per group-step)
             fe_items, ekf_items = per(R.Runner.FE_THREAD_PHASES), per(R.Runner.EKF_THREAD_PHASES)
-            frames_by_group = [run.frames_done(g) - run.group_offset(g) - args.prime for g in range(n_groups)]
             host_phases = {
                 "front_end_thread": dict(fe_items, sum=round(sum(fe_items.values()), 3),
                                          window=round(sum(w["fe_close"] - w["fe_open"] for w in windows) * 1e3 / args.steps / n_groups, 3)),
@@ -640,10 +673,10 @@ def main(argv=None):
                                    % (CONFIGS[args.config]["name"], args.config, args.width, args.height, args.clones, args.grid, n_feat, n_streams,
                                       n_groups, args.host_threads, ", FE|EKF pipelined" if pipe else "", seq_note, n_pose_streams),
                        "streams_per_gpu": n_streams, "features_per_frame": n_feat, "cam_clones": n_clones,
-                       "compression": args.compression, "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": run.num_tsqr_updates(0),
-                       "ekf_uncompressed_updates_stream0": run.num_uncompressed_updates(0),
-                       "ekf_rows_per_update_stream0": round(run.stacked_rows(0) / max(n_upd, 1), 1),
-                       "ekf_resets_stream0": run.num_resets(0), "render_s": round(render_s, 1), "kernel_timing_period": timing_period,
+                       "compression": args.compression, "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": n_tsqr,
+                       "ekf_uncompressed_updates_stream0": n_uncompressed,
+                       "ekf_rows_per_update_stream0": round(n_rows / max(n_upd, 1), 1),
+                       "ekf_resets_stream0": n_resets, "render_s": round(render_s, 1), "kernel_timing_period": timing_period,
                        "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "filter_host_threads_per_group": ekf_host_threads or args.host_threads,
@@ -651,6 +684,7 @@ def main(argv=None):
                                      if (pipe and n_groups > 1) else "fixed: every batch of streams on its own group's queues"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "id_mismatch": id_mismatch,
+            "value_householder": hh["value_householder"] if hh else None, "householder_window": hh,
             "roofline": roof, "mfma": mfma, "kernels": kernels,
             "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
             "host_phases_ms_per_step": host_phases,

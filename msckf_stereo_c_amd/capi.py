@@ -57,7 +57,7 @@ EXPORTS = [
     "mskf_ekf_get_dim", "mskf_ekf_get_cov", "mskf_ekf_set_cov", "mskf_ekf_debug_read", "mskf_ctx_get_host_time", "mskf_fe_track_batch_begin", "mskf_fe_track_batch_end",
     "mskf_ekf_update_batch_begin", "mskf_ekf_update_batch_end", "mskf_ekf_get_pos_var_batch_begin", "mskf_ekf_get_pos_var_batch_end", "mskf_ctx_timing_gate",
     "mskf_fe_grid_capacity", "mskf_fe_set_grid", "mskf_fe_frame_batch_begin", "mskf_fe_frame_batch_end", "mskf_ctx_set_wait_mode",
-    "mskf_stream_rebind", "mskf_ctx_record_point", "mskf_ctx_wait_point", "mskf_point_destroy",
+    "mskf_stream_rebind", "mskf_ctx_record_point", "mskf_ctx_wait_point", "mskf_point_destroy", "mskf_ekf_set_compression_mode",
 ]
 
 

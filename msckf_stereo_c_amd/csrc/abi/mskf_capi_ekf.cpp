@@ -8,7 +8,6 @@
 
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st);
-void ekf_launch_phiq(const EkfStreamDev *d, int n, int max_steps, hipStream_t st);
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave, const int *work_small, int n_small, const int *work_big, int n_big,
@@ -203,6 +202,15 @@ extern "C" int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d) {
     return MSKF_OK;
 }
 
+extern "C" int mskf_ekf_set_compression_mode(mskf_stream *s, int mode) {
+    if (!s) return MSKF_ERR_INVALID;
+    if (mode < 0 || mode > 2) { mskf_set_error("compression_mode must be 0 (auto), 1 (Gram only) or 2 (Householder TSQR)"); return MSKF_ERR_INVALID; }
+    if (s->ctx_ekf->pend_upd.active) { mskf_set_error("an update batch of the stream's context is pending"); return MSKF_ERR_INVALID; }
+    s->ekf.compression_mode = mode;
+    extra_of(s)->desc_valid = false;          // the cached descriptor carries the mode
+    return MSKF_OK;
+}
+
 extern "C" int mskf_ekf_get_dim(mskf_stream *s, int *d) {
     if (!s || !d) return MSKF_ERR_INVALID;
     *d = s->ekf_state.d;
@@ -277,14 +285,11 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     if (!ctx || n <= 0 || !streams || !n_steps || !steps || !J) return MSKF_ERR_INVALID;
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64), scratch = 0;
+    size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
     for (int i = 0; i < n; ++i) {
         if (!streams[i] || streams[i]->ctx_ekf != ctx || n_steps[i] < 0 || (n_steps[i] && !steps[i])) return MSKF_ERR_INVALID;
         bytes += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64) + align_up(sizeof(double) * 6 * EKF_IMU_DIM, 64);
-        scratch += align_up(sizeof(double) * 2 * EKF_IMU_DIM * EKF_IMU_DIM * (size_t)n_steps[i], 64);   // Phi_k, Q_k (device only)
     }
-    const size_t copy_cap = bytes;
-    bytes += scratch;
     if (!ctx->pred_done) MSKF_HIPCHK(hipEventCreateWithFlags(&ctx->pred_done, hipEventDisableTiming));
     if (ctx->pred_pending) { MSKF_HIPCHK(hipEventSynchronize(ctx->pred_done)); ctx->pred_pending = false; }
     if (bytes > ctx->pred_arena.cap) {
@@ -296,17 +301,13 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     EkfStreamDev *D = (EkfStreamDev *)h;
     size_t off = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
     bool any = false;
-    size_t soff = copy_cap;          // Phi/Q scratch lives behind the copied part of the device arena
-    int max_steps = 0;
     for (int i = 0; i < n; ++i) {
         mskf_stream *s = streams[i];
         EkfStreamState &E = s->ekf_state;
         base_desc(s, D[i]);
         D[i].n_steps = n_steps[i];
         if (n_steps[i] > 0) {
-            D[i].PhiQ = (const double *)(dv + soff);       // filled by k_ekf_phiq, consumed by k_ekf_propagate
-            soff += align_up(sizeof(double) * 2 * EKF_IMU_DIM * EKF_IMU_DIM * (size_t)n_steps[i], 64);
-            max_steps = std::max(max_steps, (int)n_steps[i]);
+            D[i].PhiQ = nullptr;                           // Phi_k, Q_k are built inside k_ekf_propagate from the IMU steps
             std::memcpy(h + off, steps[i], sizeof(mskf_imu_step) * (size_t)n_steps[i]);
             D[i].imu_steps = (const mskf_imu_step *)(dv + off);
             off += align_up(sizeof(mskf_imu_step) * (size_t)n_steps[i], 64);
@@ -326,7 +327,6 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_PROPAGATE);
-        ekf_launch_phiq((const EkfStreamDev *)dv, n, max_steps, st);
         ekf_launch_propagate((const EkfStreamDev *)dv, n, st);
         mskf_t_end(ctx, ts, n);
     }
@@ -498,7 +498,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     int max_feat_pairs = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, tri; int n_tri; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
-    bool any_pv = false;
+    bool any_pv_nofeat = false;
     std::vector<Lay> lay(n);
     size_t in_bytes = 0, out_bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -562,7 +562,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         L.o_pos = align_up(L.o_gamma + sizeof(double) * (size_t)a.n_feat, 16);
         L.o_rows = align_up(L.o_pos + sizeof(double) * 3 * (size_t)a.n_feat, 16);
         L.o_status = L.o_rows + 32 + 32;           // rows_out (5 ints, padded to 32 bytes) + 3 position variances
-        any_pv |= a.pos_var_out != nullptr;
+        any_pv_nofeat |= a.pos_var_out != nullptr && a.n_feat == 0;
         out_bytes = align_up(L.o_status + (size_t)a.n_feat, 64);
         if (m_total > E.max_rows) {
             // Growth of the stacked-Jacobian buffer, STREAM-ORDERED: hipFree / hipMalloc synchronise the whole device, and a
@@ -716,7 +716,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
         mskf_t_end(ctx, ts, any_general ? (long long)(4.0 * d3) : 0);
-        if (any_pv) ekf_launch_posvar_upd(ctx->ekf_desc.d, n, st);       // the position variances ride home with the results
+        if (any_pv_nofeat) ekf_launch_posvar_upd(ctx->ekf_desc.d, n, st);       // (streams with features get theirs from the downdate's epilogue)
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));

@@ -454,7 +454,7 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
     if (ctx->pend_frame.active || ctx->pend_trk.active) { mskf_set_error("a batch of this context is still pending"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    int rc = ctx->jobs.ensure((size_t)n * 2 * (MSKF_LEVELS - 1));
+    int rc = ctx->jobs.ensure((size_t)n * 2);
     if (rc != MSKF_OK) return rc;
     rc = ctx->desc[0].ensure(n);
     if (rc != MSKF_OK) return rc;
@@ -488,28 +488,26 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
         s->has_curr = true;
         max_w = std::max(max_w, s->w); max_h = std::max(max_h, s->h);
     }
-    // pyramid levels 1..3 of both cameras, one launch per level over all streams
-    int max_dw[MSKF_LEVELS] = {0}, max_dh[MSKF_LEVELS] = {0};
-    for (int l = 1; l < MSKF_LEVELS; ++l)
+    // pyramid levels 1..3 of both cameras of every stream: ONE launch (k_pyr_down3)
+    static_assert(MSKF_LEVELS == 4, "k_pyr_down3 builds exactly the levels 1, 2, 3");
+    {
+        long long px = 0;
         for (int i = 0; i < n; ++i) {
             mskf_stream *s = streams[i];
             for (int c = 0; c < 2; ++c) {
-                PyrJob &j = ctx->jobs.h[(size_t)(l - 1) * 2 * n + 2 * i + c];
+                Pyr3Job &j = ctx->jobs.h[2 * (size_t)i + c];
                 const int pi = c == 0 ? s->i_curr0 : s->i_curr1;
                 uint8_t *base = s->pyr[pi];
-                j.src = (l == 1 && s->lvl0[pi]) ? s->lvl0[pi] : base + s->lvl_off[l - 1];
-                j.dst = base + s->lvl_off[l];
-                j.sw = s->lw[l - 1]; j.sh = s->lh[l - 1]; j.dw = s->lw[l]; j.dh = s->lh[l];
+                j.src = s->lvl0[pi] ? s->lvl0[pi] : base + s->lvl_off[0];
+                j.d1 = base + s->lvl_off[1]; j.d2 = base + s->lvl_off[2]; j.d3 = base + s->lvl_off[3];
+                j.w0 = s->lw[0]; j.h0 = s->lh[0];
             }
-            max_dw[l] = std::max(max_dw[l], s->lw[l]); max_dh[l] = std::max(max_dh[l], s->lh[l]);
+            for (int l = 1; l < MSKF_LEVELS; ++l) px += 2LL * s->lw[l] * s->lh[l];
         }
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(PyrJob) * (size_t)n * 2 * (MSKF_LEVELS - 1), hipMemcpyHostToDevice, st));
-    for (int l = 1; l < MSKF_LEVELS; ++l) {
-        long long px = 0;
-        for (int i = 0; i < n; ++i) px += 2LL * streams[i]->lw[l] * streams[i]->lh[l];
+        MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(Pyr3Job) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
         const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
-        fe_launch_pyr_down(ctx->jobs.d + (size_t)(l - 1) * 2 * n, 2 * n, max_dw[l], max_dh[l], st);
-        mskf_t_end(ctx, ts, px);
+        fe_launch_pyr_down3(ctx->jobs.d, 2 * n, max_w, max_h, st);
+        mskf_t_end(ctx, ts, px);          // units: output pixels of the three levels
     }
     // detector per-cell maxima on cam0 level 0
     for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);

@@ -9,10 +9,10 @@
 #include "../hip/ekf_device.h"
 #include "host_math.h"
 
-struct PyrJob { const uint8_t *src; uint8_t *dst; int sw, sh, dw, dh; };
+struct Pyr3Job { const uint8_t *src; uint8_t *d1, *d2, *d3; int w0, h0; };      // one image: level 0 in, levels 1..3 out (fe_kernels.hip)
 
 extern "C" {
-void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t st);
+void fe_launch_pyr_down3(const Pyr3Job *jobs_dev, int n_jobs, int max_w0, int max_h0, hipStream_t st);
 // Host wait for everything queued on the context's stream.  MSKF_WAIT=block (default when the process runs
 // more waiting host threads than it has cores to spin on) parks the thread on an interrupt-driven event instead of
 // spinning in hipStreamSynchronize, leaving the core to the other groups' host phases.
@@ -93,7 +93,7 @@ struct mskf_ctx {
     unsigned long long push_gen = 0;
     hipEvent_t cell_ev = nullptr;     // recorded behind the D2H copy of the per-cell maxima of the last push
     bool cell_keys_dirty = true;      // the key array holds bytes no generation tag explains (fresh allocation): clear before use
-    PinnedDev<PyrJob> jobs;
+    PinnedDev<Pyr3Job> jobs;
     PinnedDev<EkfStreamDev> ekf_desc;
     PinnedDev<char> upd_in, upd_out;     // inputs / results of every stream of an update batch (one copy each way)
     PinnedDev<char> pred_arena;          // descriptors + IMU steps + J of mskf_ekf_predict_batch

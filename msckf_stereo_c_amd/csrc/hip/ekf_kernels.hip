@@ -112,21 +112,9 @@ __device__ __forceinline__ void build_phi_q(const mskf_imu_step &st, const doubl
     __syncthreads();
     }
 
-// Phi_k, Q_k of every IMU step of every stream, one workgroup per (step, stream): they do not depend on the
-// covariance, so only the P recursion itself stays serial in k_ekf_propagate.
-__global__ __launch_bounds__(WG) void k_ekf_phiq(const EkfStreamDev *streams) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    const int step = blockIdx.x;
-    if (step >= S.n_steps || !S.imu_steps || !S.PhiQ) return;
-    constexpr int N = EKF_IMU_DIM;
-    __shared__ double sPhi[N * N], sA[N * N], sB[N * N];
-    build_phi_q(S.imu_steps[step], S.qc, sPhi, sA, sB);
-    double *out = const_cast<double *>(S.PhiQ) + (size_t)step * 2 * N * N;
-    for (int i = threadIdx.x; i < N * N; i += WG) { out[i] = sPhi[i]; out[N * N + i] = sB[i]; }
-}
-
 // ------------------------------------------------------------------------------------ propagate (+ augment)
-// Per IMU step: P_II <- sym(Phi P_II Phi^T + Q) (in LDS); the clone cross terms are propagated once with the
+// Per IMU step: Phi, Q (build_phi_q; rounds 1-3 built them in a launch of its own, one workgroup per step: one more link in the
+// frame's launch chain, 360 us in the busy device for 10 us of work), P_II <- sym(Phi P_II Phi^T + Q) (in LDS); the clone cross terms are propagated once with the
 // composed transition  P_IC <- (Phi_n ... Phi_1) P_IC  (one pass over P instead of one per IMU sample),
 // P_CI <- P_IC^T.  With S.J set the state augmentation (rows/cols [d, d+6) = J [P_II P_IC], corner
 // sym(J P_II J^T)) is fused into the same pass.
@@ -268,12 +256,13 @@ __global__ void k_ekf_posvar(const EkfStreamDev *streams, int n, double *out) {
     out[i] = S.P[(size_t)k * S.ld + k];
 }
 
-// the same at the end of an update batch, into every stream's own result slot (mskf_ekf_update_args.pos_var_out)
+// the same for the streams of an update batch that have NO features (nothing of the update chain runs for them), into the
+// stream's own result slot (mskf_ekf_update_args.pos_var_out)
 __global__ void k_ekf_posvar_upd(const EkfStreamDev *streams, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n) return;
     const EkfStreamDev &S = streams[i / 3];
-    if (!S.pos_var_out) return;
+    if (!S.pos_var_out || S.n_feat > 0) return;        // (a stream with an update got them from k_ekf_gemm<PUPD>'s epilogue)
     const int k = 12 + i % 3;
     S.pos_var_out[i % 3] = S.P[(size_t)k * S.ld + k];
 }
@@ -1173,9 +1162,6 @@ __global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
 // ------------------------------------------------------------------------------------ launchers
 extern "C" {
 void ekf_launch_propagate(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_propagate, dim3(1, n), dim3(WG), 0, st, d); }
-void ekf_launch_phiq(const EkfStreamDev *d, int n, int max_steps, hipStream_t st) {
-    if (max_steps > 0) hipLaunchKernelGGL(k_ekf_phiq, dim3(max_steps, n), dim3(WG), 0, st, d);
-}
 void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_augment, dim3(1, n), dim3(WG), 0, st, d); }
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_remove_clone, dim3(32, n), dim3(WG), 0, st, d);

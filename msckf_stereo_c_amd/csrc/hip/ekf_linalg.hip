@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         if (i == j) v += diag_add;
         C[(size_t)i * ld + j] = v;
         if (TR::SYM && i != j) C[(size_t)j * ld + i] = v;
+        // the position variances P(12..14, 12..14) after the update ride home with the results (onlineReset, msckf_vio.cpp:1194-1196;
+        // round 3 read them with a launch of its own behind this one)
+        if (MODE == GM_PUPD && i == j && i >= 12 && i < 15 && S.pos_var_out) S.pos_var_out[i - 12] = v;
     }
 }
 

@@ -1,6 +1,6 @@
 // fe_kernels.hip — hand-written gfx950 kernels of the stereo KLT front-end.
 //
-//  k_pyr_down     : cg::pyr_down            (reference call sites image_processor.cpp:239,242)
+//  k_pyr_down3    : cg::pyr_down x 3        (reference call sites image_processor.cpp:239,242): levels 1 .. 3 of an image in one launch
 //  k_detect_cells : cg::CornerDetector      (:132,259,657) — per-cell integer Shi-Tomasi maximum (32x32 px tiles)
 //  k_lk_points4   : cg::optical_flow_multi_level (:410 temporal, :569 stereo) with the prediction (:321-350);
 //  k_pt_geom      : the image-bounds gates (:416-424, :575-583), the stereo initial guess (:542-548),
@@ -23,83 +23,222 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i;
 }
 
-#define PD_TW 64
-#define PD_TH 16
-struct PyrJob { const uint8_t *src; uint8_t *dst; int sw, sh, dw, dh; };
+// ---- levels 1, 2 and 3 of one image in ONE launch.
+// Round 3 ran cg::pyr_down as one launch per level: level k was written to HBM and read back by the level k + 1 launch
+// (1.46 x the algorithmic traffic), two of the three launches were tiny, and in the busy device each of the three dependent
+// launches queued for compute units on its own (200 us per launch in situ against 55 alone).  Here a workgroup owns a
+// 16 x 8 tile of LEVEL 3 and everything above it: it reads the level-0 footprint once (156 x 92 pixels for the 128 x 64 it
+// owns; the halo is shared with the neighbouring tiles through the XCD's L2: the tiles of one image get block ids that are
+// congruent modulo 8), keeps its level-1 region (76 x 44) and its level-2 region (36 x 20) in LDS, and writes the parts of
+// the three levels it owns.  Every level is the separable [1 4 6 4 1] / 256 filter with BORDER_REFLECT_101 of the level
+// BELOW it, so the values are those of three separate passes bit for bit: a region holds in-image pixels of its level, the
+// two reflected columns / rows on either side of the image that the next level's taps can reach are filled in by copying
+// (pd_fill_halo), and the level-0 taps are reflected at the loads.
+// Planes: columns are shifted so that the columns a tile OWNS start on a group of four (stores and LDS rows stay dword
+// aligned): a level-1 plane column pc is x1 = 4 * x3_0 - 8 + pc (80 columns, 76 used), a level-2 plane column qc is
+// x2 = 2 * x3_0 - 4 + qc (40 columns, 36 used); byte planes carry 4 bytes of padding in front of every row because the
+// next level's window of a group starts two pixels before a dword boundary.
+#define P3_TW 16
+#define P3_TH 8
+struct Pyr3Job { const uint8_t *src; uint8_t *d1, *d2, *d3; int w0, h0; };
 
-// One workgroup: a 64x16 output tile.  The (2*64+4) x (2*16+4) source footprint is staged in LDS
-// once (reflect-101 at the image border), the horizontal [1 4 6 4 1] pass is done into a second
-// LDS plane, the vertical pass reads that.
-__global__ __launch_bounds__(256) void k_pyr_down(const PyrJob *jobs) {
-    const PyrJob job = jobs[blockIdx.z];
-    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
-    if (ox0 >= job.dw || oy0 >= job.dh) return;
-    constexpr int SW = 2 * PD_TW + 4, SH = 2 * PD_TH + 4;
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[SH][SW + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[SH][PD_TW];
+namespace {
+constexpr int P3_R2H = 2 * P3_TH + 4, P3_R1H = 2 * P3_R2H + 4, P3_R0H = 2 * P3_R1H + 4;      // 20, 44, 92 rows
+constexpr int P3_P2W = 2 * P3_TW + 8, P3_P1W = 2 * (2 * P3_TW + 4) + 8;                        // 40, 80 plane columns
+constexpr int P3_P1S = P3_P1W + 8, P3_P2S = P3_P2W + 8;                                        // byte-plane row strides (4 B pad in front, 4 behind)
+typedef uint32_t __attribute__((aligned(1))) pd_u32u;
+
+// four neighbouring horizontal [1 4 6 4 1] sums from eleven consecutive pixels b0 .. b10 (three dwords): outputs at b2, b4, b6, b8
+__device__ __forceinline__ uint2 pd_h4(uint32_t w0, uint32_t w1, uint32_t w2) {
+    const int b0 = w0 & 255u, b1 = (w0 >> 8) & 255u, b2 = (w0 >> 16) & 255u, b3 = w0 >> 24, b4 = w1 & 255u, b5 = (w1 >> 8) & 255u,
+              b6 = (w1 >> 16) & 255u, b7 = w1 >> 24, b8 = w2 & 255u, b9 = (w2 >> 8) & 255u, b10 = (w2 >> 16) & 255u;
+    const uint32_t h0 = (uint32_t)(b0 + 4 * b1 + 6 * b2 + 4 * b3 + b4), h1 = (uint32_t)(b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6);
+    const uint32_t h2 = (uint32_t)(b4 + 4 * b5 + 6 * b6 + 4 * b7 + b8), h3 = (uint32_t)(b6 + 4 * b7 + 6 * b8 + 4 * b9 + b10);
+    uint2 o; o.x = h0 | (h1 << 16); o.y = h2 | (h3 << 16);
+    return o;
+}
+// four neighbouring output pixels from five rows of horizontal sums (two columns per register in 16-bit lanes:
+// s + 128 <= 16 * 16 * 255 + 128 < 2^16, so the lanes never carry into each other)
+__device__ __forceinline__ uint32_t pd_v4(uint2 r0, uint2 r1, uint2 r2, uint2 r3, uint2 r4) {
+    const uint32_t lo = (r0.x + r4.x) + 4u * (r1.x + r3.x) + 6u * r2.x + 0x00800080u;
+    const uint32_t hi = (r0.y + r4.y) + 4u * (r1.y + r3.y) + 6u * r2.y + 0x00800080u;
+    return ((lo >> 8) & 255u) | ((lo >> 24) << 8) | (((hi >> 8) & 255u) << 16) | ((hi >> 24) << 24);
+}
+// store the (up to four) pixels of a group that lie inside the image row of width w
+__device__ __forceinline__ void pd_store4(uint8_t *row, int x, int w, uint32_t px) {
+    if (x + 3 < w) *reinterpret_cast<pd_u32u *>(row + x) = px;
+    else for (int k = 0; x + k < w; ++k) row[x + k] = (uint8_t)(px >> (8 * k));
+}
+// BORDER_REFLECT_101 of the next level: the pixels at -2, -1, n, n + 1 of a level are copies of those at 2, 1, n - 2, n - 3.
+// plane(row, col) addresses a byte plane whose (0, 0) is the pixel (y_base, x_base); rows x cols plane positions.
+__device__ __forceinline__ void pd_fill_halo(uint8_t *plane, int stride, int rows, int cols, int y_base, int x_base, int w, int h, int tid) {
+    // (a) the four out-of-image columns, every row the next level can reach; (b) the four out-of-image rows over the in-image columns
+    for (int i = tid; i < 4 * rows; i += 256) {
+        const int r = i >> 2, q = i & 3;
+        const int x = q < 2 ? q - 2 : w + q - 2, y = y_base + r;
+        const int c = x - x_base;
+        if (c < 0 || c >= cols || y < -2 || y > h + 1) continue;
+        const int ys = reflect101(y, h) - y_base, xs = reflect101(x, w) - x_base;
+        if (ys < 0 || ys >= rows || xs < 0 || xs >= cols) continue;
+        plane[r * stride + 4 + c] = plane[ys * stride + 4 + xs];
+    }
+    for (int i = tid; i < 4 * cols; i += 256) {
+        const int q = i / cols, c = i - q * cols;
+        const int y = q < 2 ? q - 2 : h + q - 2, x = x_base + c;
+        const int r = y - y_base;
+        if (r < 0 || r >= rows || x < 0 || x >= w) continue;
+        const int ys = reflect101(y, h) - y_base;
+        if (ys < 0 || ys >= rows) continue;
+        plane[r * stride + 4 + c] = plane[ys * stride + 4 + c];
+    }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_pyr_down3(const Pyr3Job *jobs, int n_jobs, int tiles_x, int tiles_y) {
+    // block -> (image, tile): the tiles of ONE image get ids congruent modulo 8 (blocks b and b + 8 share an XCD, speed only)
+    const int tiles = tiles_x * tiles_y;
+    const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
+    const int ji = bx + 8 * (bq / tiles), tile = bq - (bq / tiles) * tiles;
+    if (ji >= n_jobs) return;
+    const Pyr3Job job = jobs[ji];
+    const int w0 = job.w0, h0 = job.h0, w1 = (w0 + 1) >> 1, h1 = (h0 + 1) >> 1, w2 = (w1 + 1) >> 1, h2 = (h1 + 1) >> 1, w3 = (w2 + 1) >> 1, h3 = (h2 + 1) >> 1;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x3_0 = tx * P3_TW, y3_0 = ty * P3_TH;
+    if (x3_0 >= w3 || y3_0 >= h3) return;
+    __shared__ __attribute__((aligned(16))) uint16_t s_h0[P3_R0H][P3_P1W];     // horizontal sums of level 0 (rows: level-0 rows, columns: level-1 plane columns)
+    __shared__ __attribute__((aligned(16))) uint8_t s_p1[P3_R1H][P3_P1S];      // level-1 region
+    __shared__ __attribute__((aligned(16))) uint16_t s_h1[P3_R1H][P3_P2W];
+    __shared__ __attribute__((aligned(16))) uint8_t s_p2[P3_R2H][P3_P2S];      // level-2 region
+    __shared__ __attribute__((aligned(16))) uint16_t s_h2[P3_R2H][P3_TW];
     const int tid = threadIdx.x;
-    const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
-    if (sx0 >= 0 && sy0 >= 0 && sx0 + SW <= job.sw && sy0 + SH <= job.sh) {
-        // interior tile: whole (unaligned) dwords, 33 per row
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        constexpr int DW = SW / 4;
-        const uint8_t *base = job.src + (size_t)sy0 * job.sw + sx0;
-        for (int i = tid; i < DW * SH; i += 256) {
-            const int r = i / DW, c = i - r * DW;
-            *reinterpret_cast<uint32_t *>(&s_src[r][4 * c]) = *reinterpret_cast<const u32u *>(base + (size_t)r * job.sw + 4 * c);
-        }
-    } else {
-        // border tile: reflect-101 indices once per row / column, then bytes
-        __shared__ int s_ix[SW], s_iy[SH];
-        if (tid < SW) s_ix[tid] = reflect101(sx0 + tid, job.sw);
-        else if (tid - SW < SH) s_iy[tid - SW] = reflect101(sy0 + tid - SW, job.sh);
-        __syncthreads();
-        for (int i = tid; i < SW * SH; i += 256) {
-            const int r = i / SW, c = i - r * SW;
-            s_src[r][c] = job.src[(size_t)s_iy[r] * job.sw + s_ix[c]];
-        }
-    }
-    __syncthreads();
-    // horizontal [1 4 6 4 1]: an item is four neighbouring outputs of a row (source bytes 8q .. 8q+10 as three LDS dwords,
-    // the four sums as one 8-byte LDS write) instead of one output from five byte reads
-    for (int i = tid; i < SH * (PD_TW / 4); i += 256) {
-        const int r = i / (PD_TW / 4), q = i - r * (PD_TW / 4);
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(&s_src[r][8 * q]);
-        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-        const int b0 = w0 & 255u, b1 = (w0 >> 8) & 255u, b2 = (w0 >> 16) & 255u, b3 = w0 >> 24, b4 = w1 & 255u, b5 = (w1 >> 8) & 255u,
-                  b6 = (w1 >> 16) & 255u, b7 = w1 >> 24, b8 = w2 & 255u, b9 = (w2 >> 8) & 255u, b10 = (w2 >> 16) & 255u;
-        const uint32_t h0 = (uint32_t)(b0 + 4 * b1 + 6 * b2 + 4 * b3 + b4), h1 = (uint32_t)(b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6);
-        const uint32_t h2 = (uint32_t)(b4 + 4 * b5 + 6 * b6 + 4 * b7 + b8), h3 = (uint32_t)(b6 + 4 * b7 + 6 * b8 + 4 * b9 + b10);
-        uint2 o; o.x = h0 | (h1 << 16); o.y = h2 | (h3 << 16);
-        *reinterpret_cast<uint2 *>(&s_h[r][4 * q]) = o;
-    }
-    __syncthreads();
-    // vertical pass: one item per thread = four neighbouring outputs of a row, stored as one dword.  The sums of two columns
-    // share a register as 16-bit lanes (s + 128 <= 16 * 16 * 255 + 128 < 2^16, so the lanes never carry into each other)
+    const int x1b = 4 * x3_0 - 8, y1b = 4 * y3_0 - 6, y0b = 8 * y3_0 - 14;       // pixel of plane column / row 0
+    const int x2b = 2 * x3_0 - 4, y2b = 2 * y3_0 - 2;
+    // ---- A: horizontal pass over the level-0 rows this tile needs.  A group is four level-1 columns = eleven source pixels.
+    //      Groups whose pixels all lie inside the image row take whole (unaligned) dwords; the groups at the left / right image
+    //      border reflect every tap and run in a loop of their own (a wavefront does not pay both paths).
     {
-        const int r = tid / (PD_TW / 4), q = tid - r * (PD_TW / 4);
-        const int ox = ox0 + 4 * q, oy = oy0 + r;
-        if (ox < job.dw && oy < job.dh) {
+        const int pa = max(0, -y0b), pb = min(P3_R0H, h0 - y0b);                 // plane rows inside the image
+        constexpr int NG = P3_P1W / 4;
+        // fast groups: x1f >= 1 (first tap 2 x1f - 2 >= 0), x1f + 3 < w1, last byte read 2 x1f + 9 < w0
+        int ga = (1 - x1b + 3) >> 2; ga = ga < 0 ? 0 : ga;
+        int gb = min(min((w1 - 4 - x1b) >> 2, (w0 - 10 - 2 * x1b) >> 3) + 1, NG);
+        if (w1 - 4 - x1b < 0 || w0 - 10 - 2 * x1b < 0) gb = 0;
+        if (gb < ga) gb = ga;
+        const int ng = gb - ga, n_fast = (pb - pa) * ng;
+        const unsigned inv = ng > 0 ? (65536u + (unsigned)ng - 1u) / (unsigned)ng : 0u;      // idx / ng for idx * ng < 2^16
+        for (int idx = tid; idx < n_fast; idx += 256) {
+            const int pr = (int)(((unsigned)idx * inv) >> 16), g = ga + idx - pr * ng, p = pa + pr;
+            const uint8_t *q = job.src + (size_t)(y0b + p) * w0 + (2 * (x1b + 4 * g) - 2);
+            const uint32_t a = *reinterpret_cast<const pd_u32u *>(q), b = *reinterpret_cast<const pd_u32u *>(q + 4), c = *reinterpret_cast<const pd_u32u *>(q + 8);
+            *reinterpret_cast<uint2 *>(&s_h0[p][4 * g]) = pd_h4(a, b, c);
+        }
+        const int n_edge = NG - ng, n_slow = (pb - pa) * n_edge;
+        for (int idx = tid; idx < n_slow; idx += 256) {
+            const int pr = idx / n_edge, e = idx - pr * n_edge, g = e < ga ? e : gb + (e - ga), p = pa + pr;
+            const uint8_t *row = job.src + (size_t)(y0b + p) * w0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x1 = x1b + 4 * g + j;
+                if (x1 < 0 || x1 >= w1) continue;
+                const int c = 2 * x1;
+                s_h0[p][4 * g + j] = (uint16_t)(row[reflect101(c - 2, w0)] + 4 * row[reflect101(c - 1, w0)] + 6 * row[reflect101(c, w0)] +
+                                                4 * row[reflect101(c + 1, w0)] + row[reflect101(c + 2, w0)]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B: vertical pass -> level 1 (in-image rows of the region), into the plane and, for the pixels this tile owns, to HBM
+    {
+        const int ra = max(0, -y1b), rb = min(P3_R1H, h1 - y1b);
+        constexpr int NG = P3_P1W / 4;
+        const int n = (rb - ra) * NG;
+        for (int idx = tid; idx < n; idx += 256) {
+            const int rr = idx / NG, g = idx - rr * NG, r = ra + rr;
+            const int y1 = y1b + r, x1 = x1b + 4 * g;
+            if (x1 + 3 < 0 || x1 >= w1) continue;
             uint2 v[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const uint2 *>(&s_h[2 * r + k][4 * q]);
-            const uint32_t lo = (v[0].x + v[4].x) + 4u * (v[1].x + v[3].x) + 6u * v[2].x + 0x00800080u;
-            const uint32_t hi = (v[0].y + v[4].y) + 4u * (v[1].y + v[3].y) + 6u * v[2].y + 0x00800080u;
-            const uint32_t px = ((lo >> 8) & 255u) | ((lo >> 24) << 8) | (((hi >> 8) & 255u) << 16) | ((hi >> 24) << 24);
-            uint8_t *d = job.dst + (size_t)oy * job.dw + ox;
-            if (ox + 3 < job.dw) {
-                typedef uint32_t __attribute__((aligned(1))) u32u;
-                *reinterpret_cast<u32u *>(d) = px;
-            } else {
-                for (int k = 0; ox + k < job.dw; ++k) d[k] = (uint8_t)(px >> (8 * k));
+            for (int k = 0; k < 5; ++k) {
+                const int p = min(max(reflect101(2 * y1 - 2 + k, h0) - y0b, 0), P3_R0H - 1);
+                v[k] = *reinterpret_cast<const uint2 *>(&s_h0[p][4 * g]);
             }
+            const uint32_t px = pd_v4(v[0], v[1], v[2], v[3], v[4]);
+            *reinterpret_cast<uint32_t *>(&s_p1[r][4 + 4 * g]) = px;
+            if (r >= 6 && r < 6 + 4 * P3_TH && g >= 2 && g < 2 + P3_TW && x1 >= 0) pd_store4(job.d1 + (size_t)y1 * w1, x1, w1, px);
+        }
+    }
+    __syncthreads();
+    const bool edge1 = x1b < 0 || y1b < 0 || x1b + P3_P1W > w1 || y1b + P3_R1H > h1;      // the region reaches past the level-1 image
+    if (edge1) { pd_fill_halo(&s_p1[0][0], P3_P1S, P3_R1H, P3_P1W, y1b, x1b, w1, h1, tid); __syncthreads(); }
+    // ---- C: horizontal pass over the level-1 region (rows -2 .. h1 + 1 of the image that the plane holds)
+    {
+        constexpr int NG = P3_P2W / 4;
+        const int ra = max(0, -2 - y1b), rb = min(P3_R1H, h1 + 2 - y1b);
+        const int n = (rb - ra) * NG;
+        for (int idx = tid; idx < n; idx += 256) {
+            const int rr = idx / NG, g = idx - rr * NG, r = ra + rr;
+            // the group's eleven pixels start at plane column 8 g - 2: bytes 8 g + 2 .. of the padded row
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(&s_p1[r][8 * g]);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+            *reinterpret_cast<uint2 *>(&s_h1[r][4 * g]) = pd_h4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2), __builtin_amdgcn_alignbyte(d3, d2, 2));
+        }
+    }
+    __syncthreads();
+    // ---- D: vertical pass -> level 2
+    {
+        constexpr int NG = P3_P2W / 4;
+        const int ra = max(0, -y2b), rb = min(P3_R2H, h2 - y2b);
+        const int n = (rb - ra) * NG;
+        for (int idx = tid; idx < n; idx += 256) {
+            const int rr = idx / NG, g = idx - rr * NG, r = ra + rr;
+            const int y2 = y2b + r, x2 = x2b + 4 * g;
+            if (x2 + 3 < 0 || x2 >= w2) continue;
+            uint2 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const uint2 *>(&s_h1[2 * r + k][4 * g]);      // level-1 row 2 y2 - 2 + k = plane row 2 r + k
+            const uint32_t px = pd_v4(v[0], v[1], v[2], v[3], v[4]);
+            *reinterpret_cast<uint32_t *>(&s_p2[r][4 + 4 * g]) = px;
+            if (r >= 2 && r < 2 + 2 * P3_TH && g >= 1 && g < 1 + P3_TW / 2 && x2 >= 0) pd_store4(job.d2 + (size_t)y2 * w2, x2, w2, px);
+        }
+    }
+    __syncthreads();
+    const bool edge2 = x2b < 0 || y2b < 0 || x2b + P3_P2W > w2 || y2b + P3_R2H > h2;
+    if (edge2) { pd_fill_halo(&s_p2[0][0], P3_P2S, P3_R2H, P3_P2W, y2b, x2b, w2, h2, tid); __syncthreads(); }
+    // ---- E: horizontal pass over the level-2 region
+    {
+        constexpr int NG = P3_TW / 4;
+        const int ra = max(0, -2 - y2b), rb = min(P3_R2H, h2 + 2 - y2b);
+        const int n = (rb - ra) * NG;
+        for (int idx = tid; idx < n; idx += 256) {
+            const int rr = idx / NG, g = idx - rr * NG, r = ra + rr;
+            // level-3 column x3_0 + 4 g: first tap at level-2 pixel 2 x3_0 + 8 g - 2 = plane column 8 g + 2
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(&s_p2[r][4 + 8 * g]);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+            *reinterpret_cast<uint2 *>(&s_h2[r][4 * g]) = pd_h4(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2), __builtin_amdgcn_alignbyte(d3, d2, 2));
+        }
+    }
+    __syncthreads();
+    // ---- F: vertical pass -> level 3 (every pixel of the tile is owned)
+    {
+        constexpr int NG = P3_TW / 4;
+        const int rb = min(P3_TH, h3 - y3_0);
+        const int n = rb * NG;
+        for (int idx = tid; idx < n; idx += 256) {
+            const int r = idx / NG, g = idx - r * NG;
+            const int x3 = x3_0 + 4 * g;
+            if (x3 >= w3) continue;
+            uint2 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const uint2 *>(&s_h2[2 * r + k][4 * g]);
+            pd_store4(job.d3 + (size_t)(y3_0 + r) * w3, x3, w3, pd_v4(v[0], v[1], v[2], v[3], v[4]));
         }
     }
 }
 
-extern "C" void fe_launch_pyr_down(const PyrJob *jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t st) {
-    dim3 grid((max_dw + PD_TW - 1) / PD_TW, (max_dh + PD_TH - 1) / PD_TH, n_jobs);
-    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, st, jobs_dev);
+extern "C" void fe_launch_pyr_down3(const Pyr3Job *jobs_dev, int n_jobs, int max_w0, int max_h0, hipStream_t st) {
+    const int w3 = (((max_w0 + 1) / 2 + 1) / 2 + 1) / 2, h3 = (((max_h0 + 1) / 2 + 1) / 2 + 1) / 2;
+    const int tiles_x = (w3 + P3_TW - 1) / P3_TW, tiles_y = (h3 + P3_TH - 1) / P3_TH;
+    hipLaunchKernelGGL(k_pyr_down3, dim3(8 * ((n_jobs + 7) / 8) * tiles_x * tiles_y), dim3(256), 0, st, jobs_dev, n_jobs, tiles_x, tiles_y);
 }
 
 // ------------------------------------------------------------------------------------------ detector

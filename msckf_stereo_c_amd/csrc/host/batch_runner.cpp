@@ -555,7 +555,7 @@ int MultiRunner::run(int first, int n, bool threaded, bool pipelined) {
     std::vector<int> rcs(n_groups_, MSKF_OK);
     auto one = [&](int g) {
         // frames [first + off, first + off + n) of the group, after catching up from where it stands
-        const int from = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
+        const int from = (off_[g] > 0 || next_[g] > 0) ? std::min(next_[g], first + off_[g]) : first;
         const int cnt = first + off_[g] + n - from;
         next_[g] = from + cnt;
         return pipelined ? groups_[g]->run_pipelined(from, cnt) : groups_[g]->run(from, cnt);
@@ -581,7 +581,7 @@ int MultiRunner::run_timed(int first, int warmup, int steps, int max_extra, doub
     if (warmup <= 0) { shared.t_open = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); shared.phase.store(1); }
     std::vector<int> from(n_groups_), cnt(n_groups_);
     for (int g = 0; g < n_groups_; ++g) {
-        from[g] = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
+        from[g] = (off_[g] > 0 || next_[g] > 0) ? std::min(next_[g], first + off_[g]) : first;
         cnt[g] = first + off_[g] + warmup + steps - from[g];
         TimedWindow &w = win_[g];
         w = TimedWindow();
@@ -610,7 +610,7 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
     shared.target_close = (long)nb * (warmup + steps);
     if (plain) {     // an ordinary run: every batch does exactly its own frames (catch-up of staggered groups included), accounting on throughout
         shared.target_open = 0; shared.target_close = 0; max_extra = 0;
-        for (int g = 0; g < nb; ++g) { const int from = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first; shared.target_close += first + off_[g] + warmup + steps - from; }
+        for (int g = 0; g < nb; ++g) { const int from = (off_[g] > 0 || next_[g] > 0) ? std::min(next_[g], first + off_[g]) : first; shared.target_close += first + off_[g] + warmup + steps - from; }
         if (shared.target_close <= 0) return MSKF_OK;
     }
     if (shared.target_open <= 0) { shared.t_open = now_s(); shared.phase.store(1); }
@@ -618,7 +618,7 @@ int MultiRunner::run_balanced(int first, int warmup, int steps, int max_extra, d
     struct Batch { int from = 0, cnt = 0, fe_next = 0, mark_end = 0; bool fe_busy = false, ekf_busy = false, fe_done = false; };
     std::vector<Batch> B(nb);
     for (int g = 0; g < nb; ++g) {
-        B[g].from = off_[g] > 0 ? std::min(next_[g], first + off_[g]) : first;
+        B[g].from = (off_[g] > 0 || next_[g] > 0) ? std::min(next_[g], first + off_[g]) : first;
         B[g].cnt = first + off_[g] + warmup + steps - B[g].from;
         B[g].fe_next = B[g].from;
         B[g].mark_end = first + off_[g] + warmup + steps;

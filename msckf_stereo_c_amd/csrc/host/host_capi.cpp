@@ -90,6 +90,12 @@ void mskfh_runner_mark_dump(void *h, int g, uint64_t *ids, int32_t *lifetime, ms
 }
 void mskfh_runner_keep_trajectory_stream(void *h, int stream, int keep) { ((MultiRunner *)h)->system(stream).msckfvio_ptr()->keepTrajectory = keep != 0; }
 void mskfh_runner_set_stagger(void *h, int delta) { ((MultiRunner *)h)->set_stagger(delta); }
+// QR compression of every stream's stacked Jacobian from the next update on (mskf_ekf_set_compression_mode); call between runs
+int mskfh_runner_set_compression(void *h, int mode) {
+    MultiRunner *r = (MultiRunner *)h;
+    for (int i = 0; i < r->n_streams(); ++i) { const int rc = mskf_ekf_set_compression_mode(r->system(i).stream(), mode); if (rc != MSKF_OK) return rc; }
+    return MSKF_OK;
+}
 void mskfh_runner_set_workers(void *h, int fe_workers, int ekf_workers) { ((MultiRunner *)h)->set_workers(fe_workers, ekf_workers); }
 int mskfh_runner_group_offset(void *h, int g) { return ((MultiRunner *)h)->group_offset(g); }
 void mskfh_runner_keep_trajectory(void *h, int keep) {

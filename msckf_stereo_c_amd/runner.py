@@ -26,6 +26,7 @@ def lib():
         L.mskfh_runner_create.restype = C.c_void_p
         L.mskfh_runner_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Calib), C.POINTER(FeCfg), C.POINTER(EkfCfg), C.c_int, C.c_int, C.c_int]
         L.mskfh_runner_set_workers.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mskfh_runner_set_compression.argtypes = [C.c_void_p, C.c_int]
         L.mskfh_runner_destroy.argtypes = [C.c_void_p]
         L.mskfh_runner_error.restype = C.c_char_p
         L.mskfh_runner_error.argtypes = [C.c_void_p]
@@ -112,6 +113,10 @@ class Runner:
     def _chk(self, rc):
         if rc != 0:
             raise MskfError("runner status %d: %s" % (rc, self.L.mskfh_runner_error(self.h).decode()))
+
+    def set_compression(self, mode):
+        """QR compression of every stream from its next update on: 0 auto, 1 Gram + Cholesky, 2 Householder TSQR (call between runs)."""
+        self._chk(self.L.mskfh_runner_set_compression(self.h, int(mode)))
 
     def set_workers(self, fe_workers=0, ekf_workers=0):
         """Workers of the balanced runner (MultiRunner::run_balanced): front-end / filter workers that serve the n_groups

@@ -19,8 +19,12 @@ def _stream(gpu_ctx, oracle, w, h, **kw):
     return capi.Stream(gpu_ctx, calib, default_fe_cfg(), default_ekf_cfg(**kw)), calib
 
 
-@pytest.mark.parametrize("w,h", [(752, 480), (376, 240), (333, 251), (1280, 720)])
+@pytest.mark.parametrize("w,h", [(752, 480), (376, 240), (333, 251), (1280, 720), (64, 64), (65, 67), (129, 71), (255, 130), (257, 193), (1001, 99), (122, 509)])
 def test_pyramid_bit_exact(gpu_ctx, oracle, w, h):
+    """Levels 1 .. 3 from the one-launch kernel (k_pyr_down3: a workgroup owns a 16 x 8 tile of level 3 and the levels above
+    it, regions in LDS, reflected borders filled per level) equal three separate pyr_down passes of the oracle bit for bit:
+    the benchmark shapes, odd sizes at every level, sizes one pixel either side of a tile boundary at level 3 (16 x 8 tiles =
+    128 x 64 pixels of level 0), images smaller than one tile, long thin images."""
     rng = np.random.default_rng(w * 1000 + h)
     a = rng.integers(0, 256, (h, w), dtype=np.uint8)
     b = rng.integers(0, 256, (h, w), dtype=np.uint8)

@@ -11,7 +11,7 @@ from msckf_stereo_c_amd.ctypes_types import default_ekf_cfg, default_fe_cfg
 
 pytestmark = pytest.mark.gpu
 
-PYR_LAUNCHES_PER_FRAME = 3      # k_pyr_down launches of a front-end frame (levels 1..3)
+PYR_LAUNCHES_PER_FRAME = 1      # k_pyr_down3: levels 1..3 of both cameras of every stream in one launch
 POS_TOL = 1e-4   # metres
 ANG_TOL = 1e-4   # radians
 
