@@ -92,6 +92,7 @@ def parse(argv=None):
                     help="steps of the SECOND timed window, run with the literal Householder compression on every update "
                          "(value_householder in the JSON line); -1 = min(steps, 12) when the first window ran with --compression auto, 0 = off")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
+    ap.add_argument("--host-render", action="store_true", help="render the synthetic sequences on the host (round 3's way) instead of on the device")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reductions, "
                     "JSON line) without any device work: for the gloo tests only, the line it prints says so")
     args = ap.parse_args(argv)
@@ -153,12 +154,17 @@ def sequence_seed(rank, world, u):
     return 0x5EED0000 if u == 0 else 0x5EED0000 + u * world + rank
 
 
+def make_generators(oracle_py, args, rank, world):
+    return [oracle_py.Synth(seed=sequence_seed(rank, world, u), width=args.width, height=args.height, n_static=25, n_loop=args.loop)
+            for u in range(args.unique)]
+
+
 def render_sequences(oracle_py, args, rank, world, n_keys):
-    """Pre-render `unique` looping stereo sequences on the host (threads; the generator releases the GIL)."""
+    """Pre-render `unique` looping stereo sequences on the HOST (threads; the generator releases the GIL).  --host-render only:
+    the default renders them on the device (msckf_stereo_c_amd/synth_device.py, identical bytes)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
-    syns = [oracle_py.Synth(seed=sequence_seed(rank, world, u), width=args.width, height=args.height, n_static=25, n_loop=args.loop)
-            for u in range(args.unique)]
+    syns = make_generators(oracle_py, args, rank, world)
     frames = np.empty((args.unique, 2, n_keys, args.height, args.width), np.uint8)
 
     def job(uk):
@@ -423,17 +429,28 @@ def main(argv=None):
     total_frames = args.prime + args.warmup + args.steps
 
     t_r0 = time.perf_counter()
-    syns, frames = render_sequences(oracle_py, args, rank, world, n_keys)
-    render_s = time.perf_counter() - t_r0
     frame_bytes = args.width * args.height
-    if args.host_images:
-        h_frames = torch.from_numpy(frames).pin_memory()
-        base, on_device = h_frames.data_ptr(), 0
-        del frames
-    else:
-        d_frames = torch.from_numpy(frames).cuda(local_rank)  # resident in HBM before the timed region
-        base, on_device = d_frames.data_ptr(), 2              # borrowed in place
+    if args.host_render:
+        syns, frames = render_sequences(oracle_py, args, rank, world, n_keys)
+        d_frames = None if args.host_images else torch.from_numpy(frames).cuda(local_rank)
+        h_frames = torch.from_numpy(frames).pin_memory() if args.host_images else None
         del frames                                            # the host copy (GBs per rank) is not needed any more
+    else:
+        # the sequences are rendered ON THE DEVICE (synth_render.hip: the generator's own per-pixel source, one thread per four
+        # pixels): start-up no longer scales with ranks x host cores (round 3: 52 s and 11.8 GB of host memory per rank)
+        from msckf_stereo_c_amd import synth_device
+        syns = make_generators(oracle_py, args, rank, world)
+        d_frames = synth_device.render_sequences(syns, n_keys, torch.device("cuda", local_rank))
+        h_frames = None
+        if args.host_images:
+            h_frames = torch.empty(d_frames.shape, dtype=torch.uint8).pin_memory()
+            h_frames.copy_(d_frames)
+            d_frames = None
+    render_s = time.perf_counter() - t_r0
+    if args.host_images:
+        base, on_device = h_frames.data_ptr(), 0
+    else:
+        base, on_device = d_frames.data_ptr(), 2              # resident in HBM before the timed region, borrowed in place
     calib = syns[0].calib
     run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads, ekf_host_threads=ekf_host_threads)
     # pose_out.txt / path_ / points3d_ growth (msckf_vio.cpp:1296-1302, Q20) is off for the batch; the streams whose
@@ -676,7 +693,7 @@ def main(argv=None):
                        "compression": args.compression, "ekf_updates_stream0": n_upd, "ekf_tsqr_updates_stream0": n_tsqr,
                        "ekf_uncompressed_updates_stream0": n_uncompressed,
                        "ekf_rows_per_update_stream0": round(n_rows / max(n_upd, 1), 1),
-                       "ekf_resets_stream0": n_resets, "render_s": round(render_s, 1), "kernel_timing_period": timing_period,
+                       "ekf_resets_stream0": n_resets, "render_s": round(render_s, 1), "rendered_on": "host" if args.host_render else "device", "kernel_timing_period": timing_period,
                        "group_stagger_frames": args.stagger if max_offset else 0,
                        "host_cpu_quota": cpu_quota, "host_wait": os.environ.get("MSKF_WAIT", "spin"),
                        "filter_host_threads_per_group": ekf_host_threads or args.host_threads,

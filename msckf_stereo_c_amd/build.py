@@ -80,6 +80,21 @@ def build_host(force=False, verbose=False):
     return target
 
 
+def build_synth_hip(force=False, verbose=False):
+    """Device renderer of the synthetic bench / test sequences (csrc/synth/synth_render.hip): an input generator, a library of
+    its own, not part of the C-ABI."""
+    os.makedirs(OUT, exist_ok=True)
+    target = os.path.join(OUT, "libmskf_synth_hip.so")
+    srcs = [os.path.join(CSRC, "synth", "synth_render.hip"), os.path.join(CSRC, "synth", "synth.h")]
+    if not force and not _newer(target, srcs):
+        return target
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared"] + COMMON + ["-o", target, srcs[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return target
+
+
 def build_app(force=False, verbose=False):
     """Headless counterpart of the reference harness apps/run_euroc_single_thread.cpp (zlib PNG reader)."""
     src = os.path.join(CSRC, "apps", "run_euroc_single_thread.cpp")
@@ -116,6 +131,7 @@ def build_all(force=False, verbose=False):
         a = build_hip(force, verbose)
         b = build_host(force, verbose)
         build_app(force, verbose)
+        build_synth_hip(force, verbose)
     return a, b
 
 

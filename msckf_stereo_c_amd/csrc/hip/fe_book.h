@@ -290,20 +290,25 @@ FB_FN void fb_two_point_ransac(const FeBookDev &B, FeBookScratch &L, int cam, in
         const int step = fb_uniform_int(draw0 + 2ULL * (unsigned)h + 2ULL, 1, m - 1);
         const int second = first + step < m ? first + step : first + step - m;
         const int i1 = L.b[first], i2 = L.b[second];
-        const double c1[3] = {ctx[i1], cty[i1], ctz[i1]}, c2[3] = {ctx[i2], cty[i2], ctz[i2]};
-        double l1[3];
-        for (int q = 0; q < 3; ++q) l1[q] = fabs(c1[q]) + fabs(c2[q]);
+        // (selects instead of arrays indexed by `fixed`: a dynamically indexed array lives in scratch memory on the device)
+        const double x1 = ctx[i1], y1 = cty[i1], z1 = ctz[i1], x2 = ctx[i2], y2 = cty[i2], z2 = ctz[i2];
+        const double l1x = fabs(x1) + fabs(x2), l1y = fabs(y1) + fabs(y2), l1z = fabs(z1) + fabs(z2);
         int fixed = 0;
-        for (int q = 1; q < 3; ++q) if (l1[q] < l1[fixed]) fixed = q;
-        const int ka = fixed == 0 ? 1 : 0, kb = fixed == 2 ? 1 : 2;
-        const double a0 = c1[ka], a1 = c2[ka], b0 = c1[kb], b1 = c2[kb];
-        const double r0 = -c1[fixed], r1 = -c2[fixed];
+        double l1min = l1x;
+        if (l1y < l1min) { fixed = 1; l1min = l1y; }
+        if (l1z < l1min) { fixed = 2; l1min = l1z; }
+        // the two other columns, ascending: (y, z), (x, z) or (x, y)
+        const double a0 = fixed == 0 ? y1 : x1, a1 = fixed == 0 ? y2 : x2;
+        const double b0 = fixed == 2 ? y1 : z1, b1 = fixed == 2 ? y2 : z2;
+        const double f1 = fixed == 0 ? x1 : (fixed == 1 ? y1 : z1), f2 = fixed == 0 ? x2 : (fixed == 1 ? y2 : z2);
+        const double r0 = -f1, r1 = -f2;
         const double det = a0 * b1 - b0 * a1;
         const double v00 = b1 / det, v01 = -b0 / det, v10 = -a1 / det, v11 = a0 / det;
+        const double ta = v00 * r0 + v01 * r1, tb = v10 * r0 + v11 * r1;
         double t[3];
-        t[fixed] = 1.0;
-        t[ka] = v00 * r0 + v01 * r1;
-        t[kb] = v10 * r0 + v11 * r1;
+        t[0] = fixed == 0 ? 1.0 : ta;
+        t[1] = fixed == 1 ? 1.0 : (fixed == 0 ? ta : tb);
+        t[2] = fixed == 2 ? 1.0 : tb;
         model[4 * h + 0] = t[0]; model[4 * h + 1] = t[1]; model[4 * h + 2] = t[2];
     }
     FB_SYNC();

@@ -126,11 +126,28 @@ __global__ __launch_bounds__(256) void k_pyr_down3(const Pyr3Job *jobs, int n_jo
         if (gb < ga) gb = ga;
         const int ng = gb - ga, n_fast = (pb - pa) * ng;
         const unsigned inv = ng > 0 ? (65536u + (unsigned)ng - 1u) / (unsigned)ng : 0u;      // idx / ng for idx * ng < 2^16
-        for (int idx = tid; idx < n_fast; idx += 256) {
-            const int pr = (int)(((unsigned)idx * inv) >> 16), g = ga + idx - pr * ng, p = pa + pr;
-            const uint8_t *q = job.src + (size_t)(y0b + p) * w0 + (2 * (x1b + 4 * g) - 2);
-            const uint32_t a = *reinterpret_cast<const pd_u32u *>(q), b = *reinterpret_cast<const pd_u32u *>(q + 4), c = *reinterpret_cast<const pd_u32u *>(q + 8);
-            *reinterpret_cast<uint2 *>(&s_h0[p][4 * g]) = pd_h4(a, b, c);
+        // every load of the tile is issued before the first sum is formed (a thread has at most MAXIT groups: 24 dwords in
+        // flight per lane; with the loads inside the loop a workgroup paid the memory latency once per iteration: 145 us per
+        // 192-stream launch alone against ... with them hoisted)
+        constexpr int MAXIT = (P3_R0H * NG + 255) / 256;
+        uint32_t la[MAXIT], lb[MAXIT], lc[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = tid + 256 * it;
+            la[it] = lb[it] = lc[it] = 0u;
+            if (idx < n_fast) {
+                const int pr = (int)(((unsigned)idx * inv) >> 16), g = ga + idx - pr * ng, p = pa + pr;
+                const uint8_t *q = job.src + (size_t)(y0b + p) * w0 + (2 * (x1b + 4 * g) - 2);
+                la[it] = *reinterpret_cast<const pd_u32u *>(q); lb[it] = *reinterpret_cast<const pd_u32u *>(q + 4); lc[it] = *reinterpret_cast<const pd_u32u *>(q + 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = tid + 256 * it;
+            if (idx < n_fast) {
+                const int pr = (int)(((unsigned)idx * inv) >> 16), g = ga + idx - pr * ng, p = pa + pr;
+                *reinterpret_cast<uint2 *>(&s_h0[p][4 * g]) = pd_h4(la[it], lb[it], lc[it]);
+            }
         }
         const int n_edge = NG - ng, n_slow = (pb - pa) * n_edge;
         for (int idx = tid; idx < n_slow; idx += 256) {

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "../../../include/mskf_types.h"
 
@@ -41,12 +42,74 @@ struct Pcg32 {
     }
 };
 
-static inline uint32_t hash32(uint32_t x) {
+// Functions a pixel's value is made of: the same source is compiled for the host renderer (Stream::render) and for the HIP
+// kernel of synth_render.hip (bench.py renders its sequences on the device); both with -ffp-contract=off, every operation
+// a single IEEE double / integer operation, so the two produce identical bytes.
+#if defined(__HIPCC__)
+#define SYNTH_FN __host__ __device__ inline
+#else
+#define SYNTH_FN static inline
+#endif
+SYNTH_FN uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-static inline uint32_t hash3(int32_t a, int32_t b, uint32_t c) {
+SYNTH_FN uint32_t hash3(int32_t a, int32_t b, uint32_t c) {
     return hash32((uint32_t)a * 0x9E3779B1U ^ hash32((uint32_t)b * 0x85EBCA77U ^ hash32(c)));
+}
+
+// smooth value noise, one octave
+SYNTH_FN double vnoise(double u, double v, uint32_t salt) {
+    const double fu = floor(u), fv = floor(v);
+    const int iu = (int)fu, iv = (int)fv;
+    double a = u - fu, b = v - fv;
+    a = a * a * (3 - 2 * a); b = b * b * (3 - 2 * b);
+    const double h00 = (hash3(iu, iv, salt) & 0xFFFF) * (1.0 / 65535.0), h10 = (hash3(iu + 1, iv, salt) & 0xFFFF) * (1.0 / 65535.0);
+    const double h01 = (hash3(iu, iv + 1, salt) & 0xFFFF) * (1.0 / 65535.0), h11 = (hash3(iu + 1, iv + 1, salt) & 0xFFFF) * (1.0 / 65535.0);
+    return (h00 * (1 - a) + h10 * a) * (1 - b) + (h01 * (1 - a) + h11 * a) * b;
+}
+SYNTH_FN double texture(uint32_t seed, double u, double v, uint32_t plane) {
+    const uint32_t s = seed * 31u + plane * 1013u;
+    double t = 0.30 * vnoise(u / 0.64, v / 0.64, s + 1) + 0.30 * vnoise(u / 0.32, v / 0.32, s + 2) +
+               0.45 * vnoise(u / 0.16, v / 0.16, s + 3) + 0.55 * vnoise(u / 0.08, v / 0.08, s + 4) +
+               0.30 * vnoise(u / 0.04, v / 0.04, s + 5);
+    t = (t - 0.95) * 2.2 + 0.5;  // contrast stretch around the mean
+    // sparse high-contrast blobs (blocks) so a corner detector fires in every region
+    const int bu = (int)floor(u / 0.24), bv = (int)floor(v / 0.24);
+    const uint32_t hb = hash3(bu, bv, s + 9);
+    if ((hb & 7u) == 0u) {
+        const double cu = (bu + 0.5) * 0.24, cv = (bv + 0.5) * 0.24;
+        if (fabs(u - cu) < 0.07 && fabs(v - cv) < 0.07) t = (hb & 8u) ? 0.95 : 0.05;
+    }
+    return t < 0 ? 0 : (t > 1 ? 1 : t);
+}
+
+// What one image of a sequence is rendered from: camera rotation (world <- camera) and centre of the frame's pose, the
+// stream's seed, k2c = 2 * frame key + camera (the pixel-noise stream), and which camera's ray table its pixels read.
+struct RenderImg { double R_wc[9]; double o[3]; double pixel_sigma; uint32_t seed; int32_t k2c; int32_t cam; int32_t pad; };
+
+// value of pixel `idx` whose undistorted viewing ray is (rx, ry, 1): the textured box room seen along the ray, plus noise
+SYNTH_FN uint8_t shade_pixel(const RenderImg &I, float rx, float ry, uint32_t idx) {
+    const double cx = rx, cy = ry, cz = 1.0;
+    const double rv[3] = {I.R_wc[0] * cx + I.R_wc[1] * cy + I.R_wc[2] * cz, I.R_wc[3] * cx + I.R_wc[4] * cy + I.R_wc[5] * cz,
+                          I.R_wc[6] * cx + I.R_wc[7] * cy + I.R_wc[8] * cz};
+    // box room: x in [-3, 5.5], y in [-4, 4], z in [-1.6, 2.4]
+    const double lo[3] = {-3.0, -4.0, -1.6}, hi[3] = {5.5, 4.0, 2.4};
+    double tbest = 1e30; int pbest = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (rv[a] > 1e-9) { const double t = (hi[a] - I.o[a]) / rv[a]; if (t < tbest) { tbest = t; pbest = 2 * a; } }
+        else if (rv[a] < -1e-9) { const double t = (lo[a] - I.o[a]) / rv[a]; if (t < tbest) { tbest = t; pbest = 2 * a + 1; } }
+    }
+    const double hx = I.o[0] + tbest * rv[0], hy = I.o[1] + tbest * rv[1], hz = I.o[2] + tbest * rv[2];
+    double tu, tv;
+    if (pbest < 2) { tu = hy; tv = hz; } else if (pbest < 4) { tu = hx; tv = hz; } else { tu = hx; tv = hy; }
+    double val = 20.0 + 215.0 * texture(I.seed, tu, tv, (uint32_t)pbest);
+    // pixel noise ~ N(0, sigma^2): sum of 4 uniforms (Irwin-Hall), deterministic in (seed, cam, frame, pixel)
+    const uint32_t h = hash3((int32_t)idx, I.k2c, I.seed ^ 0xC0FFEEu);
+    const double n4 = ((h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + ((h >> 24) & 0xFF)) * (1.0 / 255.0) - 2.0;
+    val += I.pixel_sigma * n4 * 1.7320508;  // var of sum of 4 U(0,1) = 1/3
+    const int iv = (int)floor(val + 0.5);
+    return (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
 }
 
 struct Cfg {
@@ -120,7 +183,6 @@ class Stream {
   public:
     explicit Stream(const Cfg &cfg) : cfg_(cfg) {
         period_ = cfg.n_loop * (cfg.frame_dt_ns * 1e-9);
-        build_ray_tables();
         gen_imu_noise_seed_ = cfg.seed ^ 0xA5A5A5A5u;
     }
     const Cfg &cfg() const { return cfg_; }
@@ -214,6 +276,20 @@ class Stream {
         return s;
     }
 
+    // what the image of camera c at frame k is rendered from (also the input of the device renderer, synth_render.hip)
+    RenderImg render_params(const Pose &P, int c, int k) const {
+        Mat3 R_cw; Vec3 o;
+        cam_pose(P, c, R_cw, o);
+        const Mat3 R_wc = transpose(R_cw);
+        RenderImg I;
+        for (int i = 0; i < 9; ++i) I.R_wc[i] = R_wc.m[i];
+        I.o[0] = o.x; I.o[1] = o.y; I.o[2] = o.z;
+        I.pixel_sigma = cfg_.pixel_sigma; I.seed = cfg_.seed; I.k2c = k * 2 + c; I.cam = c; I.pad = 0;
+        return I;
+    }
+    RenderImg render_params(int k, int c) const { return render_params(pose_of_frame(k), c, k); }
+    const float *ray_table(int c) const { need_rays(); return rays_[c].data(); }      // width x height x (x, y): undistorted viewing rays
+
     // ---- render stereo pair for frame k (row-major u8, pitch = width)
     void render(int k, uint8_t *cam0, uint8_t *cam1) const {
         Pose P = pose_of_frame(k);
@@ -280,6 +356,9 @@ class Stream {
         t_wc = Vec3{P.p.x - cw.x, P.p.y - cw.y, P.p.z - cw.z};
     }
 
+    // the ray tables are built on first use (a generator that only feeds IMU samples, or whose images are rendered on the device
+    // from another generator's tables - they depend on the calibration alone - never needs them: 0.2 s per generator at 752 x 480)
+    void need_rays() const { std::call_once(rays_once_, [this]() { const_cast<Stream *>(this)->build_ray_tables(); }); }
     void build_ray_tables() {
         for (int c = 0; c < 2; ++c) {
             const double *K = c ? cfg_.calib.cam1_intrinsics : cfg_.calib.cam0_intrinsics;
@@ -302,67 +381,18 @@ class Stream {
         }
     }
 
-    // smooth value noise, one octave
-    static inline double vnoise(double u, double v, uint32_t salt) {
-        const double fu = std::floor(u), fv = std::floor(v);
-        const int iu = (int)fu, iv = (int)fv;
-        double a = u - fu, b = v - fv;
-        a = a * a * (3 - 2 * a); b = b * b * (3 - 2 * b);
-        const double h00 = (hash3(iu, iv, salt) & 0xFFFF) * (1.0 / 65535.0), h10 = (hash3(iu + 1, iv, salt) & 0xFFFF) * (1.0 / 65535.0);
-        const double h01 = (hash3(iu, iv + 1, salt) & 0xFFFF) * (1.0 / 65535.0), h11 = (hash3(iu + 1, iv + 1, salt) & 0xFFFF) * (1.0 / 65535.0);
-        return (h00 * (1 - a) + h10 * a) * (1 - b) + (h01 * (1 - a) + h11 * a) * b;
-    }
-    inline double texture(double u, double v, uint32_t plane) const {
-        const uint32_t s = cfg_.seed * 31u + plane * 1013u;
-        double t = 0.30 * vnoise(u / 0.64, v / 0.64, s + 1) + 0.30 * vnoise(u / 0.32, v / 0.32, s + 2) +
-                   0.45 * vnoise(u / 0.16, v / 0.16, s + 3) + 0.55 * vnoise(u / 0.08, v / 0.08, s + 4) +
-                   0.30 * vnoise(u / 0.04, v / 0.04, s + 5);
-        t = (t - 0.95) * 2.2 + 0.5;  // contrast stretch around the mean
-        // sparse high-contrast blobs (blocks) so a corner detector fires in every region
-        const int bu = (int)std::floor(u / 0.24), bv = (int)std::floor(v / 0.24);
-        const uint32_t hb = hash3(bu, bv, s + 9);
-        if ((hb & 7u) == 0u) {
-            const double cu = (bu + 0.5) * 0.24, cv = (bv + 0.5) * 0.24;
-            if (std::fabs(u - cu) < 0.07 && std::fabs(v - cv) < 0.07) t = (hb & 8u) ? 0.95 : 0.05;
-        }
-        return t < 0 ? 0 : (t > 1 ? 1 : t);
-    }
-
     void render_cam(const Pose &P, int c, int k, uint8_t *out) const {
-        Mat3 R_cw; Vec3 o;
-        cam_pose(P, c, R_cw, o);
-        const Mat3 R_wc = transpose(R_cw);
+        const RenderImg I = render_params(P, c, k);
+        need_rays();
         const std::vector<float> &tab = rays_[c];
-        // box room: x in [-3, 5.5], y in [-4, 4], z in [-1.6, 2.4]
-        const double lo[3] = {-3.0, -4.0, -1.6}, hi[3] = {5.5, 4.0, 2.4};
-        const double ov[3] = {o.x, o.y, o.z};
-        for (int v = 0; v < cfg_.height; ++v)
-            for (int u = 0; u < cfg_.width; ++u) {
-                const size_t idx = (size_t)v * cfg_.width + u;
-                Vec3 rc{tab[2 * idx], tab[2 * idx + 1], 1.0};
-                Vec3 rw = mul(R_wc, rc);
-                const double rv[3] = {rw.x, rw.y, rw.z};
-                double tbest = 1e30; int pbest = 0;
-                for (int a = 0; a < 3; ++a) {
-                    if (rv[a] > 1e-9) { const double t = (hi[a] - ov[a]) / rv[a]; if (t < tbest) { tbest = t; pbest = 2 * a; } }
-                    else if (rv[a] < -1e-9) { const double t = (lo[a] - ov[a]) / rv[a]; if (t < tbest) { tbest = t; pbest = 2 * a + 1; } }
-                }
-                const double hx = ov[0] + tbest * rv[0], hy = ov[1] + tbest * rv[1], hz = ov[2] + tbest * rv[2];
-                double tu, tv;
-                if (pbest < 2) { tu = hy; tv = hz; } else if (pbest < 4) { tu = hx; tv = hz; } else { tu = hx; tv = hy; }
-                double val = 20.0 + 215.0 * texture(tu, tv, (uint32_t)pbest);
-                // pixel noise ~ N(0, sigma^2): sum of 4 uniforms (Irwin-Hall), deterministic in (seed, cam, frame, pixel)
-                const uint32_t h = hash3((int32_t)idx, k * 2 + c, cfg_.seed ^ 0xC0FFEEu);
-                const double n4 = ((h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + ((h >> 24) & 0xFF)) * (1.0 / 255.0) - 2.0;
-                val += cfg_.pixel_sigma * n4 * 1.7320508;  // var of sum of 4 U(0,1) = 1/3
-                int iv = (int)std::floor(val + 0.5);
-                out[idx] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
-            }
+        const size_t n = (size_t)cfg_.width * cfg_.height;
+        for (size_t idx = 0; idx < n; ++idx) out[idx] = shade_pixel(I, tab[2 * idx], tab[2 * idx + 1], (uint32_t)idx);
     }
 
     Cfg cfg_;
     double period_;
     std::vector<float> rays_[2];
+    mutable std::once_flag rays_once_;
     std::vector<Bias> bias_;
     uint32_t gen_imu_noise_seed_;
 };

@@ -17,6 +17,9 @@ void synth_render(void *h, int k, uint8_t *cam0, uint8_t *cam1) { ((synth::Strea
 double synth_frame_time(void *h, int k) { return ((synth::Stream *)h)->frame_time(k); }
 void synth_imu(void *h, int j, mskf_imu_sample *out) { *out = ((synth::Stream *)h)->imu_sample(j); }
 void synth_gt_pose(void *h, int k, mskf_pose *out) { *out = ((synth::Stream *)h)->gt_pose(k); }
+// inputs of the device renderer (synth_render.hip): per-image parameters and the per-camera ray table (w x h x 2 floats)
+void synth_render_params(void *h, int k, int cam, synth::RenderImg *out) { *out = ((synth::Stream *)h)->render_params(k, cam); }
+const float *synth_ray_table(void *h, int cam) { return ((synth::Stream *)h)->ray_table(cam); }
 int synth_imu_per_frame(void *h) { return ((synth::Stream *)h)->cfg().imu_per_frame; }
 
 }  // extern "C"

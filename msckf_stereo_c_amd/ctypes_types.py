@@ -88,3 +88,7 @@ def default_ekf_cfg(max_cam_state_size=20, compression_mode=0):
     c.max_stack_rows = 1500
     c.compression_mode = compression_mode
     return c
+
+
+# synth::RenderImg (csrc/synth/synth.h): what one image of a synthetic sequence is rendered from (input generator, host and device)
+RENDER_IMG = np.dtype([("R_wc", "<f8", 9), ("o", "<f8", 3), ("pixel_sigma", "<f8"), ("seed", "<u4"), ("k2c", "<i4"), ("cam", "<i4"), ("pad", "<i4")])

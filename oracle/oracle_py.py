@@ -95,8 +95,14 @@ def synth_lib():
         S.synth_imu.argtypes = [C.c_void_p, C.c_int, C.POINTER(ImuSample)]
         S.synth_gt_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         S.synth_euroc_calib.argtypes = [C.c_int, C.c_int, C.POINTER(Calib)]
+        S.synth_render_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        S.synth_ray_table.argtypes = [C.c_void_p, C.c_int]
+        S.synth_ray_table.restype = C.POINTER(C.c_float)
         _synth = S
     return _synth
+
+
+from msckf_stereo_c_amd.ctypes_types import RENDER_IMG   # synth::RenderImg
 
 
 def euroc_calib(w, h):
@@ -138,6 +144,17 @@ class Synth:
 
     def frame_time(self, k):
         return self.S.synth_frame_time(self.h_, k)
+
+    def render_params(self, k, cam):
+        """Inputs of the device renderer (csrc/synth/synth_render.hip) for camera `cam` of frame k: one RENDER_IMG record."""
+        out = np.zeros(1, RENDER_IMG)
+        self.S.synth_render_params(self.h_, self.frame_key(k), cam, _p(out))
+        return out[0]
+
+    def ray_table(self, cam):
+        """Undistorted viewing rays of camera `cam`, (h, w, 2) float32 (the same for every seed: it depends on the calibration only)."""
+        p = self.S.synth_ray_table(self.h_, cam)
+        return np.ctypeslib.as_array(p, shape=(self.h, self.w, 2)).copy()
 
     def imu(self, j):
         s = ImuSample()

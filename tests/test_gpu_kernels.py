@@ -39,6 +39,21 @@ def test_pyramid_bit_exact(gpu_ctx, oracle, w, h):
     s.close()
 
 
+@pytest.mark.parametrize("w,h,seed", [(376, 240, 0x5EED0000), (752, 480, 0x5EED0007), (188, 120, 11)])
+def test_device_renderer_equals_host(gpu_ctx, oracle, w, h, seed):
+    """The input generator on the device (csrc/synth/synth_render.hip, what bench.py renders its sequences with) produces the
+    bytes of the host generator (synth.h, what every parity test and the CPU oracle's legs use): static prefix, moving frames,
+    both cameras, the wrap of the looping trajectory."""
+    import torch
+    from msckf_stereo_c_amd import synth_device
+    syn = oracle.Synth(seed=seed, width=w, height=h, n_static=3, n_loop=6)
+    dev = synth_device.render_sequences([syn], 9, torch.device("cuda", 0)).cpu().numpy()
+    for k in range(9):
+        a, b = syn.render(k)
+        assert np.array_equal(dev[0, 0, k], a), (k, 0, int((dev[0, 0, k] != a).sum()))
+        assert np.array_equal(dev[0, 1, k], b), (k, 1, int((dev[0, 1, k] != b).sum()))
+
+
 def test_pitched_host_images_are_repacked(gpu_ctx, oracle):
     """mskf_fe_push_stereo with pitch > width (padded rows, cv::Mat::step): the padding never reaches the pyramid."""
     w, h, pitch = 376, 240, 384
