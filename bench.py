@@ -428,19 +428,23 @@ def main(argv=None):
     max_offset = args.stagger * (n_groups - 1) if args.unique < n_streams else 0
     total_frames = args.prime + args.warmup + args.steps
 
+    syns = make_generators(oracle_py, args, rank, world)
+    calib = syns[0].calib
+    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads, ekf_host_threads=ekf_host_threads)
     t_r0 = time.perf_counter()
     frame_bytes = args.width * args.height
     if args.host_render:
-        syns, frames = render_sequences(oracle_py, args, rank, world, n_keys)
+        _, frames = render_sequences(oracle_py, args, rank, world, n_keys)
         d_frames = None if args.host_images else torch.from_numpy(frames).cuda(local_rank)
         h_frames = torch.from_numpy(frames).pin_memory() if args.host_images else None
         del frames                                            # the host copy (GBs per rank) is not needed any more
     else:
         # the sequences are rendered ON THE DEVICE (synth_render.hip: the generator's own per-pixel source, one thread per four
-        # pixels): start-up no longer scales with ranks x host cores (round 3: 52 s and 11.8 GB of host memory per rank)
+        # pixels): start-up no longer scales with ranks x host cores (round 3: 52 s and 11.8 GB of host memory per rank).  The kernels
+        # run on the first group's own stream: every stage of the pipeline has a hardware queue to itself (GPU_MAX_HW_QUEUES), a
+        # generator on the null stream would bind a seventeenth
         from msckf_stereo_c_amd import synth_device
-        syns = make_generators(oracle_py, args, rank, world)
-        d_frames = synth_device.render_sequences(syns, n_keys, torch.device("cuda", local_rank))
+        d_frames = synth_device.render_sequences(syns, n_keys, torch.device("cuda", local_rank), hip_stream=run.hip_stream(0))
         h_frames = None
         if args.host_images:
             h_frames = torch.empty(d_frames.shape, dtype=torch.uint8).pin_memory()
@@ -451,8 +455,6 @@ def main(argv=None):
         base, on_device = h_frames.data_ptr(), 0
     else:
         base, on_device = d_frames.data_ptr(), 2              # resident in HBM before the timed region, borrowed in place
-    calib = syns[0].calib
-    run = R.Runner(calib, fe, ekf, n_groups, per_group, device=local_rank, host_threads=args.host_threads, ekf_host_threads=ekf_host_threads)
     # pose_out.txt / path_ / points3d_ growth (msckf_vio.cpp:1296-1302, Q20) is off for the batch; the streams whose
     # trajectories are compared with the CPU oracle after the run keep theirs
     run.keep_trajectory(False)

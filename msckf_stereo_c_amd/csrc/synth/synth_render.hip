@@ -31,21 +31,24 @@ __global__ __launch_bounds__(256) void k_synth_render(const synth::RenderImg *im
 
 extern "C" {
 // Render n_imgs images of width x height pixels: image i goes to out_dev + i * frame_bytes (device memory, frame_bytes a multiple
-// of 4), from imgs_host[i] (synth_render_params) and the two cameras' ray tables (device memory).  Synchronous; returns 0 on success.
+// of 4), from imgs_host[i] (synth_render_params) and the two cameras' ray tables (device memory).  Everything is enqueued on
+// `stream` (a hipStream_t; nullptr = the null stream) and waited for: a bench that gives every pipeline stage a hardware queue of
+// its own passes one of those streams, so that the generator does not bind one more queue.  Returns 0 on success.
 int synth_hip_render(const synth::RenderImg *imgs_host, int n_imgs, const float *rays0_dev, const float *rays1_dev, int width, int height,
-                     uint8_t *out_dev, size_t frame_bytes) {
+                     uint8_t *out_dev, size_t frame_bytes, void *stream) {
     if (!imgs_host || n_imgs <= 0 || !rays0_dev || !rays1_dev || !out_dev || width <= 0 || height <= 0 || (frame_bytes & 3) || frame_bytes < (size_t)width * height) return -1;
+    hipStream_t st = (hipStream_t)stream;
     synth::RenderImg *d = nullptr;
     if (hipMalloc((void **)&d, sizeof(synth::RenderImg) * (size_t)n_imgs) != hipSuccess) return -2;
     int rc = 0;
-    if (hipMemcpy(d, imgs_host, sizeof(synth::RenderImg) * (size_t)n_imgs, hipMemcpyHostToDevice) != hipSuccess) rc = -2;
+    if (hipMemcpyAsync(d, imgs_host, sizeof(synth::RenderImg) * (size_t)n_imgs, hipMemcpyHostToDevice, st) != hipSuccess) rc = -2;
     const int n_px = width * height;
     for (int i0 = 0; rc == 0 && i0 < n_imgs; i0 += 32768) {          // (grid.y limit)
         const int cnt = n_imgs - i0 < 32768 ? n_imgs - i0 : 32768;
-        hipLaunchKernelGGL(k_synth_render, dim3((n_px + 1023) / 1024, cnt), dim3(256), 0, 0, d + i0, rays0_dev, rays1_dev, out_dev + (size_t)i0 * frame_bytes, frame_bytes, n_px);
+        hipLaunchKernelGGL(k_synth_render, dim3((n_px + 1023) / 1024, cnt), dim3(256), 0, st, d + i0, rays0_dev, rays1_dev, out_dev + (size_t)i0 * frame_bytes, frame_bytes, n_px);
         if (hipGetLastError() != hipSuccess) rc = -3;
     }
-    if (hipDeviceSynchronize() != hipSuccess && rc == 0) rc = -3;
+    if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = -3;
     (void)hipFree(d);
     return rc;
 }

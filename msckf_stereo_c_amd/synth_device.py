@@ -18,20 +18,23 @@ def lib():
         if not os.path.exists(p):
             raise RuntimeError("libmskf_synth_hip.so is not built (python -m msckf_stereo_c_amd.build)")
         L = C.CDLL(p)
-        L.synth_hip_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.synth_hip_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.synth_hip_render.restype = C.c_int
         _LIB = L
     return _LIB
 
 
-def render_sequences(syns, n_keys, device):
+def render_sequences(syns, n_keys, device, hip_stream=None):
     """Frames 0 .. n_keys - 1 of both cameras of every generator in `syns` (same image size), rendered on `device`: a uint8 torch
-    tensor [len(syns), 2, n_keys, h, w] resident in HBM.  Chunked so that the parameter records stay small."""
+    tensor [len(syns), 2, n_keys, h, w] resident in HBM.  hip_stream: the HIP stream (an integer handle) the kernels run on; a
+    bench that gives every stage of its pipeline a hardware queue of its own passes one of those, so the generator binds no
+    further queue (None = the null stream)."""
     import torch
     w, h = syns[0].w, syns[0].h
     assert (w * h) % 4 == 0, "the device renderer stores four pixels per thread"
     out = torch.empty((len(syns), 2, n_keys, h, w), dtype=torch.uint8, device=device)
     rays = [torch.from_numpy(syns[0].ray_table(c)).to(device) for c in (0, 1)]       # calibration only: the same for every seed
+    torch.cuda.synchronize(device)
     from .ctypes_types import RENDER_IMG
     with torch.cuda.device(device):
         for u, s in enumerate(syns):
@@ -40,7 +43,7 @@ def render_sequences(syns, n_keys, device):
             for c in (0, 1):
                 for k in range(n_keys):
                     params[c * n_keys + k] = s.render_params(k, c)
-            rc = lib().synth_hip_render(params.ctypes.data, len(params), rays[0].data_ptr(), rays[1].data_ptr(), w, h, out[u].data_ptr(), w * h)
+            rc = lib().synth_hip_render(params.ctypes.data, len(params), rays[0].data_ptr(), rays[1].data_ptr(), w, h, out[u].data_ptr(), w * h, hip_stream)
             if rc != 0:
                 raise RuntimeError("synth_hip_render failed with status %d" % rc)
     return out
