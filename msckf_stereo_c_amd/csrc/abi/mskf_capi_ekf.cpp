@@ -12,7 +12,6 @@ void ekf_launch_augment(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_remove_clone(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_features(const EkfStreamDev *d, const int *work_wave, int n_wave, const int *work_small, int n_small, const int *work_big, int n_big,
                          int max_rows, int max_rows_small, int big_clones, hipStream_t st);
-void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_pair_features(const EkfStreamDev *d, int n, int max_feat, int max_tri, hipStream_t st);
 void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st);
 void ekf_launch_posvar_upd(const EkfStreamDev *d, int n, hipStream_t st);
@@ -493,7 +492,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     int max_frows_cls[3] = {0, 0, 0};
     std::vector<int> &cnt_cls = ctx->pend_upd.cnt_cls;          // [3][n]
     cnt_cls.assign((size_t)3 * n, 0);
-    std::vector<int> route(n, 0);
+    std::vector<int> route(n, 0), na_max(n, 0);
     bool any_pairs = false, any_small = false, any_general = false;
     int max_feat_pairs = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
@@ -588,6 +587,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             if (pairs) wave = false;
             const bool small = 6 * __builtin_popcountll(clone_mask) <= ekf_small_update_max_na();
             route[i] = (pairs ? 1 : 0) | (wave ? 2 : 0) | (small ? 4 : 0);
+            na_max[i] = 6 * __builtin_popcountll(clone_mask);
             any_pairs |= pairs; any_small |= small; any_general |= !small;
             if (pairs) { max_feat_pairs = std::max(max_feat_pairs, a.n_feat); max_tri = std::max(max_tri, n_tri); }
             if (pairs || wave) {
@@ -650,7 +650,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         EkfStreamDev &D = ctx->ekf_desc.h[i];
         base_desc(s, D);
         D.n_clones = a.n_clones; D.n_feat = a.n_feat; D.n_obs = a.n_obs;
-        D.route = route[i];
+        D.route = route[i]; D.na_max = na_max[i];
         D.dof_offset = a.dof_offset; D.apply_row_cap = a.apply_row_cap;
         D.m_total = L.m_total;
         for (int k = 0; k < 3; ++k) D.gravity[k] = a.gravity[k];
@@ -678,9 +678,8 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
                                 max_frows_cls[1], max_clones_cfg, st);
         }
         mskf_t_end(ctx, ts, (long long)fl_feat);
-        ts = mskf_t_begin(ctx, MSKF_K_EKF_CAP);
-        ekf_launch_cap(ctx->ekf_desc.d, n, st);
-        mskf_t_end(ctx, ts, n);
+        // (which blocks are stacked - the 1500-row cap of :1002-1010 - is worked out by the first dense kernel of each route
+        //  itself: ekf_cap.h; rounds 1-3 ran it as a launch of its own here)
         enum { GM_GRAM = 0, GM_T = 1, GM_S2 = 2, GM_PUPD = 3 };
         const double d3 = fl_upd / (4.0 + 1.0 / 3.0 + 2.0 + 2.0 + 2.0);     // sum of d^3 over the launch
         if (any_small) {

@@ -35,7 +35,7 @@ struct EkfStreamDev {
     // feature observed (+ column d, the residual); what a row carries is its rowmask (clone bits, 0 = the row is not
     // stacked: failed triangulation / gate, or behind the row cap).  Nothing else of a row is ever written or read.
     double *Hs;
-    unsigned long long *rowmask;   // m_total, filled by k_ekf_cap
+    unsigned long long *rowmask;   // m_total, written by the feature kernels for their own rows
     // The dense update works on the active columns only (compact index i <-> column act[i]): a stacked Jacobian is
     // identically zero in the 21 IMU columns and in the columns of clones none of its features observed, and such
     // columns contribute nothing to S, K or the covariance downdate.
@@ -50,11 +50,12 @@ struct EkfStreamDev {
     uint8_t *feat_status;     // n_feat: bit0 triangulation valid, bit1 gate passed and stacked
     double *gamma;            // n_feat
     double *pos_out;          // n_feat x 3: feature positions used (triangulated when needs_init)
-    double *pos_var_out;      // 3: P(12,12), P(13,13), P(14,14) after the update (k_ekf_posvar_upd), or null
+    double *pos_var_out;      // 3: P(12,12), P(13,13), P(14,14) after the update (epilogue of k_ekf_gemm<PUPD>), or null
     int route;                // which kernels handle this stream's update, decided per STREAM from its own features (never from
                               // the rest of the batch, so a stream's arithmetic does not depend on its neighbours): bit 0 pair
                               // kernels (every feature has exactly the same two Jacobian clones), bit 1 wave-per-feature class
                               // (every feature <= 4 observations), bit 2 fused small update (at most 4 clones touched)
+    int na_max;               // 6 x the clones any feature of this update observed: an upper bound of the active columns (from the host)
     int qr_mode;              // mskf_ekf_cfg.compression_mode: 0 auto (Gram + Cholesky, Householder TSQR when flagged), 1 Gram only, 2 TSQR always
     const int *tri_idx;       // features that need triangulation (pair path: k_ekf_triangulate), n_tri of them
     int n_tri;

@@ -5,7 +5,7 @@
 //  k_ekf_remove_clone   : clone row/column deletion              (:1161-1181)
 //  k_ekf_feature_blocks : Feature::initializePosition (feature.hpp:289-450), measurementJacobian
 //                         (:610-677), featureJacobian null-space projection (:679-775), gatingTest (:909-935)
-//  k_ekf_cap            : stacking order + 1500-row cap          (:1003-1010)
+//  (ekf_cap.h)          : stacking order + 1500-row cap          (:1003-1010), run by the first dense kernel of the update
 //  (ekf_linalg.hip)     : QR compression (:795-811) as Gram + Cholesky, gain / correction / covariance update (:831-904)
 //
 // All arithmetic is FP64.  The covariance P stays resident in HBM (ld x ld, row-major, exactly
@@ -530,6 +530,7 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
         GSYNC();
         if (!sValid || M < 2) {
             if (gt == 0) { S.feat_status[j] = 0; S.gamma[j] = -1.0; F.colmask = 0ULL; }
+            for (int i = gt; i < n; i += GS) S.rowmask[F.row_off + i] = 0ULL;       // its rows are not stacked
             continue;
         }
         TDBG();
@@ -843,11 +844,14 @@ __global__ __launch_bounds__(TPB, 2) void k_ekf_feature_blocks(const EkfStreamDe
         }
         const int dof = M + S.dof_offset;
         const bool pass = pd_ok && dof >= 1 && dof < 100 && gamma < S.chi2[dof];
-        if (gt == 0) {
-            S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma;
+        if (gt < 64) {
+            // what the block's rows carry: the clone bits of its observations if it passed the gate, 0 otherwise (every row of the
+            // block: the Gram pass reads a row only where its mask says so; k_ekf_cap wrote these masks in rounds 1-3)
             unsigned long long cm = 0ULL;
-            if (pass) for (int o = 0; o < M; ++o) cm |= 1ULL << sCloneOfObs[o];
-            F.colmask = cm;
+            if (pass) for (int o = gt; o < M; o += 64) cm |= 1ULL << sCloneOfObs[o];
+            for (int off = 32; off > 0; off >>= 1) cm |= __shfl_xor(cm, off);
+            for (int i = gt; i < n; i += 64) S.rowmask[F.row_off + i] = cm;
+            if (gt == 0) { S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0)); S.gamma[j] = gamma; F.colmask = cm; }
         }
         };
         if (rows <= lds_rows) gate_steps(s_arena);
@@ -929,6 +933,7 @@ __global__ __launch_bounds__(64) void k_ekf_pair_blocks(const EkfStreamDev *stre
         S.pos_out[3 * j] = pos[0]; S.pos_out[3 * j + 1] = pos[1]; S.pos_out[3 * j + 2] = pos[2];
         if (!valid || F.n_obs != 2 || c0 != pa || c1 != pb) {      // (a foreign pair cannot happen: the host checks the batch)
             S.feat_status[j] = 0; S.gamma[j] = -1.0; F.colmask = 0ULL;
+            for (int i = 0; i < 4 * F.n_obs - 3; ++i) S.rowmask[F.row_off + i] = 0ULL;
             continue;
         }
         // ---- per-observation Jacobians (msckf_vio.cpp:610-677)
@@ -1078,84 +1083,7 @@ __global__ __launch_bounds__(64) void k_ekf_pair_blocks(const EkfStreamDev *stre
         S.feat_status[j] = (uint8_t)(1 | (pass ? 2 : 0));
         S.gamma[j] = gamma;
         F.colmask = pass ? ((1ULL << pa) | (1ULL << pb)) : 0ULL;
-    }
-}
-
-// ------------------------------------------------------------------------------------ cap
-// msckf_vio.cpp:1002-1010: stack the passing blocks in feature order and stop once the stacked rows exceed the cap
-// (the block that crosses it is still stacked).  Parallel form: every thread owns a contiguous run of features, the
-// rows of the passing ones are prefix-summed across the workgroup, the first feature whose inclusive sum exceeds the
-// cap ends the stack.  Also produced here: the rowmask of every row (what k_ekf_gemm<GRAM> may read), the active
-// column list and the counters rows_out[0..2].
-__global__ __launch_bounds__(WG) void k_ekf_cap(const EkfStreamDev *streams) {
-    const EkfStreamDev &S = streams[blockIdx.y];
-    const int nf = S.n_feat;
-    if (nf <= 0) return;
-    __shared__ int s_sum[WG], s_cross[WG];
-    __shared__ unsigned long long s_or[WG / 64];
-    __shared__ int s_cap_from;
-    const int tid = threadIdx.x;
-    const int per = (nf + WG - 1) / WG;
-    const int j0 = tid * per, j1 = min(nf, j0 + per);
-    int local = 0;
-    for (int j = j0; j < j1; ++j) if (S.feat_status[j] & 2) local += 4 * S.feats[j].n_obs - 3;
-    s_sum[tid] = local;
-    __syncthreads();
-    // inclusive scan of the per-thread sums (Hillis-Steele over WG entries)
-    for (int off = 1; off < WG; off <<= 1) {
-        const int v = tid >= off ? s_sum[tid - off] : 0;
-        __syncthreads();
-        s_sum[tid] += v;
-        __syncthreads();
-    }
-    const int before = s_sum[tid] - local;
-    // first feature of this thread's run whose inclusive stacked-row count exceeds the cap
-    int cross = nf;
-    if (S.apply_row_cap) {
-        int run = before;
-        for (int j = j0; j < j1; ++j) {
-            if (S.feat_status[j] & 2) { run += 4 * S.feats[j].n_obs - 3; if (run > S.max_stack_rows) { cross = j; break; } }
-        }
-    }
-    s_cross[tid] = cross;
-    __syncthreads();
-    if (tid == 0) {
-        int c = nf;
-        for (int t = 0; t < WG; ++t) if (s_cross[t] < c) c = s_cross[t];
-        s_cap_from = c < nf ? c + 1 : nf;       // features [cap_from, nf) are not stacked
-    }
-    __syncthreads();
-    const int cap_from = s_cap_from;
-    // stacked rows, last stacked row, clone mask of the stack; capped features lose their block
-    int stack = 0, meff = 0;
-    unsigned long long orm = 0ULL;
-    for (int j = j0; j < j1; ++j) {
-        EkfFeatDev &F = S.feats[j];
-        const int n = 4 * F.n_obs - 3;
-        unsigned long long cm = F.colmask;
-        if (!(S.feat_status[j] & 2)) cm = 0ULL;
-        if (j >= cap_from && cm) { cm = 0ULL; F.colmask = 0ULL; S.feat_status[j] &= (uint8_t)~2; }
-        if (cm) { stack += n; meff = F.row_off + n; orm |= cm; }
-        for (int i = 0; i < n; ++i) S.rowmask[F.row_off + i] = cm;
-    }
-    s_sum[tid] = stack; s_cross[tid] = meff;
-    for (int off = 32; off > 0; off >>= 1) orm |= __shfl_xor(orm, off);
-    if ((tid & 63) == 0) s_or[tid >> 6] = orm;
-    __syncthreads();
-    if (tid == 0) {
-        int st = 0, me = 0;
-        for (int t = 0; t < WG; ++t) { st += s_sum[t]; if (s_cross[t] > me) me = s_cross[t]; }
-        unsigned long long m = 0ULL;
-        for (int w = 0; w < WG / 64; ++w) m |= s_or[w];
-        // active columns: the six columns of every clone observed by a stacked feature, ascending
-        int na = 0;
-        for (int c = 0; c < S.n_clones; ++c)
-            if ((m >> c) & 1ULL) for (int k = 0; k < 6; ++k) S.act[na++] = EKF_IMU_DIM + 6 * c + k;
-        S.rows_out[0] = st;
-        S.rows_out[1] = me;       // rows beyond the last stacked block carry nothing: the Gram pass stops there
-        S.rows_out[2] = na;
-        S.rows_out[3] = 0;
-        S.rows_out[4] = na;       // rows of the compressed measurement (k_ekf_qr lowers it when nothing is compressed)
+        for (int i = 0; i < 5; ++i) S.rowmask[F.row_off + i] = F.colmask;
     }
 }
 
@@ -1222,5 +1150,4 @@ void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st
 void ekf_launch_posvar_upd(const EkfStreamDev *d, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_ekf_posvar_upd, dim3((3 * n + 63) / 64), dim3(64), 0, st, d, n);
 }
-void ekf_launch_cap(const EkfStreamDev *d, int n, hipStream_t st) { hipLaunchKernelGGL(k_ekf_cap, dim3(1, n), dim3(WG), 0, st, d); }
 }

@@ -24,6 +24,7 @@
 // IMU columns of H are zero, unobserved clones, the gauge): the factorisation is regularised, see k_ekf_chol_lds.
 #include <mutex>
 #include "ekf_device.h"
+#include "ekf_cap.h"
 #include "chol_block.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -83,14 +84,26 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0) return;
     if (MODE != GM_PUPD && (S.route & EKF_ROUTE_SMALL)) return;
-    if (MODE == GM_GRAM && ekf_skip_gram(S)) return;
     const int d = S.d, ld = S.ld;
-    const int na = S.rows_out[2];                  // active columns (compact index i <-> column act[i])
+    // GRAM is the first dense kernel of the update: every tile works out for itself which blocks are stacked (ekf_cap.h; tile 0
+    // writes the result down for the kernels that follow).  Tiles that cannot exist whatever is stacked - above the diagonal,
+    // or beyond the clones any feature of the stream observed (na_max, from the host) - leave before that.
+    int gram_tile_i = 0, gram_tile_j = 0;
+    EkfCapResult cap = {0, 0, 0, 0ULL};
+    if (MODE == GM_GRAM) {
+        int tg = 1;
+        while ((tg + 1) * (tg + 1) <= (int)gridDim.x) ++tg;      // the launch is tg x tg tiles per stream
+        gram_tile_i = (int)blockIdx.x / tg; gram_tile_j = (int)blockIdx.x - gram_tile_i * tg;
+        if (gram_tile_j > gram_tile_i || gram_tile_i * GT > S.na_max) return;
+        cap = ekf_cap_local(S, blockIdx.x == 0);
+        if (S.qr_mode == 2 || (S.qr_mode == 0 && cap.stacked <= cap.na)) return;       // ekf_skip_gram, on this update's own numbers
+    }
+    const int na = MODE == GM_GRAM ? cap.na : S.rows_out[2];                  // active columns (compact index i <-> column act[i])
     const int *__restrict__ act = S.act;
     const double *__restrict__ A; const double *__restrict__ B; double *C;
     int M, N, K;
     double alpha = 1.0, beta = 0.0, diag_add = 0.0;
-    if (MODE == GM_GRAM)      { A = S.Hs; B = S.Hs; C = S.S; M = N = na + 1; K = S.rows_out[1]; }       // G_c = [H_act|r]^T [H_act|r]
+    if (MODE == GM_GRAM)      { A = S.Hs; B = S.Hs; C = S.S; M = N = na + 1; K = cap.end; }       // G_c = [H_act|r]^T [H_act|r]
     const int nk = MODE == GM_GRAM ? 0 : S.rows_out[4];                                               // rows of the compressed measurement
     const bool direct = MODE != GM_GRAM && MODE != GM_PUPD && ekf_direct(S);                          // R = H_act itself (no compression)
     if (MODE == GM_T)         { A = direct ? S.Hs : S.S;  B = S.P;  C = S.T; M = nk; N = d; K = na; }   // T = R P[act, :]
@@ -120,8 +133,9 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         }
         return;
     }
-    if (tile >= tiles_m * tiles_n) return;
-    const int ti = tile / tiles_n, tj = tile - ti * tiles_n;
+    if (MODE != GM_GRAM && tile >= tiles_m * tiles_n) return;
+    const int ti = MODE == GM_GRAM ? gram_tile_i : tile / tiles_n, tj = MODE == GM_GRAM ? gram_tile_j : tile - ti * tiles_n;
+    if (MODE == GM_GRAM && ti >= tiles_m) return;
     if (TR::SYM && tj > ti) return;
     const int i0 = ti * GT, j0 = tj * GT;
     __shared__ double sA[GK][GT + 1];   // sA[k][i]
@@ -136,8 +150,8 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
     // gathered source columns of this thread's fixed (i = lo / j = lo) operand lanes
     int colA = i0 + lo, colB = j0 + lo;
     if (MODE == GM_GRAM) {
-        colA = (i0 + lo < na) ? act[i0 + lo] : d;       // compact index na is the residual column d of [H | r]
-        colB = (j0 + lo < na) ? act[j0 + lo] : d;
+        colA = (i0 + lo < na) ? ekf_act_column(cap.clones, i0 + lo) : d;       // compact index na is the residual column d of [H | r]
+        colB = (j0 + lo < na) ? ekf_act_column(cap.clones, j0 + lo) : d;
     }
     // GRAM: what a stacked row carries is its rowmask (bit c = the six columns of clone c, any bit = the residual column);
     // everything else of the row was never written and is not read
@@ -644,7 +658,8 @@ __global__ __launch_bounds__(256) void k_ekf_trsm(const EkfStreamDev *streams) {
 __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *streams) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || !(S.route & EKF_ROUTE_SMALL)) return;
-    const int d = S.d, ld = S.ld, na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1];
+    const EkfCapResult cap = ekf_cap_local(S, true);         // the first dense kernel of this route: which blocks are stacked (ekf_cap.h)
+    const int d = S.d, ld = S.ld, na = cap.na, n1 = na + 1, K = cap.end;
     const int tid = threadIdx.x;
     if (na <= 0 || na > SU_MAX_NA) {            // nothing stacked (or a caller error): no correction, P unchanged
         for (int c = tid; c < d; c += 256) S.delta_x[c] = 0.0;
@@ -658,7 +673,7 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
     __shared__ int s_col[SU_MAX_NA + 1], s_clone[SU_MAX_NA + 1];
     __shared__ double s_lam;
     if (tid < n1) {
-        const int col = tid < na ? S.act[tid] : d;
+        const int col = tid < na ? ekf_act_column(cap.clones, tid) : d;
         s_col[tid] = col;
         s_clone[tid] = tid < na ? (col - EKF_IMU_DIM) / 6 : -1;
     }
@@ -748,7 +763,7 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
         __syncthreads();
         const int tiny = s_tiny;
-        const bool need_qr = S.qr_mode == 2 || (S.qr_mode == 0 && (S.rows_out[0] <= na || s_bias));
+        const bool need_qr = S.qr_mode == 2 || (S.qr_mode == 0 && (cap.stacked <= na || s_bias));
         if (need_qr) {
             for (int e = tid; e < n1 * n1; e += 256) sG[e] = 0.0;
             __syncthreads();
