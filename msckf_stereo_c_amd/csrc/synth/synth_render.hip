@@ -52,4 +52,22 @@ int synth_hip_render(const synth::RenderImg *imgs_host, int n_imgs, const float 
     (void)hipFree(d);
     return rc;
 }
+
+// The same from and to HOST memory (ray tables w x h x 2 floats each, out n_imgs x frame_bytes): device buffers are allocated
+// and released inside.  For the parity test (no other GPU library in the process) and small renders.
+int synth_hip_render_host(const synth::RenderImg *imgs_host, int n_imgs, const float *rays0_host, const float *rays1_host, int width, int height,
+                          uint8_t *out_host, size_t frame_bytes) {
+    if (!rays0_host || !rays1_host || !out_host || width <= 0 || height <= 0 || n_imgs <= 0) return -1;
+    const size_t rb = sizeof(float) * 2 * (size_t)width * height, ob = frame_bytes * (size_t)n_imgs;
+    float *r0 = nullptr, *r1 = nullptr; uint8_t *o = nullptr;
+    int rc = 0;
+    if (hipMalloc((void **)&r0, rb) != hipSuccess || hipMalloc((void **)&r1, rb) != hipSuccess || hipMalloc((void **)&o, ob) != hipSuccess) rc = -2;
+    if (rc == 0 && (hipMemcpy(r0, rays0_host, rb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(r1, rays1_host, rb, hipMemcpyHostToDevice) != hipSuccess)) rc = -2;
+    if (rc == 0) rc = synth_hip_render(imgs_host, n_imgs, r0, r1, width, height, o, frame_bytes, nullptr);
+    if (rc == 0 && hipMemcpy(out_host, o, ob, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
+    if (r0) (void)hipFree(r0);
+    if (r1) (void)hipFree(r1);
+    if (o) (void)hipFree(o);
+    return rc;
+}
 }

@@ -20,6 +20,8 @@ def lib():
         L = C.CDLL(p)
         L.synth_hip_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.synth_hip_render.restype = C.c_int
+        L.synth_hip_render_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.synth_hip_render_host.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -46,4 +48,21 @@ def render_sequences(syns, n_keys, device, hip_stream=None):
             rc = lib().synth_hip_render(params.ctypes.data, len(params), rays[0].data_ptr(), rays[1].data_ptr(), w, h, out[u].data_ptr(), w * h, hip_stream)
             if rc != 0:
                 raise RuntimeError("synth_hip_render failed with status %d" % rc)
+    return out
+
+
+def render_frames_to_host(syn, keys):
+    """Both cameras of the frames `keys` of one generator, rendered on the device and copied back: uint8 array [2, len(keys), h, w].
+    No torch involved (the parity test of the renderer runs in a process that holds the product library only)."""
+    from .ctypes_types import RENDER_IMG
+    w, h = syn.w, syn.h
+    params = np.zeros(2 * len(keys), RENDER_IMG)
+    for c in (0, 1):
+        for i, k in enumerate(keys):
+            params[c * len(keys) + i] = syn.render_params(k, c)
+    r0, r1 = np.ascontiguousarray(syn.ray_table(0)), np.ascontiguousarray(syn.ray_table(1))
+    out = np.empty((2, len(keys), h, w), np.uint8)
+    rc = lib().synth_hip_render_host(params.ctypes.data, len(params), r0.ctypes.data, r1.ctypes.data, w, h, out.ctypes.data, w * h)
+    if rc != 0:
+        raise RuntimeError("synth_hip_render_host failed with status %d" % rc)
     return out

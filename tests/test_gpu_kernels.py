@@ -44,14 +44,13 @@ def test_device_renderer_equals_host(gpu_ctx, oracle, w, h, seed):
     """The input generator on the device (csrc/synth/synth_render.hip, what bench.py renders its sequences with) produces the
     bytes of the host generator (synth.h, what every parity test and the CPU oracle's legs use): static prefix, moving frames,
     both cameras, the wrap of the looping trajectory."""
-    import torch
     from msckf_stereo_c_amd import synth_device
     syn = oracle.Synth(seed=seed, width=w, height=h, n_static=3, n_loop=6)
-    dev = synth_device.render_sequences([syn], 9, torch.device("cuda", 0)).cpu().numpy()
+    dev = synth_device.render_frames_to_host(syn, list(range(9)))
     for k in range(9):
         a, b = syn.render(k)
-        assert np.array_equal(dev[0, 0, k], a), (k, 0, int((dev[0, 0, k] != a).sum()))
-        assert np.array_equal(dev[0, 1, k], b), (k, 1, int((dev[0, 1, k] != b).sum()))
+        assert np.array_equal(dev[0, k], a), (k, 0, int((dev[0, k] != a).sum()))
+        assert np.array_equal(dev[1, k], b), (k, 1, int((dev[1, k] != b).sum()))
 
 
 def test_pitched_host_images_are_repacked(gpu_ctx, oracle):
