@@ -865,7 +865,14 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
 void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const size_t lds = ((size_t)SU_MAX_NA * (max_d + 1) + (SU_MAX_NA + 1) * (SU_MAX_NA + 1) + SU_MAX_NA * SU_MAX_NA + SU_CH * (SU_MAX_NA + 1)) * sizeof(double);
     static std::once_flag attr_once;
-    std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_small_update), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
+    std::call_once(attr_once, []() {
+        // the whole CU's LDS less what the kernel declares statically (a request beyond that is refused, and the refusal would
+        // surface as the "last error" of a later, innocent launch)
+        hipFuncAttributes fa;
+        size_t stat = 4096;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_ekf_small_update)) == hipSuccess) stat = fa.sharedSizeBytes;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_small_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - stat)) != hipSuccess) (void)hipGetLastError();
+    });
     hipLaunchKernelGGL(k_ekf_small_update, dim3(1, n), dim3(256), lds, st, d);
 }
 int ekf_small_update_max_na(void) { return SU_MAX_NA; }
