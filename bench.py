@@ -37,11 +37,11 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2                # wave-instructions/s: 1024 SI
 
 def _profile(name):
     """Newest committed summary of a counter pass (profiles/rNN_<name>.json)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", "r03_%s.json" % name)
+    return os.path.join(ROOT, "profiles", "r04_%s.json" % name)
 
 
 PMC_TRAFFIC_FILE = _profile("pmc_hbm_traffic")

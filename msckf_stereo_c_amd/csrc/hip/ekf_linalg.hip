@@ -23,6 +23,7 @@
 // over output tiles) instead of d sequential reflector applications.  H^T H is rank deficient (the 21
 // IMU columns of H are zero, unobserved clones, the gauge): the factorisation is regularised, see k_ekf_chol_lds.
 #include <mutex>
+#include <type_traits>
 #include "ekf_device.h"
 #include "ekf_cap.h"
 #include "chol_block.h"
@@ -31,7 +32,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Gram + regularised Cholesky adds a prior lambda I to the stacked information H^T H / sigma^2: the posterior covariance
 // moves by about lambda max(P_aa) / sigma^2 relative.  Above this limit (or when the stack has no more rows than active
-// columns) the compression runs as Householder TSQR instead (tsqr16), which has no such term.
+// columns) the compression runs as Householder TSQR instead (tsqr_wide), which has no such term.
 #define QR_BIAS_LIMIT 1e-6
 // How a stream's stack is compressed is decided from ONE pair of numbers everywhere (the GRAM pass, the factorisation
 // kernels, the fused small update): st = rows_out[0], the rows actually stacked, and na = rows_out[2], the active columns.
@@ -256,13 +257,34 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
 // (Round 2 ran this as a kernel of its own, launched after the Gram factorisation of EVERY update just to find that nothing
 // was to do: 1.6 % of the kernel time of the bench and one more link in the update's dependency chain.  The factorisation
 // kernels call it now, with their own LDS: the packed factor's space holds R, the panel's the row block.)
-#define QR_BR 16
-template <class ColOf, class RAt>
-__device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, ColOf colOf, RAt Rat, double *sB) {
+// Round 4: WIDE row blocks.  Round 3 streamed sixteen rows at a time with one thread per column: a step (one reflector) is a
+// workgroup barrier plus 16 multiply-adds per thread, ceil(K / 16) * n1 steps in all (7500 at C2: 50 row blocks x 150
+// columns), most of the workgroup idle (150 of 512 threads have a column) - 3 to 4.5 ms per update in the busy device, which
+// made this kernel the dominant one with the literal Householder compression (profiles/r03_bench_tsqr.json).  Now a column of
+// the block is shared by Q neighbouring lanes (Q = 4 or 8: the partial dot products meet in DPP quad / half-row butterflies),
+// each owning RL rows, so a block is Q * RL rows (48 at C2: what the LDS left beside the resident R allows; 128 in the fused
+// small update) and the number of barrier-separated steps drops by that factor while every thread has work.
+template <int Q> __device__ __forceinline__ double qr_lane_sum(double v) {
+    // sum over the Q lanes of a group (Q = 4: a DPP quad, Q = 8: half a DPP row); every lane of the group gets the total
+    auto bfly = [](double x, auto ctrl) {
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, decltype(ctrl)::value, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, true);
+        return x + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    v = bfly(v, std::integral_constant<int, 0xB1>());        // quad_perm [1,0,3,2]
+    v = bfly(v, std::integral_constant<int, 0x4E>());        // quad_perm [2,3,0,1]
+    if (Q == 8) v = bfly(v, std::integral_constant<int, 0x141>());   // row_half_mirror: lane i <-> 7 - i of each half row
+    return v;
+}
+template <int Q, int RL, class ColOf, class RAt>
+__device__ __forceinline__ void tsqr_wide(const EkfStreamDev &S, int n1, int K, ColOf colOf, RAt Rat, double *sB) {
+    constexpr int BR = Q * RL;
     const int tid = threadIdx.x, nth = blockDim.x, ld = S.ld;
-    for (int k0 = 0; k0 < K; k0 += QR_BR) {
+    const int q = tid & (Q - 1), g = tid / Q, ng = nth / Q;
+    for (int k0 = 0; k0 < K; k0 += BR) {
         __syncthreads();
-        for (int e = tid; e < QR_BR * n1; e += nth) {
+        for (int e = tid; e < BR * n1; e += nth) {
             const int r = e / n1, c = e - r * n1, gk = k0 + r;
             double v = 0.0;
             if (gk < K) {
@@ -275,35 +297,46 @@ __device__ __forceinline__ void tsqr16(const EkfStreamDev &S, int n1, int K, Col
             sB[e] = v;
         }
         __syncthreads();
+        double *own = sB + (size_t)q * RL * n1;          // this lane's RL rows of the block
         for (int k = 0; k < n1; ++k) {
-            double bk[QR_BR];
+            double bk[RL];
             double ss = 0.0;
 #pragma unroll
-            for (int i = 0; i < QR_BR; ++i) { bk[i] = sB[i * n1 + k]; ss += bk[i] * bk[i]; }
+            for (int i = 0; i < RL; ++i) { bk[i] = own[i * n1 + k]; ss += bk[i] * bk[i]; }
+            ss = qr_lane_sum<Q>(ss);
             // Nothing (left) in this column of the block: structurally zero, or what earlier reflectors of this block left
-            // of it.  Rounding residue shrinks by ~1e-16 per generation of 16 reflectors; once its square leaves the
-            // normal range 2 / (v0^2 + ss) overflows, and far above that it is already meaningless: below 1e-40 of
-            // R_kk^2 (or 1e-200 absolute) the column counts as annihilated.  Uniform: every thread reads the same values.
+            // of it.  Rounding residue shrinks by ~1e-16 per generation of reflectors; once its square leaves the normal range
+            // 2 / (v0^2 + ss) overflows, and far above that it is already meaningless: below 1e-40 of R_kk^2 (or 1e-200
+            // absolute) the column counts as annihilated.  Uniform: every group forms the same sum in the same order.
             const double x0 = Rat(k, k);
             if (ss < 1e-200 || ss < 1e-40 * (x0 * x0)) continue;
             const double nrm = sqrt(x0 * x0 + ss);
             const double alpha = x0 > 0.0 ? -nrm : nrm;
             const double v0 = x0 - alpha;
             const double beta = 2.0 / (v0 * v0 + ss);
-            for (int j = k + 1 + tid; j < n1; j += nth) {
-                double dot = v0 * Rat(k, j);
+            for (int j = k + 1 + g; j < n1; j += ng) {
+                double bj[RL];
+                double dot = 0.0;
 #pragma unroll
-                for (int i = 0; i < QR_BR; ++i) dot += bk[i] * sB[i * n1 + j];
-                const double t = beta * dot;
-                Rat(k, j) -= t * v0;
+                for (int i = 0; i < RL; ++i) { bj[i] = own[i * n1 + j]; dot += bk[i] * bj[i]; }
+                const double rkj = Rat(k, j);
+                const double t = beta * (qr_lane_sum<Q>(dot) + v0 * rkj);
 #pragma unroll
-                for (int i = 0; i < QR_BR; ++i) sB[i * n1 + j] -= t * bk[i];
+                for (int i = 0; i < RL; ++i) own[i * n1 + j] = bj[i] - t * bk[i];
+                if (q == 0) Rat(k, j) = rkj - t * v0;
             }
             __syncthreads();
             if (tid == 0) Rat(k, k) = alpha;
         }
     }
     __syncthreads();
+}
+// rows per lane of a quad for a row block of `room` doubles beside the resident R: 16, 32 or 48 rows per block
+template <class ColOf, class RAt>
+__device__ __forceinline__ void tsqr_quads(const EkfStreamDev &S, int n1, int K, ColOf colOf, RAt Rat, double *sB, int room) {
+    if (room >= 48 * n1) tsqr_wide<4, 12>(S, n1, K, colOf, Rat, sB);
+    else if (room >= 32 * n1) tsqr_wide<4, 8>(S, n1, K, colOf, Rat, sB);
+    else tsqr_wide<4, 4>(S, n1, K, colOf, Rat, sB);
 }
 
 // What the Gram factorisation kernels do for a stream BEFORE factoring (which == 0 only).  Returns 0: factor the Gram
@@ -343,9 +376,9 @@ __device__ __forceinline__ int ekf_compress_entry(const EkfStreamDev &S, int *s_
 }
 // ... and AFTER it: Householder TSQR instead, for the streams that need it (forced, no Gram matrix formed, or the bias flag
 // of the factorisation just done), handed over in the layout the update expects: S.S = L = R^T (lower, ld-wide rows),
-// column d of T = Q^T r.  Rat(k, j): the resident R (zeroed here); sB: QR_BR x n1 doubles.
+// column d of T = Q^T r.  Rat(k, j): the resident R (zeroed here); sB: the row block, `room` doubles (>= 16 x n1).
 template <class RAt>
-__device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gram_done, int diag, RAt Rat, double *sB) {
+__device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gram_done, int diag, RAt Rat, double *sB, int room) {
     const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], d = S.d, ld = S.ld;
     const int tid = threadIdx.x, nth = blockDim.x;
     const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && (!gram_done || (diag & 2)));
@@ -353,7 +386,7 @@ __device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gr
     __syncthreads();
     for (int e = tid; e < n1 * n1; e += nth) { const int k = e / n1, j = e - k * n1; if (j >= k) Rat(k, j) = 0.0; }
     const int *act = S.act;
-    tsqr16(S, n1, K, [=](int c, int &col, int &clone) { col = c < na ? act[c] : d; clone = c < na ? (col - EKF_IMU_DIM) / 6 : -1; }, Rat, sB);
+    tsqr_quads(S, n1, K, [=](int c, int &col, int &clone) { col = c < na ? act[c] : d; clone = c < na ? (col - EKF_IMU_DIM) / 6 : -1; }, Rat, sB, room);
     for (int e = tid; e < na * na; e += nth) {
         const int i = e / na, j = e - i * na;
         if (j <= i) S.S[(size_t)i * ld + j] = Rat(j, i);
@@ -388,7 +421,7 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     if (tid == 0) s_diag = 0;
     if (entry == 2) {   // no Gram matrix: Householder TSQR, R in the stream's W buffer (ld-wide rows), the row block in the panel's space
         double *Rg = S.W;
-        ekf_compress_exit(S, false, 0, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT);
+        ekf_compress_exit(S, false, 0, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT, LNB * pan_rs);
         return;
     }
     for (int e = tid; e < LNB * pan_rs; e += CHOLG_THREADS) sPanT[e] = 0.0;
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
         for (int k = tid; k < n; k += CHOLG_THREADS) S.T[(size_t)k * lda + S.d] = A[(size_t)n * lda + k];
         __syncthreads();
         double *Rg = S.W;
-        ekf_compress_exit(S, true, s_diag, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT);
+        ekf_compress_exit(S, true, s_diag, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT, LNB * pan_rs);
     }
 }
 
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
 
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 
-__global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which) {
+__global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDev *streams, int which, int lds_doubles) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
@@ -477,7 +510,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     if (tid == 0) s_diag = 0;
     // R of the TSQR lives where the packed factor does (packed upper by rows: the same n1 (n1 + 1) / 2 doubles), the row block in the panel's space
     auto Rl = [=](int k, int j) -> double & { return sM[k * nt - k * (k - 1) / 2 + (j - k)]; };
-    if (entry == 2) { ekf_compress_exit(S, false, 0, Rl, sPanT); return; }
+    const int room = lds_doubles - nt * (nt + 1) / 2;       // what the launch's LDS leaves beside the packed factor / the resident R: the TSQR's row block
+    if (entry == 2) { ekf_compress_exit(S, false, 0, Rl, sPanT, room); return; }
     // load: one matrix row per wave pass, coalesced along j
     // (8 rows x 3 column chunks = up to 24 loads in flight per lane: the copy is latency bound otherwise)
     for (int i0 = wave * 8; i0 < nt; i0 += CHOL_WAVES * 8) {
@@ -551,7 +585,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
         // column d of T <- (Q^T r) = the extra row of L, so the TRSM carries w = L2^-1 Q^T r along
         for (int k = tid; k < n; k += CHOL_THREADS) S.T[(size_t)k * lda + S.d] = sM[pk(n, k)];
         __syncthreads();
-        ekf_compress_exit(S, true, s_diag, Rl, sPanT);
+        ekf_compress_exit(S, true, s_diag, Rl, sPanT, room);
     }
 }
 
@@ -767,7 +801,8 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         if (need_qr) {
             for (int e = tid; e < n1 * n1; e += 256) sG[e] = 0.0;
             __syncthreads();
-            tsqr16(S, n1, K, [&](int c, int &col, int &clone) { col = s_col[c]; clone = s_clone[c]; }, [=](int k, int j) -> double & { return sG[k * n1 + j]; }, sC);
+            static_assert(SU_CH == 8 * 16, "the fused update's row block is eight lanes x sixteen rows per column");
+            tsqr_wide<8, 16>(S, n1, K, [&](int c, int &col, int &clone) { col = s_col[c]; clone = s_clone[c]; }, [=](int k, int j) -> double & { return sG[k * n1 + j]; }, sC);
             for (int e = tid; e < n1 * n1; e += 256) { const int i = e / n1, j = e - i * n1; if (j < i) sG[e] = sG[j * n1 + i]; }
             __syncthreads();
         }
@@ -856,7 +891,7 @@ void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStre
     std::call_once(attr_once, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ekf_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(((size_t)CHOL_LDS_MAX_ROWS * (CHOL_LDS_MAX_ROWS + 1) / 2 + (size_t)CHOL_PAN_RS * LNB) * sizeof(double))); });
         const size_t lds = ((size_t)nt * (nt + 1) / 2 + (size_t)CHOL_PAN_RS * LNB) * sizeof(double);
-        hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(CHOL_THREADS), lds, st, d, which);
+        hipLaunchKernelGGL(k_ekf_chol_lds, dim3(1, n), dim3(CHOL_THREADS), lds, st, d, which, (int)(lds / sizeof(double)));
         return;
     }
     const int pan_rs = (nt + 15) / 16 * 16;
