@@ -48,6 +48,8 @@ PMC_TRAFFIC_FILE = _profile("pmc_hbm_traffic")
 PMC_SQ_FILE = _profile("pmc_sq")
 PMC_MFMA_FILE = _profile("pmc_mfma_c2")
 
+COMPRESSION_MODES = {"auto": 0, "gram": 1, "tsqr": 2, "householder": 3}      # mskf_ekf_cfg.compression_mode (include/mskf_types.h)
+
 # BASELINE.json configs: image, clone window, grid rows x cols x min x max, streams per GPU, groups
 CONFIGS = {
     "c2": dict(width=752, height=480, clones=30, grid="8x10x5x6", streams=1536, groups=8, loop=60, cpu_frames=150, cpu_all_frames=80,
@@ -85,12 +87,14 @@ def parse(argv=None):
     ap.add_argument("--cpu-all-frames", type=int, default=None, help="frames per stream of the all-cores CPU-oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("MSKF_BENCH_BACKEND", "nccl"), help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--compression", choices=["auto", "gram", "tsqr"], default="auto",
-                    help="QR compression of the stacked Jacobian (msckf_vio.cpp:795-817): auto = Gram + regularised Cholesky with the "
-                         "Householder TSQR where the device decides it is needed (default), gram = Gram only, tsqr = the literal Householder path always")
-    ap.add_argument("--householder-steps", type=int, default=-1,
-                    help="steps of the SECOND timed window, run with the literal Householder compression on every update "
-                         "(value_householder in the JSON line); -1 = min(steps, 12) when the first window ran with --compression auto, 0 = off")
+    ap.add_argument("--compression", choices=["householder", "auto", "gram", "tsqr"], default="householder",
+                    help="QR compression of the stacked Jacobian (msckf_vio.cpp:795-821): householder = the reference's own rule, Householder QR when "
+                         "the stack has more rows than columns and nothing otherwise (default); auto = Gram + regularised Cholesky with the "
+                         "Householder TSQR where the device decides it is needed; gram = Gram only; tsqr = Householder always")
+    ap.add_argument("--gram-steps", type=int, default=-1,
+                    help="steps of the SECOND timed window, run with the Gram + regularised Cholesky compression (--compression auto) instead of the "
+                         "reference's Householder QR (value_gram_cholesky in the JSON line); -1 = min(steps, 12) when the first window ran with "
+                         "--compression householder, 0 = off")
     ap.add_argument("--host-images", action="store_true", help="stereo pairs stay in host memory: PCIe-inclusive rate (not the headline value)")
     ap.add_argument("--host-render", action="store_true", help="render the synthetic sequences on the host (round 3's way) instead of on the device")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, reductions, "
@@ -100,8 +104,8 @@ def parse(argv=None):
     for k in ("width", "height", "clones", "grid", "streams", "groups", "loop", "cpu_frames", "cpu_all_frames"):
         if getattr(args, k) is None:
             setattr(args, k, preset[k] if k not in ("streams", "groups") else int(os.environ.get("MSKF_BENCH_" + k.upper(), preset[k])))
-    if args.householder_steps < 0:
-        args.householder_steps = min(args.steps, 12) if (args.compression == "auto" and not args.no_pipeline) else 0
+    if args.gram_steps < 0:
+        args.gram_steps = min(args.steps, 12) if (args.compression == "householder" and not args.no_pipeline) else 0
     if args.prime is None:
         # static start, gravity / bias initialisation, clone window full — and one whole period of the looping trajectory, so that
         # every group has met its largest frame (staging buffers grow to their final size) before the timed steps
@@ -144,7 +148,7 @@ def make_cfgs(args):
     from msckf_stereo_c_amd.ctypes_types import default_ekf_cfg, default_fe_cfg
     r, c, mn, mx = (int(x) for x in args.grid.split("x"))
     return (default_fe_cfg(grid_row=r, grid_col=c, grid_min=mn, grid_max=mx),
-            default_ekf_cfg(max_cam_state_size=args.clones, compression_mode={"auto": 0, "gram": 1, "tsqr": 2}[args.compression]))
+            default_ekf_cfg(max_cam_state_size=args.clones, compression_mode=COMPRESSION_MODES[args.compression]))
 
 
 def sequence_seed(rank, world, u):
@@ -465,7 +469,7 @@ def main(argv=None):
     if max_offset:
         run.set_stagger(args.stagger)
     hh_warm = 3
-    hh_frames = (hh_warm + args.householder_steps + cooldown + 8) if args.householder_steps > 0 else 0      # frames the second window may add
+    hh_frames = (hh_warm + args.gram_steps + cooldown + 8) if args.gram_steps > 0 else 0      # frames the second window may add
     imus = [imu_array(s, (total_frames + max_offset + 2 * cooldown + hh_frames + 3) * 10 + 20) for s in syns]
     for s in range(n_streams):
         u = s % args.unique
@@ -547,26 +551,27 @@ def main(argv=None):
     status = 0
     n_tsqr, n_uncompressed, n_rows, n_resets = run.num_tsqr_updates(0), run.num_uncompressed_updates(0), run.stacked_rows(0), run.num_resets(0)
 
-    # ---- second window: the same streams go on with the QR of msckf_vio.cpp:795-817 taken literally - Householder (TSQR) on
-    #      EVERY update instead of Gram + regularised Cholesky with TSQR where the device asks for it - so that the line carries
-    #      both rates from one run of the driver's command (the trajectories checked against the oracle below run through both)
+    # ---- second window: the same streams go on with the faster, not literal compression - Gram + regularised Cholesky (the MFMA
+    #      GEMM pass), Householder only where the device asks for it - instead of the reference's own rule (Householder QR when the
+    #      stack has more rows than columns, msckf_vio.cpp:795-821) that the headline window ran, so that the line carries both rates
+    #      from one run of the driver's command (the trajectories checked against the oracle below run through both)
     hh = None
-    if pipe and args.householder_steps > 0:
-        run.set_compression(2)
+    if pipe and args.gram_steps > 0:
+        run.set_compression(COMPRESSION_MODES["auto"])
         first2 = max(run.frames_done(g) - run.group_offset(g) for g in range(n_groups))      # every batch catches up to here first
         tsqr0 = run.num_tsqr_updates(0)
         run.set_timing(timing_period)
         run.get_timing(reset=True)
         barrier()
-        el2 = run.run_timed(first2, hh_warm, args.householder_steps, max_extra=cooldown)
+        el2 = run.run_timed(first2, hh_warm, args.gram_steps, max_extra=cooldown)
         barrier()
         timing2 = run.get_timing(reset=True)
         run.set_timing(False)
-        run.set_compression({"auto": 0, "gram": 1, "tsqr": 2}[args.compression])
-        el2, frames2 = aggregate_throughput(el2, n_streams * args.householder_steps, world, device=red_dev)
+        run.set_compression(COMPRESSION_MODES[args.compression])
+        el2, frames2 = aggregate_throughput(el2, n_streams * args.gram_steps, world, device=red_dev)
         dom2 = max(timing2, key=lambda k: timing2[k][0])
-        hh = {"value_householder": frames2 / el2, "steps": args.householder_steps, "warmup": hh_warm, "ms_per_step": el2 * 1e3 / args.householder_steps,
-              "tsqr_updates_stream0_in_window_and_warmup": run.num_tsqr_updates(0) - tsqr0,
+        hh = {"value_gram_cholesky": frames2 / el2, "compression": "auto", "steps": args.gram_steps, "warmup": hh_warm, "ms_per_step": el2 * 1e3 / args.gram_steps,
+              "householder_updates_stream0_in_window_and_warmup": run.num_tsqr_updates(0) - tsqr0,
               "dominant_kernel": dom2, "kernels": {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(v[0] * 1e3 / max(v[1], 1), 2)}
                                                    for k, v in timing2.items() if v[1] and k.startswith("k_ekf")}}
 
@@ -703,7 +708,7 @@ def main(argv=None):
                                      if (pipe and n_groups > 1) else "fixed: every batch of streams on its own group's queues"),
                        "host_throttled_ms_in_timed_region": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)},
             "id_mismatch": id_mismatch,
-            "value_householder": hh["value_householder"] if hh else None, "householder_window": hh,
+            "value_gram_cholesky": hh["value_gram_cholesky"] if hh else None, "gram_window": hh,
             "roofline": roof, "mfma": mfma, "kernels": kernels,
             "host_bookkeeping_us_per_stream_frame": {k: round(v * 1e6 / (n_streams * args.steps), 2) for k, v in hostprof.items()},
             "host_phases_ms_per_step": host_phases,

@@ -286,8 +286,8 @@ int mskf_ekf_remove_clone(mskf_stream *s, int clone_index);
 int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *idx);
 /* Diagnostics for tests: raw work buffers of the stream's last update (0 Hs, 1 rowmask, 2 S, 3 T, 4 W, 5 act). */
 int mskf_ekf_debug_read(mskf_stream *s, int which, void *out, size_t capacity, int *ld_out);
-/* Change mskf_ekf_cfg.compression_mode of a live stream (0 auto, 1 Gram + Cholesky only, 2 Householder TSQR always: the QR of
- * msckf_vio.cpp:795-817 as written); takes effect with the stream's next update.  Not while an update of the stream is pending. */
+/* Change mskf_ekf_cfg.compression_mode of a live stream (0 auto, 1 Gram + Cholesky only, 2 Householder TSQR always, 3 the rule
+ * of msckf_vio.cpp:795-821 as written); takes effect with the stream's next update.  Not while an update of the stream is pending. */
 int mskf_ekf_set_compression_mode(mskf_stream *s, int mode);
 int mskf_ekf_get_dim(mskf_stream *s, int *d);
 int mskf_ekf_get_cov(mskf_stream *s, double *P, int capacity /* doubles */);

@@ -66,8 +66,10 @@ typedef struct mskf_ekf_cfg {
                                     Cholesky; Householder TSQR when the stack has no more STACKED rows than active columns, or
                                     when the factorisation finds that its lambda prior would move the posterior covariance by
                                     more than 1e-6 relative: lambda max(P_aa) / sigma^2; the count of near-zero pivots is
-                                    reported in diag_out[1] but decides nothing), 1 = Gram only, 2 = Householder TSQR always.
-                                    Any other value is refused by mskf_stream_create */
+                                    reported in diag_out[1] but decides nothing), 1 = Gram only, 2 = Householder TSQR always,
+                                    3 = the reference's own rule, literally (:795-821): Householder QR when the stack has more
+                                    rows than (active) columns, no compression otherwise.  Any other value is refused by
+                                    mskf_stream_create */
 } mskf_ekf_cfg;
 
 typedef struct mskf_feature_meas {  /* == cg::FeatureMeasurement */

@@ -72,9 +72,9 @@ int mskf_ekf_stream_init(mskf_stream *s) {
         mskf_set_error("max_cam_state_size must be in [4, 64]");
         return MSKF_ERR_UNSUPPORTED;
     }
-    if (s->ekf.compression_mode < 0 || s->ekf.compression_mode > 2) {
+    if (s->ekf.compression_mode < 0 || s->ekf.compression_mode > 3) {
         // (the field took the place of padding in ABI v1: a caller that never initialised it must hear about it)
-        mskf_set_error("mskf_ekf_cfg.compression_mode must be 0 (auto), 1 (Gram only) or 2 (Householder TSQR)");
+        mskf_set_error("mskf_ekf_cfg.compression_mode must be 0 (auto), 1 (Gram only), 2 (Householder TSQR always) or 3 (the reference's rule)");
         return MSKF_ERR_INVALID;
     }
     E.ld = (int)align_up((size_t)(EKF_IMU_DIM + 6 * E.max_clones), 8);
@@ -203,7 +203,7 @@ extern "C" int mskf_ekf_set_cov(mskf_stream *s, const double *P, int d) {
 
 extern "C" int mskf_ekf_set_compression_mode(mskf_stream *s, int mode) {
     if (!s) return MSKF_ERR_INVALID;
-    if (mode < 0 || mode > 2) { mskf_set_error("compression_mode must be 0 (auto), 1 (Gram only) or 2 (Householder TSQR)"); return MSKF_ERR_INVALID; }
+    if (mode < 0 || mode > 3) { mskf_set_error("compression_mode must be 0 (auto), 1 (Gram only), 2 (Householder TSQR always) or 3 (the reference's rule)"); return MSKF_ERR_INVALID; }
     if (s->ctx_ekf->pend_upd.active) { mskf_set_error("an update batch of the stream's context is pending"); return MSKF_ERR_INVALID; }
     s->ekf.compression_mode = mode;
     extra_of(s)->desc_valid = false;          // the cached descriptor carries the mode

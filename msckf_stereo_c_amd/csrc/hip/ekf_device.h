@@ -56,7 +56,8 @@ struct EkfStreamDev {
                               // kernels (every feature has exactly the same two Jacobian clones), bit 1 wave-per-feature class
                               // (every feature <= 4 observations), bit 2 fused small update (at most 4 clones touched)
     int na_max;               // 6 x the clones any feature of this update observed: an upper bound of the active columns (from the host)
-    int qr_mode;              // mskf_ekf_cfg.compression_mode: 0 auto (Gram + Cholesky, Householder TSQR when flagged), 1 Gram only, 2 TSQR always
+    int qr_mode;              // mskf_ekf_cfg.compression_mode: 0 auto (Gram + Cholesky, Householder TSQR when flagged), 1 Gram only, 2 TSQR always,
+                              // 3 the reference's own rule (Householder when rows > columns, uncompressed otherwise)
     const int *tri_idx;       // features that need triangulation (pair path: k_ekf_triangulate), n_tri of them
     int n_tri;
     int *rows_out;            // [0] stacked rows, [1] last stacked row + 1 (K range of the Gram pass), [2] number of active columns,

@@ -42,8 +42,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 //     stacked row, rows_out[1], may lie far beyond na), so the rows are addressed through a compact list of their indices
 //     (rowidx, built by ekf_compress_entry behind the active-column list).
 //   * otherwise Gram + regularised Cholesky, re-done as Householder TSQR when the factorisation raises the bias flag (bit 1).
-__device__ __forceinline__ bool ekf_direct_wanted(const EkfStreamDev &S) { return S.qr_mode == 0 && S.rows_out[0] <= S.rows_out[2]; }
-__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return S.qr_mode == 2 || ekf_direct_wanted(S); }
+// qr_mode (mskf_ekf_cfg.compression_mode): 0 auto, 1 Gram only, 2 Householder always, 3 = the reference literally
+// (msckf_vio.cpp:795-821): Householder QR when the stack has more rows than columns, nothing otherwise.
+__device__ __forceinline__ bool ekf_mode_direct(int qr_mode, int stacked, int na) { return (qr_mode == 0 || qr_mode == 3) && stacked <= na; }
+__device__ __forceinline__ bool ekf_mode_householder(int qr_mode) { return qr_mode == 2 || qr_mode == 3; }
+__device__ __forceinline__ bool ekf_direct_wanted(const EkfStreamDev &S) { return ekf_mode_direct(S.qr_mode, S.rows_out[0], S.rows_out[2]); }
+__device__ __forceinline__ bool ekf_skip_gram(const EkfStreamDev &S) { return ekf_mode_householder(S.qr_mode) || ekf_direct_wanted(S); }
 // the stream's stacked rows are used uncompressed (set by the factorisation kernel): R = H_act (rows_out[1] x na, dense, rowmask-gathered)
 __device__ __forceinline__ bool ekf_direct(const EkfStreamDev &S) { return (S.rows_out[3] & 4) != 0; }
 // streams whose whole update runs in k_ekf_small_update (route bit, set per STREAM by the host: at most SU_MAX_NA active
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void k_ekf_gemm(const EkfStreamDev *streams) {
         gram_tile_i = (int)blockIdx.x / tg; gram_tile_j = (int)blockIdx.x - gram_tile_i * tg;
         if (gram_tile_j > gram_tile_i || gram_tile_i * GT > S.na_max) return;
         cap = ekf_cap_local(S, blockIdx.x == 0);
-        if (S.qr_mode == 2 || (S.qr_mode == 0 && cap.stacked <= cap.na)) return;       // ekf_skip_gram, on this update's own numbers
+        if (ekf_mode_householder(S.qr_mode) || ekf_mode_direct(S.qr_mode, cap.stacked, cap.na)) return;       // ekf_skip_gram, on this update's own numbers
     }
     const int na = MODE == GM_GRAM ? cap.na : S.rows_out[2];                  // active columns (compact index i <-> column act[i])
     const int *__restrict__ act = S.act;
@@ -381,7 +385,7 @@ template <class RAt>
 __device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gram_done, int diag, RAt Rat, double *sB, int room) {
     const int na = S.rows_out[2], n1 = na + 1, K = S.rows_out[1], d = S.d, ld = S.ld;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const bool need = S.qr_mode == 2 || (S.qr_mode == 0 && (!gram_done || (diag & 2)));
+    const bool need = ekf_mode_householder(S.qr_mode) || (S.qr_mode == 0 && (!gram_done || (diag & 2)));
     if (!need) { if (tid == 0) S.rows_out[3] = diag; return; }
     __syncthreads();
     for (int e = tid; e < n1 * n1; e += nth) { const int k = e / n1, j = e - k * n1; if (j >= k) Rat(k, j) = 0.0; }
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
         __syncthreads();
         const int tiny = s_tiny;
-        const bool need_qr = S.qr_mode == 2 || (S.qr_mode == 0 && (cap.stacked <= na || s_bias));
+        const bool need_qr = ekf_mode_householder(S.qr_mode) || (S.qr_mode == 0 && (cap.stacked <= na || s_bias));
         if (need_qr) {
             for (int e = tid; e < n1 * n1; e += 256) sG[e] = 0.0;
             __syncthreads();

@@ -36,6 +36,9 @@ mskf_ekf_cfg ekf_cfg_from_yaml(const YAML::Node &y) {
     c.max_cam_state_size = (int)y["max_cam_state_size"].as<double>();
     c.chi2_mode = 0;
     c.max_stack_rows = 1500;   // msckf_vio.cpp:1009
+    // how the stacked Jacobian is compressed (not a key of the reference's file): by default the reference's own rule, Householder
+    // QR when there are more rows than columns (:795-821); "compression_mode: 0" selects Gram + regularised Cholesky (include/mskf_types.h)
+    c.compression_mode = y["compression_mode"].IsDefined() ? y["compression_mode"].as<int>() : 3;
     return c;
 }
 

@@ -72,8 +72,10 @@ def default_fe_cfg(grid_row=4, grid_col=5, grid_min=3, grid_max=4, compat=COMPAT
     return c
 
 
-def default_ekf_cfg(max_cam_state_size=20, compression_mode=0):
-    """config/app_msckfvio.yaml values of the reference.  compression_mode: 0 auto, 1 Gram + Cholesky only, 2 Householder TSQR."""
+def default_ekf_cfg(max_cam_state_size=20, compression_mode=3):
+    """config/app_msckfvio.yaml values of the reference.  compression_mode: 3 (default) the reference's own rule - Householder QR
+    when the stack has more rows than columns, nothing otherwise (msckf_vio.cpp:795-821) -, 0 auto (Gram + regularised Cholesky,
+    Householder where the device asks for it), 1 Gram + Cholesky only, 2 Householder TSQR always."""
     c = EkfCfg()
     c.frame_rate = 20.0
     c.max_cam_state_size = max_cam_state_size

@@ -416,6 +416,22 @@ def test_ekf_update_rows_not_more_than_columns_skips_gram(gpu_ctx, oracle):
     assert many["errP"] < 2e-9
 
 
+def test_ekf_update_reference_rule(gpu_ctx, oracle):
+    """compression_mode = 3 (the default of the host mirror and of bench.py): msckf_vio.cpp:795-821 as written - Householder QR
+    when the stack has more rows than (active) columns, the stacked rows themselves otherwise.  Both branches against the
+    oracle, which does the same: rounding level."""
+    many = _update_vs_oracle(gpu_ctx, oracle, 13, 8, 1301, 3, min_obs=3)
+    assert many["got"]["rows"] > many["na"] and many["got"]["used_qr"] == 1           # 1 = Householder
+    assert many["errP"] < 1e-12 and many["errdx"] < 1e-9
+    few = _update_vs_oracle(gpu_ctx, oracle, 13, 2, 1301, 3, min_obs=3)
+    assert few["got"]["rows"] <= few["na"] and few["got"]["used_qr"] == 2             # 2 = uncompressed
+    assert few["errP"] < 1e-12 and few["errdx"] < 1e-9
+    big = _update_vs_oracle(gpu_ctx, oracle, 30, 60, 3, 3)                            # the 1500-row cap, R beside a 48-row block in LDS
+    assert big["got"]["used_qr"] == 1 and big["errP"] < 1e-12
+    prune = _update_vs_oracle(gpu_ctx, oracle, 30, 400, 31, 3, 0, False, pair=(3, 4), noise=0.004)    # pruning shape: 128-row blocks in the fused update
+    assert prune["got"]["used_qr"] == 1 and prune["errP"] < 1e-12
+
+
 def test_ekf_compression_condition_sweep(gpu_ctx, oracle):
     """Gram + regularised Cholesky squares cond(H) and adds the prior lambda I; how far can the stack be pushed before
     that shows?  The generator is driven towards ill conditioning (camera motion between clones shrunk to 1e-4, cond(H)
@@ -624,9 +640,9 @@ def test_ekf_gated_out_block_leaves_a_gap_in_a_short_stack(gpu_ctx, oracle):
 
 
 def test_compression_mode_is_validated(gpu_ctx, oracle):
-    """mskf_ekf_cfg.compression_mode took the place of padding: anything but 0, 1, 2 is refused at stream creation."""
+    """mskf_ekf_cfg.compression_mode took the place of padding: anything but 0, 1, 2, 3 is refused at stream creation."""
     calib = oracle.euroc_calib(376, 240)
-    for bad in (-1, 3, 0x7fffffff):
+    for bad in (-1, 4, 0x7fffffff):
         with pytest.raises(capi.MskfError):
             capi.Stream(gpu_ctx, calib, default_fe_cfg(), default_ekf_cfg(compression_mode=bad))
 

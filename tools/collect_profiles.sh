@@ -13,13 +13,13 @@ OUT=gpurun_out/${1:-prof}
 WHAT=${2:-lines}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SOLO="python bench.py --no-cpu --steps 6 --warmup 2 --streams 192 --groups 1 --no-pipeline --householder-steps 0"     # one 192-stream launch per kernel: the benched launch shape
-SOLO3="python bench.py --config c3 --no-cpu --steps 6 --warmup 2 --streams 16 --groups 1 --no-pipeline --householder-steps 0"
+SOLO="python bench.py --no-cpu --steps 6 --warmup 2 --streams 192 --groups 1 --no-pipeline --gram-steps 0"     # one 192-stream launch per kernel: the benched launch shape
+SOLO3="python bench.py --config c3 --no-cpu --steps 6 --warmup 2 --streams 16 --groups 1 --no-pipeline --gram-steps 0"
 if [ "$WHAT" = lines ]; then
   timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>> "$OUT/log.txt" || exit 1
   echo "driver command done" ; cut -c1-160 "$OUT/bench_driver_cmd.json"
   timeout -k 10 300 python bench.py --no-cpu > "$OUT/bench_60_steps.json" 2>> "$OUT/log.txt" || exit 2
-  timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --compression tsqr > "$OUT/bench_tsqr.json" 2>> "$OUT/log.txt" || exit 3
+  timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --compression auto > "$OUT/bench_gram.json" 2>> "$OUT/log.txt" || exit 3
   timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --host-images > "$OUT/bench_host_images.json" 2>> "$OUT/log.txt" || exit 4
   echo "c2 variants done"
   timeout -k 10 400 python bench.py --config c3 > "$OUT/bench_c3.json" 2>> "$OUT/log.txt" || exit 5
@@ -32,7 +32,7 @@ if [ "$WHAT" = lines ]; then
   timeout -k 10 400 python bench.py --gpus 2 --backend gloo --no-cpu --steps 20 --warmup 5 > "$OUT/bench_2rank_gloo_one_gpu.json" 2>> "$OUT/log.txt" || exit 7
   echo "all lines done"
 else
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --no-cpu --steps 20 --warmup 5 --householder-steps 0 > "$OUT/bench_under_rocprof.json" 2>> "$OUT/log.txt" || exit 2
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --no-cpu --steps 20 --warmup 5 --gram-steps 0 > "$OUT/bench_under_rocprof.json" 2>> "$OUT/log.txt" || exit 2
   echo "stats done"
   python tools/trace_busy.py "$OUT"/stats/*/*_kernel_trace.csv > "$OUT/trace_occupancy.txt" 2>> "$OUT/log.txt"
   rm -f "$OUT"/stats/*/*_kernel_trace.csv
