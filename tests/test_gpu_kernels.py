@@ -536,13 +536,14 @@ def test_track_capacity_and_errors(gpu_ctx, oracle):
     s.close()
 
 
-def test_ekf_mixed_batch_takes_each_stream_its_own_route(gpu_ctx, oracle):
+@pytest.mark.parametrize("mode,expect", [(3, {1, 2}), (0, {0, 2})])
+def test_ekf_mixed_batch_takes_each_stream_its_own_route(gpu_ctx, oracle, mode, expect):
     """One mskf_ekf_update_batch over streams of every route (EkfStreamDev::route): a pruning-shaped stream (pair kernels +
     fused small update), a stream whose features all have <= 4 observations (wave class), a general stream with small and
     large features, a stream with fewer stacked rows than active columns, an empty one.  Each stream's results are
     bit-identical to the same update issued alone."""
     calib = oracle.euroc_calib(376, 240)
-    cfg = default_ekf_cfg(max_cam_state_size=30)
+    cfg = default_ekf_cfg(max_cam_state_size=30, compression_mode=mode)
     specs = [dict(n_clones=30, n_feat=120, seed=41, pair=(3, 4)),             # pairs + small
              dict(n_clones=30, n_feat=25, seed=42, min_obs=3, max_obs=4),     # wave class
              dict(n_clones=30, n_feat=50, seed=43, min_obs=3),                # general: classes [1] and [2]
@@ -585,7 +586,7 @@ def test_ekf_mixed_batch_takes_each_stream_its_own_route(gpu_ctx, oracle):
         assert np.array_equal(a["delta_x"], b["delta_x"]) and np.array_equal(Pa, Pb)
         routes.add(a["used_qr"])
     assert all(r["rows"] > 0 for r in alone)
-    assert {0, 2} <= routes                 # the batch really mixed Gram-compressed and uncompressed updates
+    assert expect <= routes                 # the batch really mixed compressed (1 Householder / 0 Gram) and uncompressed (2) updates
     # ... and against the oracle, per stream
     for pr, kw, got, Pg in zip(problems, kwargs, together, P_together):
         ref = oracle.ekf_update_problem(calib, cfg, pr["gravity"], pr["clones"], pr["P"], pr["positions"], pr["obs_start"], pr["obs_clone"],
