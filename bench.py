@@ -375,6 +375,16 @@ def rehearse(args, rank, world):
     return 0
 
 
+_T0 = time.perf_counter()
+
+
+def progress(rank, what):
+    """One stderr line per stage of the run (rank 0): where a run that stops making progress stopped."""
+    if rank == 0:
+        sys.stderr.write("bench.py [%7.2f s] %s\n" % (time.perf_counter() - _T0, what))
+        sys.stderr.flush()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -455,6 +465,7 @@ def main(argv=None):
             h_frames.copy_(d_frames)
             d_frames = None
     render_s = time.perf_counter() - t_r0
+    progress(rank, "sequences rendered (%s), %d streams in %d batches" % ("host" if args.host_render else "device", n_streams, n_groups))
     if args.host_images:
         base, on_device = h_frames.data_ptr(), 0
     else:
@@ -486,6 +497,7 @@ def main(argv=None):
 
     pipe = not args.no_pipeline
     run.run(0, args.prime, pipelined=pipe)                       # untimed: gravity/bias init, clone window fills, group offsets
+    progress(rank, "primed: %d frames per stream" % args.prime)
     # per-kernel HIP events on every 5th launch of a kind (5 is coprime to the launches per step of every kind, so all of a
     # step's launches are sampled in turn); MSKF_BENCH_TIMING_PERIOD=1 times every launch, MSKF_BENCH_NO_KERNEL_TIMING=1 none
     timing_period = 0 if os.environ.get("MSKF_BENCH_NO_KERNEL_TIMING") else int(os.environ.get("MSKF_BENCH_TIMING_PERIOD", "5"))
@@ -521,6 +533,7 @@ def main(argv=None):
         barrier()
         elapsed = wall_run = time.perf_counter() - t0
         phases = run.get_phases(reset=True)
+    progress(rank, "timed window done: %d steps in %.3f s" % (args.steps, elapsed))
     hostprof = run.get_hostprof()
     _, thr1 = cgroup_cpu()
     timing = run.get_timing(reset=True)
@@ -566,6 +579,7 @@ def main(argv=None):
         el2 = run.run_timed(first2, hh_warm, args.gram_steps, max_extra=cooldown)
         barrier()
         timing2 = run.get_timing(reset=True)
+        progress(rank, "second window (Gram + Cholesky) done: %d steps in %.3f s" % (args.gram_steps, el2))
         run.set_timing(False)
         run.set_compression(COMPRESSION_MODES[args.compression])
         el2, frames2 = aggregate_throughput(el2, n_streams * args.gram_steps, world, device=red_dev)

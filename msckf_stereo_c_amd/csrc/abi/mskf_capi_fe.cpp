@@ -8,6 +8,7 @@
 #include <chrono>
 #include <atomic>
 #include <mutex>
+#include <vector>
 #include "mskf_internal.h"
 
 static thread_local std::string g_last_error;
@@ -426,6 +427,25 @@ extern "C" void mskf_stream_destroy(mskf_stream *s) {
     delete s;
 }
 
+// TEMPORARY DIAGNOSTIC: stage marks of a device frame in pinned host memory (MSKF_FE_CRUMBS=1), printed when a frame times out
+static volatile unsigned int *crumb_word(mskf_ctx *ctx) {
+    static const bool on = [] { const char *e = std::getenv("MSKF_FE_CRUMBS"); return e && e[0] == '1'; }();
+    if (!on) return nullptr;
+    static std::mutex mu;
+    static std::vector<std::pair<mskf_ctx *, unsigned int *>> tab;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &t : tab) if (t.first == ctx) return t.second;
+    unsigned int *p = nullptr;
+    if (hipHostMalloc((void **)&p, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return nullptr;
+    *p = 0;
+    tab.push_back({ctx, p});
+    return p;
+}
+static void crumb(mskf_ctx *ctx, unsigned int v) {
+    volatile unsigned int *w = crumb_word(ctx);
+    if (w) (void)hipStreamWriteValue32(ctx->stream, (void *)w, v, 0);
+}
+
 static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
     std::memset(&d, 0, sizeof(d));
     fill_pyr(s, s->i_prev0, d.prev0);
@@ -506,7 +526,9 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
         }
         MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(Pyr3Job) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
         const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
+        crumb(ctx, 1);
         fe_launch_pyr_down3(ctx->jobs.d, 2 * n, max_w, max_h, st);
+        crumb(ctx, 2);
         mskf_t_end(ctx, ts, px);          // units: output pixels of the three levels
     }
     // detector per-cell maxima on cam0 level 0
@@ -524,6 +546,7 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
         for (int i = 0; i < n; ++i) px += (long long)streams[i]->w * streams[i]->h;
         const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
         fe_launch_detect(ctx->desc[0].d, n, max_w, max_h, gen, st);
+        crumb(ctx, 3);
         mskf_t_end(ctx, ts, px);
     }
     if (copy_cells) {
@@ -869,17 +892,22 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
     MSKF_HIPCHK(hipMemcpyAsync(ctx->book_desc.d, ctx->book_desc.h, sizeof(FeBookDev) * (size_t)n, hipMemcpyHostToDevice, st));
     const int ts1 = mskf_t_begin(ctx, MSKF_K_LK);
     fe_launch_track(ctx->desc[1].d, n, max_prev, st);
+    crumb(ctx, 4);
     mskf_t_end(ctx, ts1, 0);
     int tb = mskf_t_begin(ctx, MSKF_K_FE_BOOK);
     fe_launch_book(ctx->book_desc.d, n, 0, scratch_bytes, st);
+    crumb(ctx, 5);
     mskf_t_end(ctx, tb, n);
     const int ts2 = mskf_t_begin(ctx, MSKF_K_LK);
     fe_launch_track(ctx->desc[2].d, n, std::max(max_cand_est, 4), st);
+    crumb(ctx, 6);
     mskf_t_end(ctx, ts2, 0);
     tb = mskf_t_begin(ctx, MSKF_K_FE_BOOK);
     fe_launch_book(ctx->book_desc.d, n, 1, scratch_bytes, st);
+    crumb(ctx, 7);
     mskf_t_end(ctx, tb, n);
     MSKF_HIPCHK(hipMemcpyAsync(ctx->book_out.h, ctx->book_out.d, out_bytes, hipMemcpyDeviceToHost, st));
+    crumb(ctx, 8);
     MSKF_HIPCHK(hipGetLastError());
     if ((rc = mskf_wait_event(ctx, &ctx->pend_frame.done, true)) != MSKF_OK) return rc;
     // state rotation (:192-200): the grid just built is the next frame's previous grid, curr cam0 becomes prev cam0
@@ -902,7 +930,10 @@ extern "C" int mskf_fe_frame_batch_end(mskf_ctx *ctx) {
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     F.active = false;
     int rc;
-    if ((rc = mskf_wait_event(ctx, &F.done, false)) != MSKF_OK) return rc;
+    if ((rc = mskf_wait_event(ctx, &F.done, false)) != MSKF_OK) {
+        if (volatile unsigned int *w = crumb_word(ctx)) std::fprintf(stderr, "mskf_fe_frame_batch_end: wait failed, last stage mark of this context = %u (1 before pyramid, 2 pyramid, 3 detector, 4 track1, 5 book1, 6 track2, 7 book2, 8 copy)\n", *w);
+        return rc;
+    }
     const auto t_h1 = std::chrono::steady_clock::now();
     long long tracks1 = 0, tracks2 = 0;
     bool overflow = false;

@@ -10,6 +10,7 @@
 // per-camera ray tables (synth::Stream::render_params / ray_table).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
 #include "synth.h"
 
 __global__ __launch_bounds__(256) void k_synth_render(const synth::RenderImg *imgs, const float *rays0, const float *rays1, uint8_t *out, size_t frame_bytes, int n_px) {
@@ -38,10 +39,16 @@ int synth_hip_render(const synth::RenderImg *imgs_host, int n_imgs, const float 
                      uint8_t *out_dev, size_t frame_bytes, void *stream) {
     if (!imgs_host || n_imgs <= 0 || !rays0_dev || !rays1_dev || !out_dev || width <= 0 || height <= 0 || (frame_bytes & 3) || frame_bytes < (size_t)width * height) return -1;
     hipStream_t st = (hipStream_t)stream;
-    synth::RenderImg *d = nullptr;
-    if (hipMalloc((void **)&d, sizeof(synth::RenderImg) * (size_t)n_imgs) != hipSuccess) return -2;
+    // the records go through a pinned staging block of the library's own: an asynchronous copy straight from the caller's pageable
+    // memory (a numpy array) makes the runtime pin those pages in place, and a pinned mapping of memory the Python heap later
+    // reuses or the kernel migrates has to be torn down by the driver with every queue of the process stopped
+    const size_t pbytes = sizeof(synth::RenderImg) * (size_t)n_imgs;
+    synth::RenderImg *d = nullptr, *hp = nullptr;
+    if (hipHostMalloc((void **)&hp, pbytes, hipHostMallocDefault) != hipSuccess) return -2;
+    if (hipMalloc((void **)&d, pbytes) != hipSuccess) { (void)hipHostFree(hp); return -2; }
+    std::memcpy(hp, imgs_host, pbytes);
     int rc = 0;
-    if (hipMemcpyAsync(d, imgs_host, sizeof(synth::RenderImg) * (size_t)n_imgs, hipMemcpyHostToDevice, st) != hipSuccess) rc = -2;
+    if (hipMemcpyAsync(d, hp, pbytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = -2;
     const int n_px = width * height;
     for (int i0 = 0; rc == 0 && i0 < n_imgs; i0 += 32768) {          // (grid.y limit)
         const int cnt = n_imgs - i0 < 32768 ? n_imgs - i0 : 32768;
@@ -50,6 +57,7 @@ int synth_hip_render(const synth::RenderImg *imgs_host, int n_imgs, const float 
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = -3;
     (void)hipFree(d);
+    (void)hipHostFree(hp);
     return rc;
 }
 

@@ -35,7 +35,8 @@ def render_sequences(syns, n_keys, device, hip_stream=None):
     w, h = syns[0].w, syns[0].h
     assert (w * h) % 4 == 0, "the device renderer stores four pixels per thread"
     out = torch.empty((len(syns), 2, n_keys, h, w), dtype=torch.uint8, device=device)
-    rays = [torch.from_numpy(syns[0].ray_table(c)).to(device) for c in (0, 1)]       # calibration only: the same for every seed
+    # (calibration only: the same for every seed; through pinned memory - see synth_hip_render about pageable sources)
+    rays = [torch.from_numpy(syns[0].ray_table(c)).pin_memory().to(device) for c in (0, 1)]
     torch.cuda.synchronize(device)
     from .ctypes_types import RENDER_IMG
     with torch.cuda.device(device):
