@@ -381,7 +381,7 @@ _T0 = time.perf_counter()
 def progress(rank, what):
     """One stderr line per stage of the run (rank 0): where a run that stops making progress stopped."""
     if rank == 0:
-        sys.stderr.write("bench.py [%7.2f s] %s\n" % (time.perf_counter() - _T0, what))
+        sys.stderr.write("bench.py [%7.2f s, monotonic %.3f] %s\n" % (time.perf_counter() - _T0, time.monotonic(), what))
         sys.stderr.flush()
 
 

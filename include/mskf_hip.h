@@ -68,7 +68,7 @@ void *mskf_ctx_hip_stream(mskf_ctx *ctx);
  * 7 % of the throughput at the C2 bench shape and 36 % at C5 (one stream per launch), measured. */
 enum {
     MSKF_K_PYR = 0, MSKF_K_DETECT, MSKF_K_LK, MSKF_K_EKF_PROPAGATE, MSKF_K_EKF_AUGMENT, MSKF_K_EKF_FEATURES,
-    MSKF_K_EKF_CAP, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_FE_BOOK, MSKF_K_COUNT
+    MSKF_K_EKF_TSQR /* k_ekf_tsqr; rounds 1-3: the stacking-decision kernel, which no longer exists */, MSKF_K_EKF_GEMM, MSKF_K_EKF_CHOL, MSKF_K_EKF_TRSM, MSKF_K_EKF_SMALL, MSKF_K_EKF_REMOVE, MSKF_K_PT_GEOM, MSKF_K_FE_BOOK, MSKF_K_COUNT
 };
 int mskf_ctx_set_timing(mskf_ctx *ctx, int enable);
 /* Accounting gate (default on): while it is off, launches are not timed and host seconds not accumulated.  Unlike

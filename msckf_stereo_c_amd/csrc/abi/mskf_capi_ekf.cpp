@@ -17,6 +17,7 @@ void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st
 void ekf_launch_posvar_upd(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
+void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 int ekf_small_update_max_na(void);
@@ -321,12 +322,14 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
         }
     }
     if (!any) return MSKF_OK;
-    MSKF_HIPCHK(hipMemcpyAsync(dv, h, off, hipMemcpyHostToDevice, st));
+    { const MskfCopy cp = {dv, h, off}; const int crc = mskf_copy_async(ctx, &cp, 1); if (crc != MSKF_OK) return crc; }
     MSKF_HIPCHK(hipEventRecord(ctx->pred_done, st));
     ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_PROPAGATE);
+        mskf_crumb(ctx, 10);
         ekf_launch_propagate((const EkfStreamDev *)dv, n, st);
+        mskf_crumb(ctx, 11);
         mskf_t_end(ctx, ts, n);
     }
     MSKF_HIPCHK(hipGetLastError());
@@ -358,9 +361,8 @@ extern "C" int mskf_ekf_get_pos_var_batch_begin(mskf_ctx *ctx, int n, mskf_strea
         if (!streams[i] || streams[i]->ctx_ekf != ctx) return MSKF_ERR_INVALID;
         base_desc(streams[i], D[i]);
     }
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.d, ctx->pred_arena.h, desc_bytes, hipMemcpyHostToDevice, st));
-    ekf_launch_posvar((const EkfStreamDev *)ctx->pred_arena.d, n, (double *)(ctx->pred_arena.d + desc_bytes), st);
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.h + desc_bytes, ctx->pred_arena.d + desc_bytes, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+    // (no staging copies: the kernel reads its descriptors from the pinned arena and writes the 3 n doubles straight into it)
+    ekf_launch_posvar((const EkfStreamDev *)ctx->pred_arena.h, n, (double *)(ctx->pred_arena.h + desc_bytes), st);
     { const int wrc = mskf_wait_event(ctx, &ctx->pend_pv.done, true); if (wrc != MSKF_OK) return wrc; }
     ctx->pend_pv.active = true; ctx->pend_pv.n = n; ctx->pend_pv.out = out; ctx->pend_pv.desc_bytes = desc_bytes;
     return MSKF_OK;
@@ -441,12 +443,14 @@ extern "C" int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *c
         any |= a >= 0;
     }
     if (!any) return MSKF_OK;
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->pred_arena.d, ctx->pred_arena.h, bytes, hipMemcpyHostToDevice, st));
+    { const MskfCopy cp = {ctx->pred_arena.d, ctx->pred_arena.h, bytes}; const int crc = mskf_copy_async(ctx, &cp, 1); if (crc != MSKF_OK) return crc; }
     MSKF_HIPCHK(hipEventRecord(ctx->pred_done, st));
     ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_REMOVE);
+        mskf_crumb(ctx, 12);
         ekf_launch_remove_clone((const EkfStreamDev *)ctx->pred_arena.d, n, st);
+        mskf_crumb(ctx, 13);
         mskf_t_end(ctx, ts, n);
     }
     MSKF_HIPCHK(hipGetLastError());
@@ -494,6 +498,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     cnt_cls.assign((size_t)3 * n, 0);
     std::vector<int> route(n, 0), na_max(n, 0);
     bool any_pairs = false, any_small = false, any_general = false;
+    bool any_householder = false, any_gram = false;      // among the general-route streams: compressed by k_ekf_tsqr / by the Gram factorisation
     int max_feat_pairs = 0;
     double fl_feat = 0, fl_qr = 0, fl_upd = 0;   // algorithmic FP64 flops of this launch
     struct Lay { size_t clones, feats, obs_clone, obs_z, tri; int n_tri; size_t o_dx, o_gamma, o_rows, o_status, o_pos; int m_total; };
@@ -575,6 +580,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
             const size_t bytes = ((size_t)cap * E.ld + (size_t)cap) * sizeof(double);
             double *grown = nullptr;
+            MskfDiagScope diag("Hs growth (hipMallocAsync + memset + hipFreeAsync)");
             MSKF_HIPCHK(hipMallocAsync((void **)&grown, bytes, st));
             if (hipMemsetAsync(grown, 0, bytes, st) != hipSuccess) { (void)hipFreeAsync(grown, st); mskf_set_error("hipMemsetAsync of the grown stacked-Jacobian buffer failed"); return MSKF_ERR_HIP; }
             if (E.Hs) { if (E.hs_async) (void)hipFreeAsync(E.Hs, st); else extra_of(s)->retired_hs.push_back(E.Hs); }      // (rs lives behind Hs in the same allocation)
@@ -589,6 +595,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             route[i] = (pairs ? 1 : 0) | (wave ? 2 : 0) | (small ? 4 : 0);
             na_max[i] = 6 * __builtin_popcountll(clone_mask);
             any_pairs |= pairs; any_small |= small; any_general |= !small;
+            if (!small) { const bool hh = s->ekf.compression_mode == 2 || s->ekf.compression_mode == 3; any_householder |= hh; any_gram |= !hh; }
             if (pairs) { max_feat_pairs = std::max(max_feat_pairs, a.n_feat); max_tri = std::max(max_tri, n_tri); }
             if (pairs || wave) {
                 // the whole stream is class [0] (wave) or handled by the pair kernels: none of its features in [1] / [2]
@@ -611,6 +618,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     const size_t work_off = in_bytes;
     in_bytes = align_up(in_bytes + sizeof(int) * (size_t)(n_work[0] + n_work[1] + n_work[2]), 64);
     if (in_bytes > ctx->upd_in.cap || out_bytes > ctx->upd_out.cap) {
+        MskfDiagScope diag("update arenas grow (stream synchronise)");
         MSKF_HIPCHK(hipStreamSynchronize(st));
         if ((rc = ctx->upd_in.ensure(in_bytes)) != MSKF_OK) return rc;
         if ((rc = ctx->upd_out.ensure(out_bytes)) != MSKF_OK) return rc;
@@ -668,15 +676,20 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         D.feat_status = (uint8_t *)(dout + L.o_status);
     }
     if (max_feat > 0) {
-        MSKF_HIPCHK(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
-        MSKF_HIPCHK(hipMemcpyAsync(ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+        {
+            const MskfCopy cp[2] = {{din, hin, in_bytes}, {ctx->ekf_desc.d, ctx->ekf_desc.h, sizeof(EkfStreamDev) * (size_t)n}};
+            if ((rc = mskf_copy_async(ctx, cp, 2)) != MSKF_OK) return rc;
+        }
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
+        mskf_crumb(ctx, 20);
         if (any_pairs) ekf_launch_pair_features(ctx->ekf_desc.d, n, max_feat_pairs, max_tri, st);      // the pruning update
+        mskf_crumb(ctx, 21);
         if (n_work[0] + n_work[1] + n_work[2] > 0) {
             const int *w0 = (const int *)(din + work_off);
             ekf_launch_features(ctx->ekf_desc.d, w0, n_work[0], w0 + n_work[0], n_work[1], w0 + n_work[0] + n_work[1], n_work[2], max_frows,
                                 max_frows_cls[1], max_clones_cfg, st);
         }
+        mskf_crumb(ctx, 22);
         mskf_t_end(ctx, ts, (long long)fl_feat);
         // (which blocks are stacked - the 1500-row cap of :1002-1010 - is worked out by the first dense kernel of each route
         //  itself: ekf_cap.h; rounds 1-3 ran it as a launch of its own here)
@@ -687,6 +700,7 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             // compression, gain and Y in one launch (k_ekf_small_update); the other streams leave it at once
             ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
             ekf_launch_small_update(ctx->ekf_desc.d, n, max_d, st);
+            mskf_crumb(ctx, 23);
             mskf_t_end(ctx, ts, any_general ? 0 : (long long)(fl_qr + fl_upd));
         }
         if (any_general) {
@@ -694,31 +708,47 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             // streams that need it), then the Kalman update (ekf_linalg.hip); small-route streams leave these at once
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
+            mskf_crumb(ctx, 24);
             mskf_t_end(ctx, ts, (long long)fl_qr);
-            ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
-            ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
-            mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+            if (any_householder) {
+                // Householder TSQR of the streams in compression_mode 2 / 3 (a kernel without LDS of its own: ekf_linalg.hip)
+                ts = mskf_t_begin(ctx, MSKF_K_EKF_TSQR);
+                ekf_launch_tsqr(ctx->ekf_desc.d, n, max_d, st);
+                mskf_t_end(ctx, ts, (long long)fl_qr);
+            }
+            if (any_gram) {
+                ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
+                ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
+                mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
+            }
+            mskf_crumb(ctx, 25);
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
+            mskf_crumb(ctx, 26);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_S2, max_d, st);
+            mskf_crumb(ctx, 27);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
             ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
             ekf_launch_chol(ctx->ekf_desc.d, n, 1, max_d, st);
+            mskf_crumb(ctx, 28);
             mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
             ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
             ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
+            mskf_crumb(ctx, 29);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
         }
         // P <- P - Y^T Y and delta_x = Y^T w for every stream, whichever route produced Y
         ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
+        mskf_crumb(ctx, 30);
         mskf_t_end(ctx, ts, any_general ? (long long)(4.0 * d3) : 0);
         if (any_pv_nofeat) ekf_launch_posvar_upd(ctx->ekf_desc.d, n, st);       // (streams with features get theirs from the downdate's epilogue)
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
-        MSKF_HIPCHK(hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
+        { const MskfCopy cp = {hout, dout, out_bytes}; if ((rc = mskf_copy_async(ctx, &cp, 1)) != MSKF_OK) return rc; }
+        mskf_crumb(ctx, 31);
         if ((rc = mskf_wait_event(ctx, &ctx->pend_upd.done, true)) != MSKF_OK) return rc;
     }
     {

@@ -82,6 +82,58 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
 extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hipStream_t st);
 extern "C" size_t fe_book_lds_budget(void);
 
+// TEMPORARY DIAGNOSTIC: stage marks of a context's command stream in pinned host memory (MSKF_FE_CRUMBS=1), dumped for
+// every context when a wait runs into its time limit
+static std::mutex g_crumb_mu;
+static std::vector<std::pair<mskf_ctx *, unsigned int *>> g_crumb_tab;
+static volatile unsigned int *crumb_word(mskf_ctx *ctx) {
+    static const bool on = [] { const char *e = std::getenv("MSKF_FE_CRUMBS"); return e && e[0] == '1'; }();
+    if (!on) return nullptr;
+    std::lock_guard<std::mutex> lk(g_crumb_mu);
+    for (auto &t : g_crumb_tab) if (t.first == ctx) return t.second;
+    unsigned int *p = nullptr;
+    if (hipHostMalloc((void **)&p, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return nullptr;
+    p[0] = 0; p[1] = 0;
+    g_crumb_tab.push_back({ctx, p});
+    return p;
+}
+void mskf_crumb(mskf_ctx *ctx, unsigned int v) {
+    volatile unsigned int *w = crumb_word(ctx);
+    if (w) { ((unsigned int *)w)[1] = v; (void)hipStreamWriteValue32(ctx->stream, (void *)w, v, 0); }
+}
+static void crumb(mskf_ctx *ctx, unsigned int v) { mskf_crumb(ctx, v); }
+static void crumb_dump(mskf_ctx *who) {
+    static std::atomic<int> dumps{0};
+    if (dumps.fetch_add(1) > 0) return;
+    std::lock_guard<std::mutex> lk(g_crumb_mu);
+    for (auto &t : g_crumb_tab) {
+        const hipError_t e = hipStreamQuery(t.first->stream);
+        std::fprintf(stderr, "crumbs: ctx %p%s stream %p query=%d executed=%u enqueued=%u\n", (void *)t.first, t.first == who ? " (the waiter)" : "", (void *)t.first->stream, (int)e, t.second[0], t.second[1]);
+    }
+    std::fflush(stderr);
+}
+
+extern "C" void fe_launch_copy(void *const *dst, const void *const *src, const size_t *bytes, int n_segs, hipStream_t st);
+int mskf_copy_async(mskf_ctx *c, const MskfCopy *segs, int n) {
+    static const bool sdma = [] { const char *e = std::getenv("MSKF_SDMA_COPIES"); return e && e[0] == '1'; }();
+    if (sdma) {
+        for (int i = 0; i < n; ++i) if (segs[i].bytes) MSKF_HIPCHK(hipMemcpyAsync(segs[i].dst, segs[i].src, segs[i].bytes, hipMemcpyDefault, c->stream));
+        return MSKF_OK;
+    }
+    for (int i0 = 0; i0 < n; i0 += MSKF_COPY_SEGS) {
+        void *dst[MSKF_COPY_SEGS]; const void *src[MSKF_COPY_SEGS]; size_t bytes[MSKF_COPY_SEGS];
+        int m = 0;
+        for (int i = i0; i < n && i < i0 + MSKF_COPY_SEGS; ++i) {
+            if (!segs[i].bytes) continue;
+            if (((uintptr_t)segs[i].dst | (uintptr_t)segs[i].src) & 15) { mskf_set_error("staging copy with an unaligned end"); return MSKF_ERR_INVALID; }
+            dst[m] = segs[i].dst; src[m] = segs[i].src; bytes[m] = segs[i].bytes; ++m;
+        }
+        if (m) fe_launch_copy(dst, src, bytes, m, c->stream);
+    }
+    MSKF_HIPCHK(hipGetLastError());
+    return MSKF_OK;
+}
+
 int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
     if (c->wait_block) {
         if (!*ev_slot) MSKF_HIPCHK(hipEventCreateWithFlags(ev_slot, hipEventDisableTiming | hipEventBlockingSync));
@@ -143,9 +195,18 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
         if (check) {                                             // about every 10 ms
             const auto now = std::chrono::steady_clock::now();
             if (!timing) { t0 = now; timing = true; }
+            else if (MskfDiagScope::enabled() && std::chrono::duration<double>(now - t0).count() > 1.0) {
+                static std::atomic<int> slow{0};
+                if (slow.fetch_add(1) == 0) {
+                    std::fprintf(stderr, "mskf diag [%.3f s] a wait of ctx %p is longer than 1 s (mark %u wanted %u)\n", std::chrono::duration<double>(now.time_since_epoch()).count(), (void *)c, *w, want);
+                    crumb_dump(c);
+                }
+            }
             else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
                 const hipError_t e = hipStreamQuery(c->stream);
                 mskf_set_error(e != hipSuccess && e != hipErrorNotReady ? hipGetErrorString(e) : "completion mark not written within the wait limit");
+                std::fprintf(stderr, "mskf_wait_event: ctx %p slot %d mark %u wanted %u, stream query %d\n", (void *)c, k, *w, want, (int)e);
+                crumb_dump(c);
                 return MSKF_ERR_HIP;
             }
         }
@@ -427,25 +488,6 @@ extern "C" void mskf_stream_destroy(mskf_stream *s) {
     delete s;
 }
 
-// TEMPORARY DIAGNOSTIC: stage marks of a device frame in pinned host memory (MSKF_FE_CRUMBS=1), printed when a frame times out
-static volatile unsigned int *crumb_word(mskf_ctx *ctx) {
-    static const bool on = [] { const char *e = std::getenv("MSKF_FE_CRUMBS"); return e && e[0] == '1'; }();
-    if (!on) return nullptr;
-    static std::mutex mu;
-    static std::vector<std::pair<mskf_ctx *, unsigned int *>> tab;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto &t : tab) if (t.first == ctx) return t.second;
-    unsigned int *p = nullptr;
-    if (hipHostMalloc((void **)&p, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return nullptr;
-    *p = 0;
-    tab.push_back({ctx, p});
-    return p;
-}
-static void crumb(mskf_ctx *ctx, unsigned int v) {
-    volatile unsigned int *w = crumb_word(ctx);
-    if (w) (void)hipStreamWriteValue32(ctx->stream, (void *)w, v, 0);
-}
-
 static void fill_fe_desc(const mskf_stream *s, FeStreamDev &d) {
     std::memset(&d, 0, sizeof(d));
     fill_pyr(s, s->i_prev0, d.prev0);
@@ -524,7 +566,10 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
             }
             for (int l = 1; l < MSKF_LEVELS; ++l) px += 2LL * s->lw[l] * s->lh[l];
         }
-        MSKF_HIPCHK(hipMemcpyAsync(ctx->jobs.d, ctx->jobs.h, sizeof(Pyr3Job) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
+        // (one staging launch for the pyramid jobs and the detector's descriptors)
+        for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
+        const MskfCopy cp[2] = {{ctx->jobs.d, ctx->jobs.h, sizeof(Pyr3Job) * 2 * (size_t)n}, {ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n}};
+        if ((rc = mskf_copy_async(ctx, cp, 2)) != MSKF_OK) return rc;
         const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
         crumb(ctx, 1);
         fe_launch_pyr_down3(ctx->jobs.d, 2 * n, max_w, max_h, st);
@@ -532,8 +577,6 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
         mskf_t_end(ctx, ts, px);          // units: output pixels of the three levels
     }
     // detector per-cell maxima on cam0 level 0
-    for (int i = 0; i < n; ++i) fill_fe_desc(streams[i], ctx->desc[0].h[i]);
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
     {
         // the keys carry the push generation in their top byte: a newer push wins every atomicMax, so the key array is
         // cleared only when it is fresh or the 8-bit generation wraps (not once per frame)
@@ -887,9 +930,11 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
         B.x_cam0 = (mskf_point2f *)(o + 64 + 12 * (size_t)K.cap);
         B.x_cam1 = B.x_cam0 + K.cap; B.x_und0 = B.x_cam1 + K.cap; B.x_und1 = B.x_und0 + K.cap;
     }
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[2].d, ctx->desc[2].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->book_desc.d, ctx->book_desc.h, sizeof(FeBookDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    {
+        const MskfCopy cp[3] = {{ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n}, {ctx->desc[2].d, ctx->desc[2].h, sizeof(FeStreamDev) * (size_t)n},
+                                {ctx->book_desc.d, ctx->book_desc.h, sizeof(FeBookDev) * (size_t)n}};
+        if ((rc = mskf_copy_async(ctx, cp, 3)) != MSKF_OK) return rc;
+    }
     const int ts1 = mskf_t_begin(ctx, MSKF_K_LK);
     fe_launch_track(ctx->desc[1].d, n, max_prev, st);
     crumb(ctx, 4);
@@ -906,7 +951,7 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
     fe_launch_book(ctx->book_desc.d, n, 1, scratch_bytes, st);
     crumb(ctx, 7);
     mskf_t_end(ctx, tb, n);
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->book_out.h, ctx->book_out.d, out_bytes, hipMemcpyDeviceToHost, st));
+    { const MskfCopy cp = {ctx->book_out.h, ctx->book_out.d, out_bytes}; if ((rc = mskf_copy_async(ctx, &cp, 1)) != MSKF_OK) return rc; }
     crumb(ctx, 8);
     MSKF_HIPCHK(hipGetLastError());
     if ((rc = mskf_wait_event(ctx, &ctx->pend_frame.done, true)) != MSKF_OK) return rc;

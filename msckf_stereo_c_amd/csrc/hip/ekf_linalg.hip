@@ -399,6 +399,183 @@ __device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gr
     if (tid == 0) S.rows_out[3] = diag | 1;
 }
 
+// ------------------------------------------------------------------------------------ Householder TSQR, row block in registers
+// k_ekf_tsqr: the compression of the streams whose mode asks for the Householder path (compression_mode 2 / 3), a kernel of its
+// own since the second half of round 4.  The row-block TSQR above (tsqr_wide) lives inside the factorisation kernels and keeps
+// R and the row block in LDS: with mode 3 as the default EVERY update took that path, 192 workgroups of 150 KiB of LDS each for
+// ~1 ms, twice per update - a CU with one of them takes no workgroup of any kernel that uses LDS (every front-end kernel does),
+// and a 150 KiB request itself waits until a CU has drained completely: the front-end launches were starved for milliseconds
+// (k_fe_book 20 ms, k_track4 11 ms per launch in the worst run), the rate of the default bench fell from ~100 k to 45-90 k
+// frames/s from run to run.  The kernel was bound by LDS traffic (every element of the block read and written once per
+// reflector), not by arithmetic.  Here
+//   * a column of the block belongs to a DPP quad, lane q of the quad holding rows [q RL, (q + 1) RL) of it IN REGISTERS, a quad
+//     owning the columns g, g + 128, .. (NC of them): a block is 4 RL = 128 rows (64 for the wide windows), so the dependent
+//     chain of reflector steps is 2.7 x shorter than with 48-row blocks;
+//   * R lives in the stream's W buffer in global memory (L2): per step a quad touches one element per column it owns, read two
+//     steps ahead of its use;
+//   * LDS holds two copies of one reflector (1 KiB each): the quad that owns column k + 1 applies reflector k to that column
+//     first, forms reflector k + 1 at once and publishes it in the other copy while the rest of the workgroup is still applying
+//     reflector k - one barrier per step.
+// No LDS to speak of, so the launch shares its CUs with whatever else is running.  Arithmetic: explicit fused multiply-adds
+// (this is a factorisation, not one of the decision-bearing sequences of DESIGN section 3); same skipping rule for annihilated
+// columns as tsqr_wide.
+#define TQ_THREADS 512
+// sum over the four DPP rows of a wavefront (lanes c, c + 16, c + 32, c + 48): every one of the four gets the same bits
+__device__ __forceinline__ double tq_rows_sum(double v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+// acc += x[lane C of this lane's DPP row] * a in ONE instruction (DP-ALU DPP, row_newbcast only).  Every lane of the wavefront must
+// be active: a source lane that EXEC disables counts as invalid and the lanes that read it would skip the operation.
+template <int C, bool FIRST> __device__ __forceinline__ void tq_fmac_bcast(double &acc, double x, double a) {
+    // (FIRST: the wait states a DPP operation needs after a VALU write of EXEC - the compiler does not see a DPP instruction here)
+    if (FIRST) asm("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(a), "n"(C));
+    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(a), "n"(C));
+}
+template <int RL, int I = 0> struct TqDot {
+    static __device__ __forceinline__ void run(double (&p)[4], const double (&vr)[RL / 16], const double (&bc)[RL]) {
+        tq_fmac_bcast<I % 16, I == 0>(p[I & 3], vr[I / 16], bc[I]);
+        TqDot<RL, I + 1>::run(p, vr, bc);
+    }
+};
+template <int RL> struct TqDot<RL, RL> { static __device__ __forceinline__ void run(double (&)[4], const double (&)[RL / 16], const double (&)[RL]) {} };
+template <int RL, int I = 0> struct TqAxpy {
+    static __device__ __forceinline__ void run(double (&bc)[RL], const double (&vr)[RL / 16], double ntt) {
+        tq_fmac_bcast<I % 16, I == 0>(bc[I], vr[I / 16], ntt);
+        TqAxpy<RL, I + 1>::run(bc, vr, ntt);
+    }
+};
+template <int RL> struct TqAxpy<RL, RL> { static __device__ __forceinline__ void run(double (&)[RL], const double (&)[RL / 16], double) {} };
+// the four lanes that hold column k (one per DPP row, rows [r RL, (r + 1) RL) of the block each) form reflector k and publish it
+template <int RL>
+__device__ __forceinline__ void tq_form_reflector(const double (&bc)[RL], double x0, double *sVs, int *sFlag_s, double *Rkk, int r) {
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RL; i += 4) { p0 = __builtin_fma(bc[i], bc[i], p0); p1 = __builtin_fma(bc[i + 1], bc[i + 1], p1); p2 = __builtin_fma(bc[i + 2], bc[i + 2], p2); p3 = __builtin_fma(bc[i + 3], bc[i + 3], p3); }
+    const double ss = tq_rows_sum((p0 + p1) + (p2 + p3));
+    const bool skip = ss < 1e-200 || ss < 1e-40 * (x0 * x0);           // (see tsqr_wide)
+    if (!skip) {
+        const double nrm = sqrt(__builtin_fma(x0, x0, ss));
+        const double alpha = x0 > 0.0 ? -nrm : nrm;
+        const double v0 = x0 - alpha;
+        const double beta = 2.0 / __builtin_fma(v0, v0, ss);
+#pragma unroll
+        for (int i = 0; i < RL; i += 2) *reinterpret_cast<double2 *>(sVs + r * RL + i) = make_double2(bc[i], bc[i + 1]);
+        if (r == 0) { sVs[4 * RL] = v0; sVs[4 * RL + 1] = beta; *Rkk = alpha; }
+    }
+    if (r == 0) *sFlag_s = skip ? 0 : 1;
+}
+// Lane (r, c) of wavefront w (r = DPP row 0..3, c = lane of the row): rows [r RL, (r + 1) RL) of the block, columns 16 w + c + 128 t.
+template <int RL, int NC>
+__device__ __forceinline__ void tsqr_regs(const EkfStreamDev &S, int na, int K, double *Rg, double *sV, int *sFlag) {
+    static_assert(RL % 16 == 0, "a DPP row holds the reflector's entries of its rows, 16 per register");
+    constexpr int BR = 4 * RL, NW = TQ_THREADS / 64, SLAB = 16 * NW, VS = BR + 2, VR = RL / 16;
+    const int n1 = na + 1, d = S.d, ld = S.ld;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int col[NC], clone[NC];
+    bool has[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+        const int j = 16 * wave + c + SLAB * t;
+        has[t] = j < n1;
+        col[t] = j < na ? S.act[j] : d;
+        clone[t] = j < na ? (col[t] - EKF_IMU_DIM) / 6 : -1;
+    }
+    for (int e = tid; e < n1 * n1; e += TQ_THREADS) { const int k = e / n1, j = e - k * n1; if (j >= k) Rg[(size_t)k * ld + j] = 0.0; }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += BR) {
+        double b[NC][RL];
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            const int gk = k0 + r * RL + i;
+            const unsigned long long rm = gk < K ? S.rowmask[gk] : 0ULL;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const bool on = has[t] && (clone[t] < 0 ? rm != 0ULL : ((rm >> clone[t]) & 1ULL) != 0ULL);
+                b[t][i] = on ? S.Hs[(size_t)gk * ld + col[t]] : 0.0;
+            }
+        }
+        // R at this lane's columns: row k (ra) and row k + 1 (rb) at the top of step k, row k + 2 requested during the step
+        double ra[NC], rb[NC], rc[NC];
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            const int j = 16 * wave + c + SLAB * t;
+            ra[t] = has[t] ? Rg[j] : 0.0;
+            rb[t] = has[t] && n1 > 1 ? Rg[(size_t)ld + j] : 0.0;
+        }
+        if (wave == 0 && c == 0) tq_form_reflector<RL>(b[0], ra[0], sV, sFlag, Rg, r);      // reflector 0
+        __syncthreads();
+        for (int k = 0; k < n1; ++k) {
+            const int s = k & 1;
+            const double *vs = sV + s * VS;
+            const bool live = __builtin_amdgcn_readfirstlane(sFlag[s]) != 0;       // (uniform: the whole workgroup reads the same word)
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int j = 16 * wave + c + SLAB * t; rc[t] = (has[t] && k + 2 < n1) ? Rg[(size_t)(k + 2) * ld + j] : 0.0; }
+            double vr[VR];
+            double v0 = 0.0, beta = 0.0;
+#pragma unroll
+            for (int m = 0; m < VR; ++m) vr[m] = 0.0;
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < VR; ++m) vr[m] = vs[r * RL + 16 * m + c];
+                v0 = vs[BR]; beta = vs[BR + 1];
+            }
+            // reflector k onto the 16 columns of slab t of this wavefront (all 64 lanes: the DPP broadcasts need their source lanes)
+            auto apply = [&](double (&bc)[RL], double rkj, int j, bool on) {
+                double p[4] = {0.0, 0.0, 0.0, 0.0};
+                TqDot<RL>::run(p, vr, bc);
+                const double dot = tq_rows_sum((p[0] + p[1]) + (p[2] + p[3]));
+                const double tt = on ? beta * __builtin_fma(v0, rkj, dot) : 0.0;
+                TqAxpy<RL>::run(bc, vr, -tt);
+                if (on && r == 0) Rg[(size_t)k * ld + j] = __builtin_fma(-tt, v0, rkj);
+            };
+            // the wavefront that holds column k + 1 takes that slab first, forms reflector k + 1 at once and publishes it in the
+            // other copy while the rest of the workgroup is still applying reflector k
+            const int k1 = k + 1;
+            const int w1 = (k1 & (SLAB - 1)) >> 4, c1 = k1 & 15, t1 = k1 / SLAB;
+            const bool own_wave = k1 < n1 && wave == w1;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                if (own_wave && t1 == t) {
+                    const int j = 16 * wave + c + SLAB * t;
+                    if (live) apply(b[t], ra[t], j, has[t] && j > k);
+                    if (c == c1) tq_form_reflector<RL>(b[t], rb[t], sV + (s ^ 1) * VS, sFlag + (s ^ 1), Rg + (size_t)k1 * ld + k1, r);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const int j0 = 16 * wave + SLAB * t;                // first column of the slab: all of it done (<= k) or beyond n1 -> nothing to do
+                    if (!(own_wave && t1 == t) && j0 + 15 > k && j0 < n1) apply(b[t], ra[t], j0 + c, has[t] && j0 + c > k);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { ra[t] = rb[t]; rb[t] = rc[t]; }
+            __syncthreads();
+        }
+    }
+}
+template <int RL, int NC, int WPE>
+__global__ __launch_bounds__(TQ_THREADS, WPE) void k_ekf_tsqr(const EkfStreamDev *streams) {
+    const EkfStreamDev &S = streams[blockIdx.y];
+    if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
+    if (!ekf_mode_householder(S.qr_mode)) return;                 // the Gram route's streams: k_ekf_chol_lds / k_ekf_chol (which = 0)
+    __shared__ int s_w[TQ_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) double sV[2 * (4 * RL + 2)];
+    __shared__ int sFlag[2];
+    if (ekf_compress_entry(S, s_w) != 2) return;                  // nothing active, or the stack is used uncompressed (all set up)
+    const int na = S.rows_out[2], K = S.rows_out[1], d = S.d, ld = S.ld;
+    const int tid = threadIdx.x;
+    if (na + 1 > (TQ_THREADS / 4) * NC) { if (tid == 0) S.rows_out[3] = 0x80; return; }      // (cannot happen: the launcher picks NC from the window)
+    double *Rg = S.W;
+    tsqr_regs<RL, NC>(S, na, K, Rg, sV, sFlag);
+    // hand over in the layout the update expects: S.S = L = R^T (lower, ld-wide rows), column d of T = Q^T r
+    for (int e = tid; e < na * na; e += TQ_THREADS) {
+        const int i = e / na, j = e - i * na;
+        if (j <= i) S.S[(size_t)i * ld + j] = Rg[(size_t)j * ld + i];
+    }
+    for (int k = tid; k < na; k += TQ_THREADS) S.T[(size_t)k * ld + d] = Rg[(size_t)k * ld + na];
+    if (tid == 0) S.rows_out[3] = 1;
+}
+
 // ------------------------------------------------------------------------------------ Cholesky
 // Fallback for active blocks that do not fit LDS (more than CHOL_LDS_MAX_ROWS rows: 50- and 60-clone windows): the same
 // blocked factorisation (chol_block.h) run in place on the row-major global matrix through a generic pointer — diagonal
@@ -411,7 +588,11 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
     __shared__ int s_w[CHOLG_THREADS / 64];
-    if (which == 0) { entry = ekf_compress_entry(S, s_w); if (entry == 1) return; }
+    if (which == 0) {
+        if (ekf_mode_householder(S.qr_mode)) return;      // compressed by k_ekf_tsqr (launched beside this kernel when the batch has such streams)
+        entry = ekf_compress_entry(S, s_w);
+        if (entry == 1) return;
+    }
     const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
     const int nt = n + (which == 0 ? 1 : 0);              // + the extra Q^T r row of the Gram factorisation
     const int lda = S.ld;
@@ -423,11 +604,6 @@ __global__ __launch_bounds__(CHOLG_THREADS) void k_ekf_chol(const EkfStreamDev *
     __shared__ CholBlockShared s_cb;
     const int tid = threadIdx.x;
     if (tid == 0) s_diag = 0;
-    if (entry == 2) {   // no Gram matrix: Householder TSQR, R in the stream's W buffer (ld-wide rows), the row block in the panel's space
-        double *Rg = S.W;
-        ekf_compress_exit(S, false, 0, [=](int k, int j) -> double & { return Rg[(size_t)k * lda + j]; }, sPanT, LNB * pan_rs);
-        return;
-    }
     for (int e = tid; e < LNB * pan_rs; e += CHOLG_THREADS) sPanT[e] = 0.0;
     if (which == 0) {
         // regularised factorisation G + lambda I, lambda = 1e-14 d max(diag G) (see k_ekf_chol_lds)
@@ -498,7 +674,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     int entry = 0;
     __shared__ int s_w[CHOL_WAVES];
-    if (which == 0) { entry = ekf_compress_entry(S, s_w); if (entry == 1) return; }
+    if (which == 0) {
+        if (ekf_mode_householder(S.qr_mode)) return;      // compressed by k_ekf_tsqr (launched beside this kernel when the batch has such streams)
+        entry = ekf_compress_entry(S, s_w);
+        if (entry == 1) return;
+    }
     double *A = which == 0 ? S.S : S.W;
     const int off = 0, lda = S.ld;                 // compact storage: index i <-> column act[i]
     const int n = which == 0 ? S.rows_out[2] : S.rows_out[4];   // active columns (Gram) / rows of the compressed measurement (S)
@@ -515,7 +695,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ekf_chol_lds(const EkfStreamDe
     // R of the TSQR lives where the packed factor does (packed upper by rows: the same n1 (n1 + 1) / 2 doubles), the row block in the panel's space
     auto Rl = [=](int k, int j) -> double & { return sM[k * nt - k * (k - 1) / 2 + (j - k)]; };
     const int room = lds_doubles - nt * (nt + 1) / 2;       // what the launch's LDS leaves beside the packed factor / the resident R: the TSQR's row block
-    if (entry == 2) { ekf_compress_exit(S, false, 0, Rl, sPanT, room); return; }
     // load: one matrix row per wave pass, coalesced along j
     // (8 rows x 3 column chunks = up to 24 loads in flight per lane: the copy is latency bound otherwise)
     for (int i0 = wave * 8; i0 < nt; i0 += CHOL_WAVES * 8) {
@@ -887,6 +1066,16 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
         case GM_S2:   hipLaunchKernelGGL(k_ekf_gemm<GM_S2>, grid, dim3(256), 0, st, d); break;
         default:      hipLaunchKernelGGL(k_ekf_gemm<GM_PUPD>, grid, dim3(256), 0, st, d); break;
     }
+}
+// Householder compression of the streams in compression_mode 2 / 3 (the others leave at once)
+void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
+    const int n1 = max_d - EKF_IMU_DIM + 1;
+    static const int variant = [] { const char *e = std::getenv("MSKF_TQ_VARIANT"); return e ? std::atoi(e) : 0; }();      // EXPERIMENT
+    if (n1 <= 2 * (TQ_THREADS / 4)) {
+        if (variant == 1) hipLaunchKernelGGL((k_ekf_tsqr<16, 2, 4>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
+        else hipLaunchKernelGGL((k_ekf_tsqr<32, 2, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
+    }
+    else hipLaunchKernelGGL((k_ekf_tsqr<16, 4, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
     const int nt = max_d - EKF_IMU_DIM + 1;

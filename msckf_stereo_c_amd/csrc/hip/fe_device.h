@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include "../../../include/mskf_types.h"
 
+#define MSKF_COPY_SEGS 6        // segments of one staging-copy launch (k_mskf_copy)
+
 #define MSKF_LEVELS 4
 
 // One image pyramid resident in HBM: level l is a dense row-major u8 plane, pitch == width.

@@ -1133,6 +1133,41 @@ extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hi
     hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, st, flag, seq);
 }
 
+// Staging copies as a kernel of the stream itself (pinned host memory <-> device memory, both addressable from a kernel).
+// hipMemcpyAsync hands such copies to the SDMA engines: a second kind of queue, shared by every stream of the process, with a
+// cross-queue signal either side of each copy.  With sixteen busy streams the copies of all of them convoy behind whichever
+// copy is waiting for its own stream's kernel, and now and then (one bench run in ten to twenty, round 4) every stream's next
+// copy stood still for seconds up to a minute: every queue of the pipeline was found waiting in front of a staging copy.
+// One launch moves up to MSKF_COPY_SEGS segments; 16-byte accesses (the arenas are 64-byte aligned), the odd bytes at the
+// end of a segment one by one.
+struct MskfCopySegs { void *dst[MSKF_COPY_SEGS]; const void *src[MSKF_COPY_SEGS]; unsigned long long bytes[MSKF_COPY_SEGS]; int blocks_per_seg; };
+__global__ __launch_bounds__(256) void k_mskf_copy(MskfCopySegs segs) {
+    const int seg = (int)blockIdx.x / segs.blocks_per_seg, b = (int)blockIdx.x - seg * segs.blocks_per_seg;
+    const unsigned long long bytes = segs.bytes[seg], n16 = bytes >> 4;
+    const uint4 *__restrict__ src = (const uint4 *)segs.src[seg];
+    uint4 *__restrict__ dst = (uint4 *)segs.dst[seg];
+    const unsigned long long stride = (unsigned long long)segs.blocks_per_seg * 256ULL;
+    unsigned long long i = (unsigned long long)b * 256ULL + threadIdx.x;
+    for (; i + 3ULL * stride < n16; i += 4ULL * stride) {          // four loads in flight per lane (the source may sit across PCIe)
+        const uint4 a0 = src[i], a1 = src[i + stride], a2 = src[i + 2ULL * stride], a3 = src[i + 3ULL * stride];
+        dst[i] = a0; dst[i + stride] = a1; dst[i + 2ULL * stride] = a2; dst[i + 3ULL * stride] = a3;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+    if (b == 0 && threadIdx.x < (unsigned)(bytes & 15ULL)) ((uint8_t *)dst)[(n16 << 4) + threadIdx.x] = ((const uint8_t *)src)[(n16 << 4) + threadIdx.x];
+}
+extern "C" void fe_launch_copy(void *const *dst, const void *const *src, const size_t *bytes, int n_segs, hipStream_t st) {
+    MskfCopySegs segs;
+    size_t mx = 0;
+    for (int i = 0; i < MSKF_COPY_SEGS; ++i) {
+        segs.dst[i] = i < n_segs ? dst[i] : nullptr; segs.src[i] = i < n_segs ? src[i] : nullptr; segs.bytes[i] = i < n_segs ? bytes[i] : 0ULL;
+        if (i < n_segs && bytes[i] > mx) mx = bytes[i];
+    }
+    if (n_segs <= 0 || mx == 0) return;
+    size_t bps = (mx + 16383) / 16384;                  // 16 KiB per workgroup and sweep
+    segs.blocks_per_seg = (int)(bps < 1 ? 1 : bps > 96 ? 96 : bps);
+    hipLaunchKernelGGL(k_mskf_copy, dim3(segs.blocks_per_seg * n_segs), dim3(256), 0, st, segs);
+}
+
 extern "C" void fe_launch_track(const FeStreamDev *streams_dev, int n_streams, int max_pts, hipStream_t st) {
     if (max_pts <= 0) return;
     const int gps = (max_pts + 3) / 4;

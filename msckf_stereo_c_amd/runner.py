@@ -191,7 +191,7 @@ class Runner:
             self.L.mskfh_runner_keep_trajectory_stream(self.h, int(stream), int(keep))
 
     KERNELS = ["k_pyr_down", "k_detect_cells", "k_track4", "k_ekf_propagate", "k_ekf_augment", "k_ekf_feature_blocks",
-               "k_ekf_cap", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_small", "k_ekf_remove_clone", "k_pt_geom", "k_fe_book"]
+               "k_ekf_tsqr", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_small", "k_ekf_remove_clone", "k_pt_geom", "k_fe_book"]
 
     def set_timing(self, enable):
         self.L.mskfh_runner_set_timing(self.h, int(enable))
