@@ -327,9 +327,7 @@ extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *
     ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_PROPAGATE);
-        mskf_crumb(ctx, 10);
         ekf_launch_propagate((const EkfStreamDev *)dv, n, st);
-        mskf_crumb(ctx, 11);
         mskf_t_end(ctx, ts, n);
     }
     MSKF_HIPCHK(hipGetLastError());
@@ -448,9 +446,7 @@ extern "C" int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *c
     ctx->pred_pending = true;
     {
         const int ts = mskf_t_begin(ctx, MSKF_K_EKF_REMOVE);
-        mskf_crumb(ctx, 12);
         ekf_launch_remove_clone((const EkfStreamDev *)ctx->pred_arena.d, n, st);
-        mskf_crumb(ctx, 13);
         mskf_t_end(ctx, ts, n);
     }
     MSKF_HIPCHK(hipGetLastError());
@@ -580,7 +576,6 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             const int cap = std::min(kMaxRows, std::max(2048, m_total + m_total / 2));
             const size_t bytes = ((size_t)cap * E.ld + (size_t)cap) * sizeof(double);
             double *grown = nullptr;
-            MskfDiagScope diag("Hs growth (hipMallocAsync + memset + hipFreeAsync)");
             MSKF_HIPCHK(hipMallocAsync((void **)&grown, bytes, st));
             if (hipMemsetAsync(grown, 0, bytes, st) != hipSuccess) { (void)hipFreeAsync(grown, st); mskf_set_error("hipMemsetAsync of the grown stacked-Jacobian buffer failed"); return MSKF_ERR_HIP; }
             if (E.Hs) { if (E.hs_async) (void)hipFreeAsync(E.Hs, st); else extra_of(s)->retired_hs.push_back(E.Hs); }      // (rs lives behind Hs in the same allocation)
@@ -618,7 +613,6 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
     const size_t work_off = in_bytes;
     in_bytes = align_up(in_bytes + sizeof(int) * (size_t)(n_work[0] + n_work[1] + n_work[2]), 64);
     if (in_bytes > ctx->upd_in.cap || out_bytes > ctx->upd_out.cap) {
-        MskfDiagScope diag("update arenas grow (stream synchronise)");
         MSKF_HIPCHK(hipStreamSynchronize(st));
         if ((rc = ctx->upd_in.ensure(in_bytes)) != MSKF_OK) return rc;
         if ((rc = ctx->upd_out.ensure(out_bytes)) != MSKF_OK) return rc;
@@ -681,15 +675,12 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             if ((rc = mskf_copy_async(ctx, cp, 2)) != MSKF_OK) return rc;
         }
         int ts = mskf_t_begin(ctx, MSKF_K_EKF_FEATURES);
-        mskf_crumb(ctx, 20);
         if (any_pairs) ekf_launch_pair_features(ctx->ekf_desc.d, n, max_feat_pairs, max_tri, st);      // the pruning update
-        mskf_crumb(ctx, 21);
         if (n_work[0] + n_work[1] + n_work[2] > 0) {
             const int *w0 = (const int *)(din + work_off);
             ekf_launch_features(ctx->ekf_desc.d, w0, n_work[0], w0 + n_work[0], n_work[1], w0 + n_work[0] + n_work[1], n_work[2], max_frows,
                                 max_frows_cls[1], max_clones_cfg, st);
         }
-        mskf_crumb(ctx, 22);
         mskf_t_end(ctx, ts, (long long)fl_feat);
         // (which blocks are stacked - the 1500-row cap of :1002-1010 - is worked out by the first dense kernel of each route
         //  itself: ekf_cap.h; rounds 1-3 ran it as a launch of its own here)
@@ -700,7 +691,6 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             // compression, gain and Y in one launch (k_ekf_small_update); the other streams leave it at once
             ts = mskf_t_begin(ctx, MSKF_K_EKF_SMALL);
             ekf_launch_small_update(ctx->ekf_desc.d, n, max_d, st);
-            mskf_crumb(ctx, 23);
             mskf_t_end(ctx, ts, any_general ? 0 : (long long)(fl_qr + fl_upd));
         }
         if (any_general) {
@@ -708,7 +698,6 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
             // streams that need it), then the Kalman update (ekf_linalg.hip); small-route streams leave these at once
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
-            mskf_crumb(ctx, 24);
             mskf_t_end(ctx, ts, (long long)fl_qr);
             if (any_householder) {
                 // Householder TSQR of the streams in compression_mode 2 / 3 (a kernel without LDS of its own: ekf_linalg.hip)
@@ -721,34 +710,27 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
                 ekf_launch_chol(ctx->ekf_desc.d, n, 0, max_d, st);
                 mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
             }
-            mskf_crumb(ctx, 25);
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_T, max_d, st);
-            mskf_crumb(ctx, 26);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
             ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
             ekf_launch_gemm(ctx->ekf_desc.d, n, GM_S2, max_d, st);
-            mskf_crumb(ctx, 27);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
             ts = mskf_t_begin(ctx, MSKF_K_EKF_CHOL);
             ekf_launch_chol(ctx->ekf_desc.d, n, 1, max_d, st);
-            mskf_crumb(ctx, 28);
             mskf_t_end(ctx, ts, (long long)(d3 / 3.0));
             ts = mskf_t_begin(ctx, MSKF_K_EKF_TRSM);
             ekf_launch_trsm(ctx->ekf_desc.d, n, max_d, st);
-            mskf_crumb(ctx, 29);
             mskf_t_end(ctx, ts, (long long)(2.0 * d3));
         }
         // P <- P - Y^T Y and delta_x = Y^T w for every stream, whichever route produced Y
         ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
         ekf_launch_gemm(ctx->ekf_desc.d, n, GM_PUPD, max_d, st);
-        mskf_crumb(ctx, 30);
         mskf_t_end(ctx, ts, any_general ? (long long)(4.0 * d3) : 0);
         if (any_pv_nofeat) ekf_launch_posvar_upd(ctx->ekf_desc.d, n, st);       // (streams with features get theirs from the downdate's epilogue)
         (void)max_m;
         MSKF_HIPCHK(hipGetLastError());
         { const MskfCopy cp = {hout, dout, out_bytes}; if ((rc = mskf_copy_async(ctx, &cp, 1)) != MSKF_OK) return rc; }
-        mskf_crumb(ctx, 31);
         if ((rc = mskf_wait_event(ctx, &ctx->pend_upd.done, true)) != MSKF_OK) return rc;
     }
     {

@@ -82,37 +82,6 @@ extern "C" void mskf_ctx_destroy(mskf_ctx *c) {
 extern "C" void fe_launch_mark(volatile unsigned int *flag, unsigned int seq, hipStream_t st);
 extern "C" size_t fe_book_lds_budget(void);
 
-// TEMPORARY DIAGNOSTIC: stage marks of a context's command stream in pinned host memory (MSKF_FE_CRUMBS=1), dumped for
-// every context when a wait runs into its time limit
-static std::mutex g_crumb_mu;
-static std::vector<std::pair<mskf_ctx *, unsigned int *>> g_crumb_tab;
-static volatile unsigned int *crumb_word(mskf_ctx *ctx) {
-    static const bool on = [] { const char *e = std::getenv("MSKF_FE_CRUMBS"); return e && e[0] == '1'; }();
-    if (!on) return nullptr;
-    std::lock_guard<std::mutex> lk(g_crumb_mu);
-    for (auto &t : g_crumb_tab) if (t.first == ctx) return t.second;
-    unsigned int *p = nullptr;
-    if (hipHostMalloc((void **)&p, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return nullptr;
-    p[0] = 0; p[1] = 0;
-    g_crumb_tab.push_back({ctx, p});
-    return p;
-}
-void mskf_crumb(mskf_ctx *ctx, unsigned int v) {
-    volatile unsigned int *w = crumb_word(ctx);
-    if (w) { ((unsigned int *)w)[1] = v; (void)hipStreamWriteValue32(ctx->stream, (void *)w, v, 0); }
-}
-static void crumb(mskf_ctx *ctx, unsigned int v) { mskf_crumb(ctx, v); }
-static void crumb_dump(mskf_ctx *who) {
-    static std::atomic<int> dumps{0};
-    if (dumps.fetch_add(1) > 0) return;
-    std::lock_guard<std::mutex> lk(g_crumb_mu);
-    for (auto &t : g_crumb_tab) {
-        const hipError_t e = hipStreamQuery(t.first->stream);
-        std::fprintf(stderr, "crumbs: ctx %p%s stream %p query=%d executed=%u enqueued=%u\n", (void *)t.first, t.first == who ? " (the waiter)" : "", (void *)t.first->stream, (int)e, t.second[0], t.second[1]);
-    }
-    std::fflush(stderr);
-}
-
 extern "C" void fe_launch_copy(void *const *dst, const void *const *src, const size_t *bytes, int n_segs, hipStream_t st);
 int mskf_copy_async(mskf_ctx *c, const MskfCopy *segs, int n) {
     static const bool sdma = [] { const char *e = std::getenv("MSKF_SDMA_COPIES"); return e && e[0] == '1'; }();
@@ -195,18 +164,10 @@ int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record) {
         if (check) {                                             // about every 10 ms
             const auto now = std::chrono::steady_clock::now();
             if (!timing) { t0 = now; timing = true; }
-            else if (MskfDiagScope::enabled() && std::chrono::duration<double>(now - t0).count() > 1.0) {
-                static std::atomic<int> slow{0};
-                if (slow.fetch_add(1) == 0) {
-                    std::fprintf(stderr, "mskf diag [%.3f s] a wait of ctx %p is longer than 1 s (mark %u wanted %u)\n", std::chrono::duration<double>(now.time_since_epoch()).count(), (void *)c, *w, want);
-                    crumb_dump(c);
-                }
-            }
             else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
                 const hipError_t e = hipStreamQuery(c->stream);
                 mskf_set_error(e != hipSuccess && e != hipErrorNotReady ? hipGetErrorString(e) : "completion mark not written within the wait limit");
                 std::fprintf(stderr, "mskf_wait_event: ctx %p slot %d mark %u wanted %u, stream query %d\n", (void *)c, k, *w, want, (int)e);
-                crumb_dump(c);
                 return MSKF_ERR_HIP;
             }
         }
@@ -571,9 +532,7 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
         const MskfCopy cp[2] = {{ctx->jobs.d, ctx->jobs.h, sizeof(Pyr3Job) * 2 * (size_t)n}, {ctx->desc[0].d, ctx->desc[0].h, sizeof(FeStreamDev) * (size_t)n}};
         if ((rc = mskf_copy_async(ctx, cp, 2)) != MSKF_OK) return rc;
         const int ts = mskf_t_begin(ctx, MSKF_K_PYR);
-        crumb(ctx, 1);
         fe_launch_pyr_down3(ctx->jobs.d, 2 * n, max_w, max_h, st);
-        crumb(ctx, 2);
         mskf_t_end(ctx, ts, px);          // units: output pixels of the three levels
     }
     // detector per-cell maxima on cam0 level 0
@@ -589,11 +548,10 @@ static int push_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const u
         for (int i = 0; i < n; ++i) px += (long long)streams[i]->w * streams[i]->h;
         const int ts = mskf_t_begin(ctx, MSKF_K_DETECT);
         fe_launch_detect(ctx->desc[0].d, n, max_w, max_h, gen, st);
-        crumb(ctx, 3);
         mskf_t_end(ctx, ts, px);
     }
     if (copy_cells) {
-        MSKF_HIPCHK(hipMemcpyAsync(ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes, hipMemcpyDeviceToHost, st));
+        { const MskfCopy cp = {ctx->cell_arena.h, ctx->cell_arena.d, cell_bytes}; const int crc = mskf_copy_async(ctx, &cp, 1); if (crc != MSKF_OK) return crc; }
         { const int erc = mskf_wait_event(ctx, &ctx->cell_ev, true); if (erc != MSKF_OK) return erc; }
     }
     MSKF_HIPCHK(hipGetLastError());
@@ -745,13 +703,15 @@ extern "C" int mskf_fe_track_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
         d.out0 = (mskf_point2f *)o; d.out1 = d.out0 + np; d.und0 = d.out1 + np; d.und1 = d.und0 + np;
         d.status = (uint8_t *)(d.und1 + np);
     }
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_in.d, ctx->trk_in.h, in_bytes, hipMemcpyHostToDevice, st));
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    {
+        const MskfCopy cp[2] = {{ctx->trk_in.d, ctx->trk_in.h, in_bytes}, {ctx->desc[1].d, ctx->desc[1].h, sizeof(FeStreamDev) * (size_t)n}};
+        if ((rc = mskf_copy_async(ctx, cp, 2)) != MSKF_OK) return rc;
+    }
     // temporal track -> bounds gate + stereo guess -> stereo track -> gates + undistortion: one launch (k_track4)
     const int ts = mskf_t_begin(ctx, MSKF_K_LK);
     fe_launch_track(ctx->desc[1].d, n, max_pts, st);
     mskf_t_end(ctx, ts, 0);
-    MSKF_HIPCHK(hipMemcpyAsync(ctx->trk_out.h, ctx->trk_out.d, out_bytes, hipMemcpyDeviceToHost, st));
+    { const MskfCopy cp = {ctx->trk_out.h, ctx->trk_out.d, out_bytes}; if ((rc = mskf_copy_async(ctx, &cp, 1)) != MSKF_OK) return rc; }
     MSKF_HIPCHK(hipGetLastError());
     if ((rc = mskf_wait_event(ctx, &ctx->pend_trk.done, true)) != MSKF_OK) return rc;
     ctx->pend_trk.active = true; ctx->pend_trk.n = n; ctx->pend_trk.args = args;
@@ -937,22 +897,17 @@ extern "C" int mskf_fe_frame_batch_begin(mskf_ctx *ctx, int n, mskf_stream *cons
     }
     const int ts1 = mskf_t_begin(ctx, MSKF_K_LK);
     fe_launch_track(ctx->desc[1].d, n, max_prev, st);
-    crumb(ctx, 4);
     mskf_t_end(ctx, ts1, 0);
     int tb = mskf_t_begin(ctx, MSKF_K_FE_BOOK);
     fe_launch_book(ctx->book_desc.d, n, 0, scratch_bytes, st);
-    crumb(ctx, 5);
     mskf_t_end(ctx, tb, n);
     const int ts2 = mskf_t_begin(ctx, MSKF_K_LK);
     fe_launch_track(ctx->desc[2].d, n, std::max(max_cand_est, 4), st);
-    crumb(ctx, 6);
     mskf_t_end(ctx, ts2, 0);
     tb = mskf_t_begin(ctx, MSKF_K_FE_BOOK);
     fe_launch_book(ctx->book_desc.d, n, 1, scratch_bytes, st);
-    crumb(ctx, 7);
     mskf_t_end(ctx, tb, n);
     { const MskfCopy cp = {ctx->book_out.h, ctx->book_out.d, out_bytes}; if ((rc = mskf_copy_async(ctx, &cp, 1)) != MSKF_OK) return rc; }
-    crumb(ctx, 8);
     MSKF_HIPCHK(hipGetLastError());
     if ((rc = mskf_wait_event(ctx, &ctx->pend_frame.done, true)) != MSKF_OK) return rc;
     // state rotation (:192-200): the grid just built is the next frame's previous grid, curr cam0 becomes prev cam0
@@ -975,10 +930,7 @@ extern "C" int mskf_fe_frame_batch_end(mskf_ctx *ctx) {
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     F.active = false;
     int rc;
-    if ((rc = mskf_wait_event(ctx, &F.done, false)) != MSKF_OK) {
-        if (volatile unsigned int *w = crumb_word(ctx)) std::fprintf(stderr, "mskf_fe_frame_batch_end: wait failed, last stage mark of this context = %u (1 before pyramid, 2 pyramid, 3 detector, 4 track1, 5 book1, 6 track2, 7 book2, 8 copy)\n", *w);
-        return rc;
-    }
+    if ((rc = mskf_wait_event(ctx, &F.done, false)) != MSKF_OK) return rc;
     const auto t_h1 = std::chrono::steady_clock::now();
     long long tracks1 = 0, tracks2 = 0;
     bool overflow = false;

@@ -33,21 +33,6 @@ void mskf_set_error(const std::string &s);
         }                                                                                            \
     } while (0)
 
-// TEMPORARY DIAGNOSTIC (MSKF_FE_CRUMBS=1): rare runtime calls inside a running pipeline (allocations, stream synchronisations),
-// logged with their duration and the wall-clock time
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-struct MskfDiagScope {
-    const char *what; std::chrono::steady_clock::time_point t0; bool on;
-    static bool enabled() { static const bool e = [] { const char *v = std::getenv("MSKF_FE_CRUMBS"); return v && v[0] == '1'; }(); return e; }
-    explicit MskfDiagScope(const char *w) : what(w), on(enabled()) { if (on) t0 = std::chrono::steady_clock::now(); }
-    ~MskfDiagScope() {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "mskf diag [%.3f s] %s took %.3f ms\n", std::chrono::duration<double>(t1.time_since_epoch()).count(), what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    }
-};
 template <typename T>
 struct PinnedDev {  // a pinned host array with a device twin
     T *h = nullptr, *d = nullptr;
@@ -58,7 +43,6 @@ struct PinnedDev {  // a pinned host array with a device twin
     // The outgrown pair is retired and freed by release(); with doubling that is at most as much again as the final size.
     int ensure(size_t n) {
         if (n <= cap) return MSKF_OK;
-        MskfDiagScope diag("PinnedDev::ensure (hipHostMalloc + hipMalloc)");
         if (h || d) retired.push_back({h, d});
         h = d = nullptr; cap = 0;
         size_t c = n < 16 ? 16 : 2 * n;
@@ -141,7 +125,6 @@ struct mskf_ctx {
 struct MskfCopy { void *dst; const void *src; size_t bytes; };
 int mskf_copy_async(mskf_ctx *c, const MskfCopy *segs, int n);
 int mskf_wait_event(mskf_ctx *c, hipEvent_t *ev_slot, bool record);
-void mskf_crumb(mskf_ctx *ctx, unsigned int v);      // TEMPORARY DIAGNOSTIC (MSKF_FE_CRUMBS=1)
 
 struct mskf_stream {
     mskf_ctx *ctx = nullptr;

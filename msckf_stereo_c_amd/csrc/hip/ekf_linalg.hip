@@ -1070,11 +1070,8 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
 // Householder compression of the streams in compression_mode 2 / 3 (the others leave at once)
 void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
     const int n1 = max_d - EKF_IMU_DIM + 1;
-    static const int variant = [] { const char *e = std::getenv("MSKF_TQ_VARIANT"); return e ? std::atoi(e) : 0; }();      // EXPERIMENT
-    if (n1 <= 2 * (TQ_THREADS / 4)) {
-        if (variant == 1) hipLaunchKernelGGL((k_ekf_tsqr<16, 2, 4>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
-        else hipLaunchKernelGGL((k_ekf_tsqr<32, 2, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
-    }
+    // (a 64-row block at 128 VGPRs - four waves per SIMD left for others - measured 1270 us alone against 810 and the same bench rate)
+    if (n1 <= 2 * (TQ_THREADS / 4)) hipLaunchKernelGGL((k_ekf_tsqr<32, 2, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
     else hipLaunchKernelGGL((k_ekf_tsqr<16, 4, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {

@@ -43,8 +43,7 @@ void ForkJoin::run(int n, const std::function<void(int)> &fn) {
     while (done_.load() < nt_ - 1) std::this_thread::yield();
 }
 
-BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads, int ekf_host_threads, int halves,
-                       mskf_ctx *fe_ctx, mskf_ctx *ekf_ctx) {
+BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads, int ekf_host_threads, int halves) {
     // per-stream host phases of a group are independent: optional helper threads for the front-end / filter stages
     const int ht_fe = std::max(1, host_threads), ht_ekf = std::max(1, ekf_host_threads > 0 ? ekf_host_threads : host_threads);
     if (ht_fe > 1) pool_.reset(new ForkJoin(ht_fe));
@@ -55,11 +54,8 @@ BatchGroup::BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe
     int nh = std::max(1, std::min(2, halves));
     if (n < 2) nh = 1;
     half_.resize(nh);
-    // (contexts made by the caller - MultiRunner decides the order in which the queues of all groups are created - are adopted)
-    int rc = MSKF_OK;
-    if (fe_ctx) half_[0].ctx = fe_ctx; else rc = mskf_ctx_create(device, &half_[0].ctx);
-    if (ekf_ctx) half_[0].ctx_ekf = ekf_ctx;
-    else if (rc == MSKF_OK) rc = mskf_ctx_create_prio(device, 1, &half_[0].ctx_ekf);     // the filter is the serial chain of a frame: its queue is dispatched first
+    int rc = mskf_ctx_create(device, &half_[0].ctx);
+    if (rc == MSKF_OK) rc = mskf_ctx_create_prio(device, 1, &half_[0].ctx_ekf);     // the filter is the serial chain of a frame: its queue is dispatched first
     for (int h = 1; h < nh && rc == MSKF_OK; ++h) {
         rc = mskf_ctx_create_shared(half_[0].ctx, &half_[h].ctx);
         if (rc == MSKF_OK) rc = mskf_ctx_create_shared(half_[0].ctx_ekf, &half_[h].ctx_ekf);
@@ -532,15 +528,7 @@ MultiRunner::MultiRunner(int device, int n_groups, int per_group, const mskf_cal
                          int host_threads, int ekf_host_threads, int halves)
     : n_groups_(n_groups), per_group_(per_group), off_(n_groups, 0), next_(n_groups, 0), win_(n_groups) {
     // A device offers 16 hardware queues before streams get multiplexed (GPU_MAX_HW_QUEUES): two per group, front-end and filter
-    // EXPERIMENT (not committed): order / priority of queue creation
-    const char *xo = std::getenv("MSKF_X_ORDER");
-    const int order = xo ? std::atoi(xo) : 0;      // 0 interleaved (FE, EKF per group), 1 all EKF first, 2 all FE first, 3 interleaved without priority, 4 all EKF first without priority
-    std::vector<mskf_ctx *> fc(n_groups, nullptr), ec(n_groups, nullptr);
-    const int prio = (order == 3 || order == 4) ? 0 : 1;
-    if (order == 1 || order == 4) { for (int g = 0; g < n_groups; ++g) mskf_ctx_create_prio(device, prio, &ec[g]); for (int g = 0; g < n_groups; ++g) mskf_ctx_create(device, &fc[g]); }
-    else if (order == 2) { for (int g = 0; g < n_groups; ++g) mskf_ctx_create(device, &fc[g]); for (int g = 0; g < n_groups; ++g) mskf_ctx_create_prio(device, prio, &ec[g]); }
-    else if (order == 3) { for (int g = 0; g < n_groups; ++g) { mskf_ctx_create(device, &fc[g]); mskf_ctx_create_prio(device, 0, &ec[g]); } }
-    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads, ekf_host_threads, halves, fc[g], ec[g]));
+    for (int g = 0; g < n_groups; ++g) groups_.emplace_back(new BatchGroup(device, per_group, calib, fe, ekf, host_threads, ekf_host_threads, halves));
 }
 
 MultiRunner::~MultiRunner() { groups_.clear(); }

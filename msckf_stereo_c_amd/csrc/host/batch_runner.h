@@ -84,8 +84,7 @@ class BatchGroup {
   public:
     // host_threads / ekf_host_threads: threads that share the per-stream host phases of the front-end / filter stage (0 = as
     // host_threads); halves = 2: two staggered half-batches per stage on contexts sharing the stage's HIP stream
-    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1, int ekf_host_threads = 0, int halves = 1,
-               mskf_ctx *fe_ctx = nullptr, mskf_ctx *ekf_ctx = nullptr);
+    BatchGroup(int device, int n, const mskf_calib &calib, const mskf_fe_cfg &fe, const mskf_ekf_cfg &ekf, int host_threads = 1, int ekf_host_threads = 0, int halves = 1);
     ~BatchGroup();
     bool ok() const { return ok_; }
     int size() const { return (int)systems_.size(); }

@@ -21,6 +21,8 @@ if [ "$WHAT" = lines ]; then
   timeout -k 10 300 python bench.py --no-cpu > "$OUT/bench_60_steps.json" 2>> "$OUT/log.txt" || exit 2
   timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --compression auto > "$OUT/bench_gram.json" 2>> "$OUT/log.txt" || exit 3
   timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --host-images > "$OUT/bench_host_images.json" 2>> "$OUT/log.txt" || exit 4
+  # the staging copies through hipMemcpyAsync (SDMA) as until the middle of round 4: may stall for a minute, never fails the collection
+  MSKF_SDMA_COPIES=1 MSKF_WAIT_TIMEOUT_S=100 timeout -k 10 150 python bench.py --no-cpu --steps 20 --warmup 5 > "$OUT/bench_sdma_copies.json" 2>> "$OUT/log.txt" || echo "sdma-copies run did not finish"
   echo "c2 variants done"
   timeout -k 10 400 python bench.py --config c3 > "$OUT/bench_c3.json" 2>> "$OUT/log.txt" || exit 5
   timeout -k 10 400 python bench.py --config c5 --unique 8 > "$OUT/bench_c5.json" 2>> "$OUT/log.txt" || exit 6
