@@ -421,7 +421,29 @@ __device__ __forceinline__ void ekf_compress_exit(const EkfStreamDev &S, bool gr
 // columns as tsqr_wide.
 #define TQ_THREADS 512
 // sum over the four DPP rows of a wavefront (lanes c, c + 16, c + 32, c + 48): every one of the four gets the same bits
-__device__ __forceinline__ double tq_rows_sum(double v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+// (v_permlane16_swap / v_permlane32_swap of gfx950 - a VALU operation each, where a ds_bpermute pays the LDS crossbar's latency
+//  twice per sum on the dependent chain of every reflector step: swapping a value with a copy of itself leaves row pairs (halves)
+//  side by side in the two registers.  All four lanes of a column must be active.)
+__device__ __forceinline__ double tq_rows_sum(double v) {
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false), hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        v = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));   // rows 0, 1: x0 + x1; rows 2, 3: x2 + x3
+    }
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false), hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        v = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+    }
+    return v;
+}
+// 1 / x to double precision without the division sequence: hardware estimate + two Newton steps (as rsqrt_nr, chol_block.h)
+__device__ __forceinline__ double tq_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
 // acc += x[lane C of this lane's DPP row] * a in ONE instruction (DP-ALU DPP, row_newbcast only).  Every lane of the wavefront must
 // be active: a source lane that EXEC disables counts as invalid and the lanes that read it would skip the operation.
 template <int C, bool FIRST> __device__ __forceinline__ void tq_fmac_bcast(double &acc, double x, double a) {
@@ -452,10 +474,12 @@ __device__ __forceinline__ void tq_form_reflector(const double (&bc)[RL], double
     const double ss = tq_rows_sum((p0 + p1) + (p2 + p3));
     const bool skip = ss < 1e-200 || ss < 1e-40 * (x0 * x0);           // (see tsqr_wide)
     if (!skip) {
-        const double nrm = sqrt(__builtin_fma(x0, x0, ss));
+        // (no sqrt / division sequences on the dependent chain: estimate + Newton steps, a few ulp)
+        const double n2 = __builtin_fma(x0, x0, ss);
+        const double nrm = n2 * rsqrt_nr(n2);
         const double alpha = x0 > 0.0 ? -nrm : nrm;
         const double v0 = x0 - alpha;
-        const double beta = 2.0 / __builtin_fma(v0, v0, ss);
+        const double beta = 2.0 * tq_rcp(__builtin_fma(v0, v0, ss));
 #pragma unroll
         for (int i = 0; i < RL; i += 2) *reinterpret_cast<double2 *>(sVs + r * RL + i) = make_double2(bc[i], bc[i + 1]);
         if (r == 0) { sVs[4 * RL] = v0; sVs[4 * RL + 1] = beta; *Rkk = alpha; }
@@ -506,18 +530,15 @@ __device__ __forceinline__ void tsqr_regs(const EkfStreamDev &S, int na, int K, 
         for (int k = 0; k < n1; ++k) {
             const int s = k & 1;
             const double *vs = sV + s * VS;
+            // (the reflector's copy is read whether it is live or not - a skipped step leaves stale numbers there that nothing
+            //  uses - so that the flag and the entries come back from LDS together instead of one round trip after the other)
+            double vr[VR];
+#pragma unroll
+            for (int m = 0; m < VR; ++m) vr[m] = vs[r * RL + 16 * m + c];
+            const double v0 = vs[BR], beta = vs[BR + 1];
             const bool live = __builtin_amdgcn_readfirstlane(sFlag[s]) != 0;       // (uniform: the whole workgroup reads the same word)
 #pragma unroll
             for (int t = 0; t < NC; ++t) { const int j = 16 * wave + c + SLAB * t; rc[t] = (has[t] && k + 2 < n1) ? Rg[(size_t)(k + 2) * ld + j] : 0.0; }
-            double vr[VR];
-            double v0 = 0.0, beta = 0.0;
-#pragma unroll
-            for (int m = 0; m < VR; ++m) vr[m] = 0.0;
-            if (live) {
-#pragma unroll
-                for (int m = 0; m < VR; ++m) vr[m] = vs[r * RL + 16 * m + c];
-                v0 = vs[BR]; beta = vs[BR + 1];
-            }
             // reflector k onto the 16 columns of slab t of this wavefront (all 64 lanes: the DPP broadcasts need their source lanes)
             auto apply = [&](double (&bc)[RL], double rkj, int j, bool on) {
                 double p[4] = {0.0, 0.0, 0.0, 0.0};
@@ -550,6 +571,53 @@ __device__ __forceinline__ void tsqr_regs(const EkfStreamDev &S, int na, int K, 
 #pragma unroll
             for (int t = 0; t < NC; ++t) { ra[t] = rb[t]; rb[t] = rc[t]; }
             __syncthreads();
+        }
+    }
+}
+// The same scheme for ONE wavefront and a narrow stack (n1 <= 16 NC columns: the fused small update, n1 <= 25): lane (r, c) holds
+// rows [r RL, (r + 1) RL) of a 4 RL-row block for the columns c + 16 t; R (n1 x n1, row-major with stride ldr) and the reflector
+// (4 RL + 2 doubles, sVw) live in LDS of the wavefront's own - no workgroup barrier anywhere: the LDS operations of one wavefront
+// execute in program order.  Reduces the blocks first, first + stride, .. < n_blocks into R (which the caller has zeroed or
+// filled); load(block, row in block, column) delivers the entries (0 outside the stack).  Every lane of the wavefront calls it.
+template <int RL, int NC, class Load>
+__device__ __forceinline__ void tsqr_wave(int n1, int n_blocks, int first, int stride, Load load, double *R, int ldr, double *sVw, int *sFlagw) {
+    constexpr int BR = 4 * RL, VR = RL / 16;
+    const int lane = threadIdx.x & 63, r = lane >> 4, c = lane & 15;
+    for (int blk = first; blk < n_blocks; blk += stride) {
+        double b[NC][RL];
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+#pragma unroll
+            for (int t = 0; t < NC; ++t) b[t][i] = load(blk, r * RL + i, c + 16 * t);
+        }
+        for (int k = 0; k < n1; ++k) {
+            const int tk = k >> 4, ck = k & 15;
+#pragma unroll
+            for (int t = 0; t < NC; ++t)
+                if (tk == t && c == ck) tq_form_reflector<RL>(b[t], R[k * ldr + k], sVw, sFlagw, R + k * ldr + k, r);
+            __builtin_amdgcn_wave_barrier();
+            double vr[VR];
+#pragma unroll
+            for (int m = 0; m < VR; ++m) vr[m] = sVw[r * RL + 16 * m + c];
+            const double v0 = sVw[BR], beta = sVw[BR + 1];
+            const bool live = __builtin_amdgcn_readfirstlane(*sFlagw) != 0;
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    if (16 * t + 15 > k && 16 * t < n1) {           // (uniform: the slab still has columns right of k)
+                        const int j = c + 16 * t;
+                        const bool on = j < n1 && j > k;
+                        const double rkj = on ? R[k * ldr + j] : 0.0;
+                        double p[4] = {0.0, 0.0, 0.0, 0.0};
+                        TqDot<RL>::run(p, vr, b[t]);
+                        const double dot = tq_rows_sum((p[0] + p[1]) + (p[2] + p[3]));
+                        const double tt = on ? beta * __builtin_fma(v0, rkj, dot) : 0.0;
+                        TqAxpy<RL>::run(b[t], vr, -tt);
+                        if (on && r == 0) R[k * ldr + j] = __builtin_fma(-tt, v0, rkj);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -897,6 +965,10 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
     __syncthreads();
     // ---- 1. Gram matrix: pairs (i >= j) over the threads; with few pairs (the pruning update: 91) the threads also split
     //         the rows of a chunk into `groups` interleaved sets, summed in a fixed order at the end
+    // (the Householder modes never use the Gram matrix: steps 1 and 2 are skipped for them and the TSQR of step 2b runs at once)
+    const bool hh_only = ekf_mode_householder(S.qr_mode);
+    if (tid == 0) s_lam = 0.0;
+    if (!hh_only) {
     const int np = n1 * (n1 + 1) / 2;
     const int groups = np <= 128 ? 256 / np : 1;
     int pi[2], pj[2], pg[2];
@@ -963,11 +1035,13 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         }
         __syncthreads();
     }
+    }   // !hh_only
     // ---- 2b. the same decision as ekf_compress_exit: bias flag, no more stacked rows than columns, or forced ->
     //          Householder TSQR of the stacked rows, R in sG (full rows), then L = R^T back in place
     {
         __shared__ int s_tiny, s_bias;
-        if (tid == 0) {
+        if (tid == 0 && hh_only) { s_tiny = 0; s_bias = 0; }
+        if (tid == 0 && !hh_only) {
             int t = 0;
             double pm = 0;
             for (int i = 0; i < na; ++i) {
@@ -984,8 +1058,42 @@ __global__ __launch_bounds__(256) void k_ekf_small_update(const EkfStreamDev *st
         if (need_qr) {
             for (int e = tid; e < n1 * n1; e += 256) sG[e] = 0.0;
             __syncthreads();
-            static_assert(SU_CH == 8 * 16, "the fused update's row block is eight lanes x sixteen rows per column");
-            tsqr_wide<8, 16>(S, n1, K, [&](int c, int &col, int &clone) { col = s_col[c]; clone = s_clone[c]; }, [=](int k, int j) -> double & { return sG[k * n1 + j]; }, sC);
+            // Round 4, second half: a TSQR TREE over the four wavefronts.  The stack is tall and narrow here (the pruning update: up to
+            // 1500 rows x 13 columns): every wavefront reduces its own 128-row blocks (w, w + 4, ..) into an R of its own with the
+            // row block in registers (tsqr_wave: no workgroup barrier), then wavefront 0 annihilates the other three R's (3 n1 rows:
+            // one more block) against its own, which is sG.  (Before: tsqr_wide<8, 16>, all 256 threads on one block at a time with a
+            // workgroup barrier per reflector and the block in LDS: 250-320 us of the kernel's 310-470.)
+            static_assert(SU_CH == 128 && SU_MAX_NA + 1 <= 32, "tsqr_wave<32, 2>: 128-row blocks, two 16-column slabs");
+            {
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                double *sRw = sC;                                   // [3][n1][n1]: the R's of wavefronts 1..3
+                double *sVq = (double *)(((uintptr_t)(sC + 3 * n1 * n1) + 15) & ~(uintptr_t)15);    // [4][130]: the wavefronts' reflector buffers (16-byte accesses)
+                int *sFq = (int *)(sVq + 4 * 130);                  // [4]
+                for (int e = tid; e < 3 * n1 * n1; e += 256) sRw[e] = 0.0;
+                __syncthreads();
+                const unsigned long long *rowmask = S.rowmask;
+                const double *Hs = S.Hs;
+                auto loadH = [&](int blk, int row, int col) -> double {
+                    const int gk = blk * 128 + row;
+                    if (gk >= K || col >= n1) return 0.0;
+                    const unsigned long long rm = rowmask[gk];
+                    const int cl = s_clone[col];
+                    const bool on = cl < 0 ? rm != 0ULL : ((rm >> cl) & 1ULL) != 0ULL;
+                    return on ? Hs[(size_t)gk * ld + s_col[col]] : 0.0;
+                };
+                double *Rmine = wv == 0 ? sG : sRw + (wv - 1) * n1 * n1;
+                tsqr_wave<32, 2>(n1, (K + 127) / 128, wv, 4, loadH, Rmine, n1, sVq + wv * 130, sFq + wv);
+                __syncthreads();
+                if (wv == 0) {
+                    auto loadR = [&](int, int row, int col) -> double {
+                        if (row >= 3 * n1 || col >= n1) return 0.0;
+                        const int w2 = row / n1, rr = row - w2 * n1;
+                        return col >= rr ? sRw[(w2 * n1 + rr) * n1 + col] : 0.0;
+                    };
+                    tsqr_wave<32, 2>(n1, 1, 0, 1, loadR, sG, n1, sVq, sFq);
+                }
+                __syncthreads();
+            }
             for (int e = tid; e < n1 * n1; e += 256) { const int i = e / n1, j = e - i * n1; if (j < i) sG[e] = sG[j * n1 + i]; }
             __syncthreads();
         }
