@@ -366,10 +366,10 @@ def rehearse(args, rank, world):
     elapsed, frames = aggregate_throughput(time.perf_counter() - t0, len(mine) * args.steps, world, device="cpu")
     hashes = gather_hashes(0x5EED if os.environ.get("MSKF_REHEARSE_CORRUPT_RANK") != str(rank) else 0xBAD, world, "cpu")
     if rank == 0:
-        print(json.dumps({"metric": "rehearsal of the rank plumbing (no device work, not a measurement)", "rehearsal": True,
+        emit(json.dumps({"metric": "rehearsal of the rank plumbing (no device work, not a measurement)", "rehearsal": True,
                           "value": frames / elapsed, "unit": "stub frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed * 1e3 / args.steps, "streams_total": int(frames / args.steps),
-                          "id_mismatch": sum(1 for h in hashes if h != hashes[0])}), flush=True)
+                          "id_mismatch": sum(1 for h in hashes if h != hashes[0])}))
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -385,6 +385,25 @@ def progress(rank, what):
         sys.stderr.flush()
 
 
+_JSON_OUT = None
+
+
+def keep_stdout_clean():
+    """The contract is ONE JSON line on stdout: everything else that writes to file descriptor 1 (c10d's "[Gloo] Rank 0 is connected
+    ..." line, RCCL / runtime chatter) is sent to stderr; the line itself goes out through a duplicate of the original descriptor."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _JSON_OUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -396,6 +415,7 @@ def main(argv=None):
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let bench.py spawn them)\n" % (args.gpus, world))
         return 2
+    keep_stdout_clean()
     if args.rehearse:
         return rehearse(args, rank, world)
     # Every group runs a front-end and a filter thread that wait for the GPU between phases.  Spinning in those waits is the
@@ -756,7 +776,7 @@ def main(argv=None):
         if out.get("pose_within_tolerance") is False:
             failed.append("pose_within_tolerance %s" % json.dumps(out["pose_err_vs_cpu_ref"]))
         out["checks_failed"] = failed
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
         if failed:
             sys.stderr.write("bench.py: RESULT CHECKS FAILED: %s\n" % "; ".join(failed))
             status = 1

@@ -16,22 +16,24 @@ export TMPDIR=/tmp
 SOLO="python bench.py --no-cpu --steps 6 --warmup 2 --streams 192 --groups 1 --no-pipeline --gram-steps 0"     # one 192-stream launch per kernel: the benched launch shape
 SOLO3="python bench.py --config c3 --no-cpu --steps 6 --warmup 2 --streams 16 --groups 1 --no-pipeline --gram-steps 0"
 if [ "$WHAT" = lines ]; then
+  # (most important first: a collection that runs out of box time still has the head of the list)
   timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>> "$OUT/log.txt" || exit 1
   echo "driver command done" ; cut -c1-160 "$OUT/bench_driver_cmd.json"
   timeout -k 10 300 python bench.py --no-cpu > "$OUT/bench_60_steps.json" 2>> "$OUT/log.txt" || exit 2
   timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --compression auto > "$OUT/bench_gram.json" 2>> "$OUT/log.txt" || exit 3
-  timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --host-images > "$OUT/bench_host_images.json" 2>> "$OUT/log.txt" || exit 4
-  # the staging copies through hipMemcpyAsync (SDMA) as until the middle of round 4: may stall for a minute, never fails the collection
-  MSKF_SDMA_COPIES=1 MSKF_WAIT_TIMEOUT_S=100 timeout -k 10 150 python bench.py --no-cpu --steps 20 --warmup 5 > "$OUT/bench_sdma_copies.json" 2>> "$OUT/log.txt" || echo "sdma-copies run did not finish"
+  # configs[4] is ONE 4K stream per GPU: the single-stream line
+  timeout -k 10 300 python bench.py --config c5 --streams 1 --groups 1 --no-cpu --steps 20 --warmup 5 > "$OUT/bench_c5_1stream.json" 2>> "$OUT/log.txt" || exit 6
   echo "c2 variants done"
   timeout -k 10 400 python bench.py --config c3 > "$OUT/bench_c3.json" 2>> "$OUT/log.txt" || exit 5
   timeout -k 10 400 python bench.py --config c5 --unique 8 > "$OUT/bench_c5.json" 2>> "$OUT/log.txt" || exit 6
-  # configs[4] is ONE 4K stream per GPU: the single-stream line (and eight streams in one batch)
-  timeout -k 10 300 python bench.py --config c5 --streams 1 --groups 1 --no-cpu --steps 20 --warmup 5 > "$OUT/bench_c5_1stream.json" 2>> "$OUT/log.txt" || exit 6
-  timeout -k 10 300 python bench.py --config c5 --streams 8 --groups 1 --no-cpu --steps 20 --warmup 5 > "$OUT/bench_c5_8streams.json" 2>> "$OUT/log.txt" || exit 6
   echo "c3 c5 done"
   # two ranks (gloo) sharing the box's one GPU at the DEFAULT preset: what the host share costs when ranks multiply
   timeout -k 10 400 python bench.py --gpus 2 --backend gloo --no-cpu --steps 20 --warmup 5 > "$OUT/bench_2rank_gloo_one_gpu.json" 2>> "$OUT/log.txt" || exit 7
+  echo "2 ranks done"
+  timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 5 --host-images > "$OUT/bench_host_images.json" 2>> "$OUT/log.txt" || exit 4
+  timeout -k 10 300 python bench.py --config c5 --streams 8 --groups 1 --no-cpu --steps 20 --warmup 5 > "$OUT/bench_c5_8streams.json" 2>> "$OUT/log.txt" || exit 6
+  # the staging copies through hipMemcpyAsync (SDMA) as until the middle of round 4: may stall for a minute, never fails the collection
+  MSKF_SDMA_COPIES=1 MSKF_WAIT_TIMEOUT_S=100 timeout -k 10 150 python bench.py --no-cpu --steps 20 --warmup 5 > "$OUT/bench_sdma_copies.json" 2>> "$OUT/log.txt" || echo "sdma-copies run did not finish"
   echo "all lines done"
 else
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --no-cpu --steps 20 --warmup 5 --gram-steps 0 > "$OUT/bench_under_rocprof.json" 2>> "$OUT/log.txt" || exit 2
