@@ -48,6 +48,8 @@ PMC_TRAFFIC_FILE = _profile("pmc_hbm_traffic")
 PMC_SQ_FILE = _profile("pmc_sq")
 PMC_MFMA_FILE = _profile("pmc_mfma_c2")
 
+PROFILE_NAMES = {"k_pyr_down": "k_pyr_down3", "k_ekf_small": "k_ekf_small_update"}    # timing entry -> kernel name in the counter summaries
+
 COMPRESSION_MODES = {"auto": 0, "gram": 1, "tsqr": 2, "householder": 3}      # mskf_ekf_cfg.compression_mode (include/mskf_types.h)
 
 # BASELINE.json configs: image, clone window, grid rows x cols x min x max, streams per GPU, groups
@@ -622,10 +624,12 @@ def main(argv=None):
                 dom = single
         ms, launches, units = timing[dom]
         avg_s = max(ms * 1e-3 / max(launches, 1), 1e-12)
-        if dom in ("k_ekf_feature_blocks", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_qr"):
+        if dom in ("k_ekf_feature_blocks", "k_ekf_gemm", "k_ekf_chol_lds", "k_ekf_trsm", "k_ekf_tsqr"):
             achieved = units / max(launches, 1) / avg_s / 1e12           # units = algorithmic FP64 flops
             roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None}
+            if dom == "k_ekf_tsqr":
+                roof["note"] = "a chain of Householder reflectors on the FP64 vector units, priced against the FP64 peak (vector = matrix = 78.6 TFLOP/s on MI355X)"
         else:
             # k_pyr_down (one launch for levels 1..3): level 0 read once + the three levels written = (64 / 21 + 1) bytes per output pixel
             per_unit = {"k_track4": LK_BYTES_PER_TRACK, "k_pyr_down": 64.0 / 21.0 + 1.0, "k_detect_cells": 1}.get(dom, 0)
@@ -636,7 +640,7 @@ def main(argv=None):
         # separately); only comparable when a launch covers the same number of streams
         try:
             pmc_all = json.load(open(PMC_TRAFFIC_FILE))
-            pmc = pmc_all["kernels"].get(dom)
+            pmc = pmc_all["kernels"].get(PROFILE_NAMES.get(dom, dom))
             spl = pmc_all.get("streams_per_launch", 96)
             if pmc and args.config == pmc_all.get("config", "c2"):
                 # every stream of a launch reads its own images: traffic per launch is proportional to the streams in it
@@ -653,7 +657,7 @@ def main(argv=None):
         # (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, collected at `streams_per_launch` streams, scaled to this run's launches).
         try:
             sq_all = json.load(open(PMC_SQ_FILE))
-            sq = sq_all["kernels"].get(dom)
+            sq = sq_all["kernels"].get(PROFILE_NAMES.get(dom, dom))
             spl = sq_all.get("streams_per_launch", 96)
             if sq and args.config == sq_all.get("config", "c2"):
                 wave_insts = sq["valu_insts_per_wave"] * sq["waves_per_dispatch"] * per_group / spl

@@ -17,7 +17,7 @@ void ekf_launch_posvar(const EkfStreamDev *d, int n, double *out, hipStream_t st
 void ekf_launch_posvar_upd(const EkfStreamDev *d, int n, hipStream_t st);
 void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStream_t st);
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st);
-void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
+void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, int do_cap, hipStream_t st);
 void ekf_launch_trsm(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 void ekf_launch_small_update(const EkfStreamDev *d, int n, int max_d, hipStream_t st);
 int ekf_small_update_max_na(void);
@@ -696,13 +696,17 @@ extern "C" int mskf_ekf_update_batch_begin(mskf_ctx *ctx, int n, mskf_stream *co
         if (any_general) {
             // QR compression as Gram + semidefinite Cholesky (Householder TSQR inside the factorisation kernel for the
             // streams that need it), then the Kalman update (ekf_linalg.hip); small-route streams leave these at once
-            ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
-            ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
-            mskf_t_end(ctx, ts, (long long)fl_qr);
+            if (any_gram) {
+                // (also the first dense kernel of the general route: its tiles work out the stacking decision for every stream)
+                ts = mskf_t_begin(ctx, MSKF_K_EKF_GEMM);
+                ekf_launch_gemm(ctx->ekf_desc.d, n, GM_GRAM, max_d + 1, st);
+                mskf_t_end(ctx, ts, (long long)fl_qr);
+            }
             if (any_householder) {
-                // Householder TSQR of the streams in compression_mode 2 / 3 (a kernel without LDS of its own: ekf_linalg.hip)
+                // Householder TSQR of the streams in compression_mode 2 / 3 (a kernel without LDS of its own: ekf_linalg.hip); with no
+                // Gram launch before it, it is the first dense kernel and makes the stacking decision itself
                 ts = mskf_t_begin(ctx, MSKF_K_EKF_TSQR);
-                ekf_launch_tsqr(ctx->ekf_desc.d, n, max_d, st);
+                ekf_launch_tsqr(ctx->ekf_desc.d, n, max_d, any_gram ? 0 : 1, st);
                 mskf_t_end(ctx, ts, (long long)fl_qr);
             }
             if (any_gram) {

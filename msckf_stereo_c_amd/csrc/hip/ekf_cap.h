@@ -5,14 +5,15 @@
 // Gram pass: 17 us of work that cost 300 us as one more launch of the update's chain in the busy device.  Now
 //   * the feature kernels write the rowmask of their own rows (what a row carries: the clone bits of a block that passed
 //     the gate, 0 otherwise), and
-//   * every workgroup of the FIRST dense kernel of the stream's route - k_ekf_gemm<GRAM> (its tiles) or k_ekf_small_update -
+//   * every workgroup of the FIRST dense kernel of the stream's route - k_ekf_gemm<GRAM> (its tiles), k_ekf_small_update, or
+//     k_ekf_tsqr when no stream of the batch needs a Gram matrix (then the Gram launch does not happen at all) -
 //     computes the stacking decision for itself from the features' gate results: the passing blocks are stacked in feature
 //     order until the stacked rows exceed the cap (the block that crosses it is still stacked, :1006-1009), which gives the
 //     stacked row count, the end of the last stacked block (the K range of the Gram pass), the clones the stack touches
 //     (active columns) and the first feature behind the cap.  Integer work on a few hundred features: every workgroup gets
 //     the same answer, no workgroup waits for another.  ONE workgroup per stream (publish = true) also writes it down for
 //     the kernels that follow: rows_out[0..4], the active column list, and the gate bits / masks of the capped features.
-// All 256 threads of the workgroup call it.
+// All NT threads of the workgroup call it (256; 512 in k_ekf_tsqr).
 #pragma once
 #include "ekf_device.h"
 
@@ -31,8 +32,8 @@ __device__ __forceinline__ int ekf_act_column(unsigned long long clones, int i) 
     return EKF_IMU_DIM + 6 * (int)__builtin_ctzll(m) + i % 6;
 }
 
+template <int NT = 256>          // threads of the calling workgroup
 __device__ __forceinline__ EkfCapResult ekf_cap_local(const EkfStreamDev &S, bool publish) {
-    constexpr int NT = 256;
     __shared__ int s_sum[NT], s_cross[NT];
     __shared__ unsigned long long s_or[NT / 64];
     __shared__ int s_cap_from, s_tot[2];

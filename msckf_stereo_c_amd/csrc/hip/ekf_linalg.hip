@@ -621,11 +621,14 @@ __device__ __forceinline__ void tsqr_wave(int n1, int n_blocks, int first, int s
         }
     }
 }
+// do_cap: this is the first dense kernel of the route (no stream of the batch needs a Gram matrix, so k_ekf_gemm<GRAM> was not
+// launched): the stacking decision (ekf_cap.h) is worked out and written down here.
 template <int RL, int NC, int WPE>
-__global__ __launch_bounds__(TQ_THREADS, WPE) void k_ekf_tsqr(const EkfStreamDev *streams) {
+__global__ __launch_bounds__(TQ_THREADS, WPE) void k_ekf_tsqr(const EkfStreamDev *streams, int do_cap) {
     const EkfStreamDev &S = streams[blockIdx.y];
     if (S.n_feat <= 0 || (S.route & EKF_ROUTE_SMALL)) return;
     if (!ekf_mode_householder(S.qr_mode)) return;                 // the Gram route's streams: k_ekf_chol_lds / k_ekf_chol (which = 0)
+    if (do_cap) { (void)ekf_cap_local<TQ_THREADS>(S, true); __syncthreads(); }
     __shared__ int s_w[TQ_THREADS / 64];
     __shared__ __attribute__((aligned(16))) double sV[2 * (4 * RL + 2)];
     __shared__ int sFlag[2];
@@ -1176,11 +1179,11 @@ void ekf_launch_gemm(const EkfStreamDev *d, int n, int mode, int max_mn, hipStre
     }
 }
 // Householder compression of the streams in compression_mode 2 / 3 (the others leave at once)
-void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, hipStream_t st) {
+void ekf_launch_tsqr(const EkfStreamDev *d, int n, int max_d, int do_cap, hipStream_t st) {
     const int n1 = max_d - EKF_IMU_DIM + 1;
     // (a 64-row block at 128 VGPRs - four waves per SIMD left for others - measured 1270 us alone against 810 and the same bench rate)
-    if (n1 <= 2 * (TQ_THREADS / 4)) hipLaunchKernelGGL((k_ekf_tsqr<32, 2, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
-    else hipLaunchKernelGGL((k_ekf_tsqr<16, 4, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d);
+    if (n1 <= 2 * (TQ_THREADS / 4)) hipLaunchKernelGGL((k_ekf_tsqr<32, 2, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d, do_cap);
+    else hipLaunchKernelGGL((k_ekf_tsqr<16, 4, 2>), dim3(1, n), dim3(TQ_THREADS), 0, st, d, do_cap);
 }
 void ekf_launch_chol(const EkfStreamDev *d, int n, int which, int max_d, hipStream_t st) {
     const int nt = max_d - EKF_IMU_DIM + 1;

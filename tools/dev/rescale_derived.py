@@ -1,0 +1,31 @@
+"""The bench lines of profiles/r04_* (except the driver-command line) were collected while profiles/r04_pmc_sq.json and
+r04_pmc_mfma_c2.json did not yet say how many streams a profiled launch covered (192); bench.py then assumed round 3's 96 and
+doubled the fields it DERIVES from those static summaries (roofline.valu_issue, mfma.executed_*).  This recomputes exactly those
+fields from the committed summaries and the line's own measured launch time; nothing measured is touched.
+usage: tools/dev/rescale_derived.py <line.json> ..."""
+import json, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq.json")))
+for f in sys.argv[1:]:
+    d = None
+    for line in open(f):
+        if line.strip().startswith("{"):
+            d = json.loads(line)
+    if d is None or "[c2]" not in d["config"]["workload"]:
+        continue
+    changed = False
+    vi = d.get("roofline", {}).get("valu_issue")
+    k = sq["kernels"].get({"k_pyr_down": "k_pyr_down3"}.get(d["roofline"]["kernel"], d["roofline"]["kernel"]))
+    if vi and k and abs(vi["waves_per_launch"] / k["waves_per_dispatch"] - 2.0) < 0.05:
+        for key in ("waves_per_launch", "achieved", "frac", "insts_per_point_track"):
+            if key in vi:
+                vi[key] /= 2.0
+        changed = True
+    mm = d.get("mfma")
+    if changed and mm and "executed_gflop_per_launch" in mm:
+        for key in ("executed_gflop_per_launch", "executed_tflops", "executed_frac"):
+            mm[key] /= 2.0
+    if changed:
+        d["derived_fields_recomputed"] = "roofline.valu_issue and mfma.executed_* recomputed with streams_per_launch = 192 (tools/dev/rescale_derived.py)"
+        json.dump(d, open(f, "w"))
+        print("rescaled", f, round(vi["insts_per_point_track"]) if "insts_per_point_track" in vi else "")

@@ -24,6 +24,7 @@ FP64_PEAK_TFLOPS = 78.6
 
 def main():
     path, out, cmd = sys.argv[1:4]
+    spl = int(sys.argv[4]) if len(sys.argv) > 4 else 192      # streams per launch of the profiled command
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     dur = collections.defaultdict(float)
     seen = set()
@@ -38,7 +39,7 @@ def main():
             seen.add(r["Dispatch_Id"])
             cnt[k] += 1
             dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-    res = {"command": cmd, "note": __doc__.split("Counters:")[1].strip(), "fp64_matrix_peak_tflops": FP64_PEAK_TFLOPS, "kernels": {}}
+    res = {"command": cmd, "streams_per_launch": spl, "note": __doc__.split("Counters:")[1].strip(), "fp64_matrix_peak_tflops": FP64_PEAK_TFLOPS, "kernels": {}}
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU_MFMA_MOPS_F64"]):
         if a["SQ_INSTS_MFMA"] <= 0:
             continue

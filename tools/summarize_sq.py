@@ -15,6 +15,7 @@ import sys
 
 def main():
     path, out, cmd = sys.argv[1:4]
+    spl = int(sys.argv[4]) if len(sys.argv) > 4 else 192      # streams per launch of the profiled command
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     seen, cnt = set(), collections.Counter()
     for r in csv.DictReader(open(path)):
@@ -26,7 +27,7 @@ def main():
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
             cnt[k] += 1
-    res = {"command": cmd, "note": "per kernel, averaged over its dispatches; *_pct are shares of the waves' resident cycles", "kernels": {}}
+    res = {"command": cmd, "streams_per_launch": spl, "note": "per kernel, averaged over its dispatches; *_pct are shares of the waves' resident cycles", "kernels": {}}
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
         w, wc = max(a["SQ_WAVES"], 1.0), max(a["SQ_WAVE_CYCLES"], 1.0)
         res["kernels"][k] = {
