@@ -283,6 +283,8 @@ extern "C" int mskf_ekf_propagate_imu(mskf_stream *s, int n_steps, const mskf_im
 extern "C" int mskf_ekf_predict_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *n_steps,
                                       const mskf_imu_step *const *steps, const double *const *J) {
     if (!ctx || n <= 0 || !streams || !n_steps || !steps || !J) return MSKF_ERR_INVALID;
+    // (the position-variance read-out works out of the same pinned arena, its kernel reads its descriptors there: not before its _end)
+    if (ctx->pend_pv.active) { mskf_set_error("a position-variance read-out of this context is still pending"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     size_t bytes = align_up(sizeof(EkfStreamDev) * (size_t)n, 64);
@@ -414,6 +416,7 @@ extern "C" int mskf_ekf_augment(mskf_stream *s, const double *J) {
 
 extern "C" int mskf_ekf_remove_clones_batch(mskf_ctx *ctx, int n, mskf_stream *const *streams, const int32_t *idx) {
     if (!ctx || n <= 0 || !streams || !idx) return MSKF_ERR_INVALID;
+    if (ctx->pend_pv.active) { mskf_set_error("a position-variance read-out of this context is still pending"); return MSKF_ERR_INVALID; }
     MSKF_HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t bytes = sizeof(EkfStreamDev) * (size_t)n;
