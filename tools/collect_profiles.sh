@@ -7,7 +7,7 @@
 #   tools/collect_profiles.sh <out dir under gpurun_out/> counters   the driver's command under rocprofv3 --kernel-trace --stats
 #                                                                    and the PMC passes (each counter group in its own run,
 #                                                                    python directly after "--")
-# Summaries are made afterwards with tools/summarize_{pmc,sq,mfma}.py and tools/trace_busy.py and copied to profiles/.
+# The counter summaries (tools/summarize_{pmc,sq,mfma}.py) land in <out dir>/summaries/ and are copied to profiles/rNN_*.json by hand.
 set -o pipefail
 OUT=gpurun_out/${1:-prof}
 WHAT=${2:-lines}
@@ -50,5 +50,11 @@ else
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES --output-format csv -d "$OUT/pmc_mfma_c3" -- $SOLO3 > /dev/null 2>> "$OUT/log.txt" || exit 7
   echo "mfma done"
   rm -f "$OUT"/pmc_*/*/*_kernel_trace.csv
+  # the summaries bench.py reads (copy them to profiles/rNN_*.json); they record the launch shape themselves
+  mkdir -p "$OUT/summaries"
+  python tools/summarize_pmc.py "$OUT"/pmc_fetch/*/*_counter_collection.csv "$OUT"/pmc_write/*/*_counter_collection.csv "$OUT/summaries/pmc_hbm_traffic.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- $SOLO" 192 > /dev/null
+  python tools/summarize_sq.py "$OUT"/pmc_sq/*/*_counter_collection.csv "$OUT/summaries/pmc_sq.json" "rocprofv3 --kernel-trace --pmc SQ_* -- $SOLO" 192 > /dev/null
+  python tools/summarize_mfma.py "$OUT"/pmc_mfma_c2/*/*_counter_collection.csv "$OUT/summaries/pmc_mfma_c2.json" "rocprofv3 --kernel-trace --pmc (matrix-core counters) -- $SOLO" 192 > /dev/null
+  python tools/summarize_mfma.py "$OUT"/pmc_mfma_c3/*/*_counter_collection.csv "$OUT/summaries/pmc_mfma_c3.json" "rocprofv3 --kernel-trace --pmc (matrix-core counters) -- $SOLO3" 16 > /dev/null
   echo "all counters done"
 fi
