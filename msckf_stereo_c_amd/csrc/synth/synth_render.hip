@@ -39,9 +39,9 @@ int synth_hip_render(const synth::RenderImg *imgs_host, int n_imgs, const float 
                      uint8_t *out_dev, size_t frame_bytes, void *stream) {
     if (!imgs_host || n_imgs <= 0 || !rays0_dev || !rays1_dev || !out_dev || width <= 0 || height <= 0 || (frame_bytes & 3) || frame_bytes < (size_t)width * height) return -1;
     hipStream_t st = (hipStream_t)stream;
-    // the records go through a pinned staging block of the library's own: an asynchronous copy straight from the caller's pageable
-    // memory (a numpy array) makes the runtime pin those pages in place, and a pinned mapping of memory the Python heap later
-    // reuses or the kernel migrates has to be torn down by the driver with every queue of the process stopped
+    // the records go through a pinned staging block of the library's own rather than straight from the caller's pageable memory (a
+    // numpy array), which the runtime would have to pin in place for an asynchronous copy.  (Suspected for a while of the bench's
+    // multi-second stalls in round 4; those were the SDMA staging copies of the pipeline itself)
     const size_t pbytes = sizeof(synth::RenderImg) * (size_t)n_imgs;
     synth::RenderImg *d = nullptr, *hp = nullptr;
     if (hipHostMalloc((void **)&hp, pbytes, hipHostMallocDefault) != hipSuccess) return -2;
